@@ -1,0 +1,194 @@
+#!/usr/bin/env python3
+"""bench.py — ECG windows/s of the full train step (fwd + BCE + bwd + AdamW) on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[2]/[3]): ECGMultimodal, 12x1000 fp32 synthetic
+windows, batch 256 PER GPU (weak scaling), inputs resident in HBM, driven through the
+reference's own loop API (src.training.loop_demo.train_one_epoch_demo) with the flat AdamW;
+with N > 1 the gradient exchange is one RCCL all-reduce of the flat 3 MB gradient per step.
+Rank 0 prints ONE JSON line.  After the timed region a second, event-instrumented pass gives
+live per-kernel durations for the `roofline` object; at N=1 the CPU oracle ("port") is timed
+on the host cores for `cpu_baseline`.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "ptbxl-multimodal_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import torch  # noqa: E402
+
+PEAK_F32_TFLOPS = 157.3      # MI355X_MICROARCH.md: fp32 vector == fp32 MFMA peak
+PEAK_HBM_GBS = 8000.0
+CONV_GEOM = [(12, 32), (32, 64), (64, 128), (128, 256)]
+
+
+class ListLoader:
+    """The loop API only needs iteration and len(loader.dataset)."""
+
+    def __init__(self, batch, steps):
+        self.batch, self.steps = batch, steps
+        self.dataset = range(batch[0].shape[0] * steps)
+
+    def __iter__(self):
+        return iter([self.batch] * self.steps)
+
+    def __len__(self):
+        return self.steps
+
+
+def conv_flops_per_window(T):
+    """Algorithmic conv flops of one window: fwd, and the train step (fwd + wgrad + dgrad
+    without block 0's dgrad) — SURVEY §8(d)."""
+    L, fwd, step = T, 0.0, 0.0
+    for i, (ci, co) in enumerate(CONV_GEOM):
+        f = 2.0 * co * ci * 15 * L
+        fwd += f
+        step += f * (3 if i > 0 else 2)
+        L //= 2
+    return fwd, step
+
+
+def kernel_roofline(timings, B):
+    """Pick the entry point with the largest total time in the instrumented pass and price it."""
+    best, total_ms = None, 0.0
+    per = {}
+    for (name, sig), ms in timings.items():
+        per[(name, sig)] = (sum(ms) / len(ms), len(ms))
+        total_ms += sum(ms)
+    agg = sorted(per.items(), key=lambda kv: -kv[1][0] * kv[1][1])
+    (name, sig), (avg_ms, cnt) = agg[0]
+    out = {"kernel": f"{name}{list(sig)}", "avg_ms": round(avg_ms, 4)}
+    if name in ("ecg_conv1d_fwd", "ecg_conv1d_bwd_data", "ecg_conv1d_bwd_weight_bias"):
+        N, ci, co, Lc, K, pad = sig[-6:]
+        flops = 2.0 * N * co * ci * K * (Lc + 2 * pad - K + 1)
+        bytes_ = 4.0 * N * Lc * (ci + co) + 4.0 * co * ci * K
+        ach = flops / (avg_ms * 1e-3) / 1e12
+        out.update({"bound": "mfma", "achieved": round(ach, 3), "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(ach / PEAK_F32_TFLOPS, 4), "traffic": None,
+                    "algorithmic_flops": flops, "algorithmic_bytes": bytes_,
+                    "hbm_frac_of_algorithmic_bytes": round(bytes_ / (avg_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 5),
+                    "note": "fp32 conv: arithmetic intensity 65-615 flop/B vs ridge 20 -> fp32 MFMA/FMA peak binds, not HBM"})
+    else:
+        out.update({"bound": "hbm", "achieved": None, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": None, "traffic": None})
+    breakdown = [{"kernel": f"{n}{list(s)}", "avg_ms": round(a, 4), "calls": c} for (n, s), (a, c) in agg[:12]]
+    return out, breakdown, total_ms
+
+
+def cpu_baseline(B, T, seconds):
+    """The oracle (stock-torch CPU restatement of the reference loop body) on the host cores."""
+    from oracle import ref_models as R
+    R.seed_all(42)
+    model = R.RefECGMultimodal().train()
+    opt = R.make_adamw(model, 1e-4, 1e-4)
+    batch = R.synthetic_batch(B, T, 5, demo=True)
+    R.train_step(model, opt, batch)                     # warm-up
+    n, t0 = 0, time.perf_counter()
+    while True:
+        R.train_step(model, opt, batch)
+        n += 1
+        dt = time.perf_counter() - t0
+        if dt >= seconds or n >= 200:
+            break
+    return {"value": round(B * n / dt, 1), "unit": "windows/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"oracle/ref_models.py train_step (stock torch CPU ops), ECGMultimodal B={B} 12x{T}, {n} steps in {dt:.1f}s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--batch", type=int, default=256, help="windows per GPU")
+    ap.add_argument("--length", type=int, default=1000)
+    ap.add_argument("--model", choices=["multimodal", "cnn"], default="multimodal")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    from ecg_hip import _lib, ddp
+    from ecg_hip.optim import FlatAdamW
+    from src.models.ecg_cnn import ECGCNN
+    from src.models.ecg_multimodal import ECGMultimodal
+    from src.training.loop import train_one_epoch
+    from src.training.loop_demo import train_one_epoch_demo
+    from src.utils.seed import set_seed
+
+    rank, world, local = ddp.init_distributed("nccl")
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    _lib.load()
+    _lib.call("ecg_check_device")
+
+    B, T = args.batch, args.length
+    set_seed(42)
+    demo = args.model == "multimodal"
+    model = (ECGMultimodal() if demo else ECGCNN(num_labels=5)).to(dev)
+    if world > 1:
+        ddp.broadcast_module_state(model, 0)
+    opt = FlatAdamW(model.parameters(), lr=1e-4, weight_decay=1e-4)
+    g = torch.Generator().manual_seed(1234 + rank)            # each rank its own shard of the global batch
+    x = torch.randn(B, 12, T, generator=g).to(dev)
+    y = (torch.rand(B, 5, generator=g) < 0.3).float().to(dev)
+    batch = (x, torch.rand(B, 5, generator=g).to(dev), y) if demo else (x, y)
+    run = train_one_epoch_demo if demo else train_one_epoch
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    run(model, ListLoader(batch, args.warmup), opt, dev)
+    barrier()
+    t0 = time.perf_counter()
+    last_loss = run(model, ListLoader(batch, args.steps), opt, dev)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        elapsed = t.item()
+
+    # instrumented pass (HIP events around every ABI launch on the launch stream)
+    with _lib.kernel_timing() as kt:
+        run(model, ListLoader(batch, min(args.steps, 10)), opt, dev)
+    roof, breakdown, instr_ms = kernel_roofline(kt.result, B)
+
+    if rank == 0:
+        value = world * B * args.steps / elapsed
+        fwd_f, step_f = conv_flops_per_window(T)
+        line = {
+            "metric": "ECG windows/s (train step) at 12x1000, batch 256", "value": round(value, 1), "unit": "windows/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{'ECGMultimodal (FiLM)' if demo else 'ECGCNN(5)'} train step fwd+BCE+bwd+AdamW, "
+                                   f"12x{T} fp32, batch {B}/GPU, global batch {B * world}",
+                       "global_batch": B * world, "parallelism": f"dp{world}", "loop": "src.training API + FlatAdamW",
+                       "final_loss": round(float(last_loss), 6)},
+            "step_conv_tflops": round(value * step_f / 1e12, 2),
+            "step_frac_of_fp32_peak": round(value * step_f / 1e12 / (PEAK_F32_TFLOPS * world), 4),
+            "roofline": roof, "kernel_breakdown": breakdown,
+            "instrumented_ms_per_step": round(instr_ms / min(args.steps, 10), 4),
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(B, T, args.cpu_seconds)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,185 @@
+/*
+ * ecg_hip.h — C ABI of libecg_hip.so: the MI355X (gfx950) kernels behind the
+ * ptbxl-multimodal 1D-CNN train/eval path.
+ *
+ * The reference (cyu0330/ptbxl-multimodal) has no FFI of its own: its boundary is the
+ * Python API of src/models + src/training, and below that stock torch.nn modules
+ * dispatching to ATen.  Each entry point here replaces the ATen work dispatched by one
+ * reference call site (cited per function as <reference file>:<line>); the Python
+ * host (ptbxl-multimodal_amd/ecg_hip/) binds them with ctypes from inside
+ * torch.autograd.Function.forward/backward.  See INTEGRATION.md for the binding.
+ *
+ * Conventions
+ *   - All tensors are device pointers to contiguous float32 unless noted; activations
+ *     are NCL.  The library never allocates or frees tensor memory: outputs and
+ *     workspaces are caller-owned (query the *_ws_floats() helpers for sizes).
+ *   - Every entry point returns 0 on success and a nonzero ECG_E* code otherwise; the
+ *     message is available from ecg_last_error() (thread-local).  No exception crosses
+ *     the ABI.  Shapes are validated on the host before any launch.
+ *   - Entry points are re-entrant, keep no global mutable state and launch on the
+ *     stream handed in (a hipStream_t passed as void*; NULL = the null stream).  They
+ *     never synchronise the device.  Forward is called on the Python main thread,
+ *     backward on torch's autograd engine thread.
+ *   - Conv1d support envelope: stride 1, dilation 1, groups 1, 1 <= K <= 31,
+ *     0 <= pad < K (the reference uses K=15, pad=7 only: src/models/ecg_cnn.py:13).
+ */
+#ifndef ECG_HIP_H
+#define ECG_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void *ecg_stream_t; /* hipStream_t */
+
+enum {
+    ECG_OK = 0,
+    ECG_EINVAL = 1,   /* bad shape / null pointer / unsupported configuration */
+    ECG_ELAUNCH = 2,  /* hipGetLastError() after a launch */
+    ECG_ENODEV = 3    /* no gfx950 device visible */
+};
+
+/* ABI version, 100*major + minor. */
+int ecg_version(void);
+/* Message of the last nonzero return on the calling thread ("" if none). */
+const char *ecg_last_error(void);
+/* 0 if device 0..n-1 is a gfx950 the code object can run on, ECG_ENODEV otherwise. */
+int ecg_check_device(void);
+
+/* ------------------------------------------------------------------------------------
+ * Conv1d — replaces aten::convolution / aten::convolution_backward dispatched by
+ * ConvBlock.net[0] = nn.Conv1d(in,out,k,padding=k//2): src/models/ecg_cnn.py:13,
+ * src/models/ecg_multimodal.py:9 (backward via loss.backward(), src/training/loop.py:33).
+ * ---------------------------------------------------------------------------------- */
+
+/* Packed weights: w [C_out][C_in][K] (state_dict layout) ->
+ *   w_fwd [K][C_in][C_out]            (forward operand)
+ *   w_bwd [K][C_out][C_in], tap-flipped: w_bwd[k][co][ci] = w[co][ci][K-1-k]  (input-grad operand)
+ * Either output may be NULL.  Each holds C_out*C_in*K floats. */
+int ecg_conv1d_pack_weights(const float *w, float *w_fwd, float *w_bwd,
+                            int C_out, int C_in, int K, ecg_stream_t stream);
+
+/* Number P of per-channel (sum, sum-of-squares) partials ecg_conv1d_fwd writes per output
+ * channel for this shape; stat_partials must hold C_out*P*2 floats. */
+int ecg_conv1d_fwd_stat_partials(int N, int C_in, int C_out, int L, int K, int pad);
+
+/* y[n,co,t] = bias[co] + sum_ci sum_k w[co,ci,k] * x[n,ci,t+k-pad]   (zero padding)
+ * x [N][C_in][L], w_fwd packed as above, bias [C_out] or NULL, y [N][C_out][Lo],
+ * Lo = L + 2*pad - K + 1.
+ * stat_partials (nullable): [C_out][P][2] per-producer (sum y, sum y^2) over the producer's
+ * outputs, consumed by ecg_bn_finalize (train-mode BatchNorm statistics fused in the epilogue). */
+int ecg_conv1d_fwd(const float *x, const float *w_fwd, const float *bias, float *y,
+                   float *stat_partials, int N, int C_in, int C_out, int L, int K, int pad,
+                   ecg_stream_t stream);
+
+/* dx[n,ci,s] = sum_co sum_k dy[n,co,s-k+pad] * w[co,ci,k];  dy [N][C_out][Lo], dx [N][C_in][L] */
+int ecg_conv1d_bwd_data(const float *dy, const float *w_bwd, float *dx,
+                        int N, int C_in, int C_out, int L, int K, int pad, ecg_stream_t stream);
+
+/* Workspace (floats) for ecg_conv1d_bwd_weight_bias. */
+size_t ecg_conv1d_bwd_weight_ws_floats(int N, int C_in, int C_out, int L, int K, int pad);
+/* dw[co,ci,k] = sum_n sum_t dy[n,co,t]*x[n,ci,t+k-pad] (state_dict layout [C_out][C_in][K]);
+ * db[co] = sum_n sum_t dy[n,co,t] (nullable).  Deterministic: split partial slabs in ws are
+ * summed in a fixed order, no float atomics. */
+int ecg_conv1d_bwd_weight_bias(const float *dy, const float *x, float *dw, float *db, float *ws,
+                               int N, int C_in, int C_out, int L, int K, int pad,
+                               ecg_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * BatchNorm1d / ReLU / MaxPool1d(2) — ConvBlock.net[1..3]: src/models/ecg_cnn.py:14-16.
+ * ---------------------------------------------------------------------------------- */
+
+/* Standalone statistics partials of y [N][C][L] in the same [C][P][2] layout
+ * (used when the conv epilogue did not produce them). Returns P via the helper. */
+int ecg_bn_stat_partials_count(int N, int C, int L);
+int ecg_bn_stat_partials(const float *y, float *stat_partials, int N, int C, int L,
+                         ecg_stream_t stream);
+
+/* Train-mode statistics from partials (summed in double, fixed order):
+ * mean, biased var -> invstd = 1/sqrt(var+eps);  running_mean/var (nullable) updated with
+ * `momentum` and the UNBIASED variance;  *num_batches_tracked (nullable, device int64) += 1. */
+int ecg_bn_finalize(const float *stat_partials, int P, long long count,
+                    float *mean, float *invstd, float *running_mean, float *running_var,
+                    long long *num_batches_tracked, int C, float momentum, float eps,
+                    ecg_stream_t stream);
+
+/* invstd[c] = 1/sqrt(var[c] + eps)  (eval mode: from running_var) */
+int ecg_bn_invstd(const float *var, float *invstd, int C, float eps, ecg_stream_t stream);
+
+/* p[n,c,j] = max(0, max(a[2j], a[2j+1])),  a = (y-mean)*(invstd*gamma)+beta,  Lp = L/2 */
+int ecg_bn_relu_pool_fwd(const float *y, const float *gamma, const float *beta,
+                         const float *mean, const float *invstd, float *p,
+                         int N, int C, int L, ecg_stream_t stream);
+
+size_t ecg_bn_relu_pool_bwd_ws_floats(int N, int C, int L);
+/* Backward of the fused tail: dp [N][C][L/2] -> dy [N][C][L], dgamma[C], dbeta[C].
+ * Arg-max and ReLU mask are recomputed from y (first element wins a tie, as max_pool1d).
+ * train != 0: batch-statistics backward (native_batch_norm_backward);  train == 0: dy = da*gamma*invstd. */
+int ecg_bn_relu_pool_bwd(const float *y, const float *dp, const float *gamma, const float *beta,
+                         const float *mean, const float *invstd,
+                         float *dy, float *dgamma, float *dbeta, float *ws,
+                         int N, int C, int L, int train, ecg_stream_t stream);
+
+/* Unfused leaves (used when a caller hooks an inner module, e.g. Grad-CAM on net[0]:
+ * scripts/00_demo_inference.py:36-37). */
+int ecg_bn_apply_fwd(const float *y, const float *gamma, const float *beta, const float *mean,
+                     const float *invstd, float *out, int N, int C, int L, ecg_stream_t stream);
+size_t ecg_bn_bwd_ws_floats(int N, int C, int L);
+int ecg_bn_bwd(const float *y, const float *dout, const float *gamma, const float *mean,
+               const float *invstd, float *dy, float *dgamma, float *dbeta, float *ws,
+               int N, int C, int L, int train, ecg_stream_t stream);
+int ecg_relu_fwd(const float *x, float *out, size_t n, ecg_stream_t stream);
+int ecg_relu_bwd(const float *out, const float *dout, float *dx, size_t n, ecg_stream_t stream);
+int ecg_maxpool2_fwd(const float *x, float *p, int rows, int L, ecg_stream_t stream);
+int ecg_maxpool2_bwd(const float *x, const float *dp, float *dx, int rows, int L, ecg_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * Tail — AdaptiveAvgPool1d(1), Linear, FiLM, BCE-with-logits.
+ * ---------------------------------------------------------------------------------- */
+
+/* g[r] = mean_t p[r][t], r in [0, rows)  — src/models/ecg_cnn.py:46,62 */
+int ecg_gap_fwd(const float *p, float *g, int rows, int L, ecg_stream_t stream);
+int ecg_gap_bwd(const float *dg, float *dp, int rows, int L, ecg_stream_t stream);
+
+/* y[m,o] = act(b[o] + sum_i x[m,i]*w[o,i]);  act = ReLU if relu else identity.
+ * nn.Linear: src/models/ecg_cnn.py:47,50; src/models/ecg_multimodal.py:35,52-55,85-86 */
+int ecg_linear_fwd(const float *x, const float *w, const float *b, float *y,
+                   int M, int In, int Out, int relu, ecg_stream_t stream);
+size_t ecg_linear_bwd_ws_floats(int M, int In, int Out);
+/* dy is the gradient w.r.t. y (post-activation); y is only read when relu != 0.
+ * dx, dw, db are each nullable. */
+int ecg_linear_bwd(const float *x, const float *w, const float *y, const float *dy,
+                   float *dx, float *dw, float *db, float *ws,
+                   int M, int In, int Out, int relu, ecg_stream_t stream);
+
+/* zc = (1 + tanh(film[:, :F])) * z + film[:, F:]  — src/models/ecg_multimodal.py:92-96 */
+int ecg_film_fwd(const float *z, const float *film, float *zc, int M, int F, ecg_stream_t stream);
+int ecg_film_bwd(const float *z, const float *film, const float *dzc, float *dz, float *dfilm,
+                 int M, int F, ecg_stream_t stream);
+
+/* loss[0] = mean(max(x,0) - x*t + log1p(exp(-|x|)))  — src/training/loop.py:32, loop_demo.py:10,33
+ * dx (nullable) = (sigmoid(x) - t) / numel  (the gradient for d loss = 1). */
+int ecg_bce_logits_fwd(const float *x, const float *target, float *loss, float *dx,
+                       int numel, ecg_stream_t stream);
+/* prob = sigmoid(x) — src/training/loop.py:63 */
+int ecg_sigmoid_fwd(const float *x, float *prob, size_t n, ecg_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * Optimizer — torch.optim.AdamW defaults over one flat fp32 buffer
+ * (scripts/03_train_ecg_baseline.py:130-133).  grad_scale multiplies g first (1/world).
+ * ---------------------------------------------------------------------------------- */
+int ecg_adamw_step(float *p, const float *g, float *m, float *v, size_t n, int step,
+                   float lr, float beta1, float beta2, float eps, float weight_decay,
+                   float grad_scale, ecg_stream_t stream);
+
+/* Per-lead z-score of a window batch, (x-mean)/(std+1e-6) with population std —
+ * src/datasets/ptbxl.py:122-127.  x [rows][T] -> out [rows][T]. */
+int ecg_zscore_rows(const float *x, float *out, int rows, int T, ecg_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ECG_HIP_H */

@@ -1,0 +1,405 @@
+// bn_relu_pool.hip — BatchNorm1d statistics, the fused BatchNorm -> ReLU -> MaxPool1d(2) tail of
+// a ConvBlock and its backward, plus the unfused leaves.  All HBM-streaming kernels: one read of
+// the conv output, one write of the pooled activation (forward); backward recomputes the pool
+// arg-max and ReLU mask from the saved conv output instead of storing indices.
+//
+// Replaces ATen native_batch_norm(_backward), threshold(_backward), max_pool2d_with_indices
+// (_backward) behind ConvBlock.net[1..3] (reference src/models/ecg_cnn.py:14-16).
+#include "common.h"
+
+namespace ecg {
+
+constexpr int kBlock = 256;
+
+// ---------------------------------------------------------------------------------------
+// statistics
+// ---------------------------------------------------------------------------------------
+static int stat_splits(int N, int C) {
+    int s = cdiv(1024, C);
+    if (s > N) s = N;
+    if (s < 1) s = 1;
+    return s;
+}
+
+// partials[c][s][2] = (sum y, sum y^2) over n in split s.  grid = (C, S)
+__global__ __launch_bounds__(kBlock) void bn_stat_partials_kernel(
+    const float *__restrict__ y, float *__restrict__ partials, int N, int C, int L, int S) {
+    __shared__ float red[4][2];
+    const int c = blockIdx.x, s = blockIdx.y, tl = threadIdx.x;
+    const int n0 = (int)((long long)N * s / S), n1 = (int)((long long)N * (s + 1) / S);
+    float a = 0.f, q = 0.f;
+    for (int n = n0; n < n1; ++n) {
+        const float *r = y + ((size_t)n * C + c) * L;
+        for (int t = tl; t < L; t += kBlock) { float v = r[t]; a += v; q = __fmaf_rn(v, v, q); }
+    }
+    a = wave_sum(a); q = wave_sum(q);
+    if ((tl & 63) == 0) { red[tl >> 6][0] = a; red[tl >> 6][1] = q; }
+    __syncthreads();
+    if (tl < 2)
+        partials[((size_t)c * S + s) * 2 + tl] = red[0][tl] + red[1][tl] + red[2][tl] + red[3][tl];
+}
+
+// One wave per channel: double-precision, fixed-order combine of the P partials.
+__global__ __launch_bounds__(64) void bn_finalize_kernel(
+    const float *__restrict__ partials, int P, double count, float *__restrict__ mean,
+    float *__restrict__ invstd, float *__restrict__ running_mean, float *__restrict__ running_var,
+    long long *__restrict__ nbt, float momentum, float eps) {
+    const int c = blockIdx.x, lane = threadIdx.x;
+    double a = 0.0, q = 0.0;
+    for (int p = lane; p < P; p += 64) {
+        a += (double)partials[((size_t)c * P + p) * 2];
+        q += (double)partials[((size_t)c * P + p) * 2 + 1];
+    }
+    a = wave_sum(a); q = wave_sum(q);
+    if (lane == 0) {
+        double mu = a / count;
+        double var = q / count - mu * mu;
+        if (var < 0.0) var = 0.0;
+        mean[c] = (float)mu;
+        invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+        if (running_mean) {
+            double unb = count > 1.0 ? var * count / (count - 1.0) : var;
+            running_mean[c] = (float)((1.0 - momentum) * running_mean[c] + momentum * mu);
+            running_var[c] = (float)((1.0 - momentum) * running_var[c] + momentum * unb);
+        }
+        if (nbt && c == 0) *nbt += 1;
+    }
+}
+
+__global__ void bn_invstd_kernel(const float *__restrict__ var, float *__restrict__ invstd, int C,
+                                 float eps) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < C) invstd[c] = (float)(1.0 / sqrt((double)var[c] + (double)eps));
+}
+
+// ---------------------------------------------------------------------------------------
+// forward
+// ---------------------------------------------------------------------------------------
+// thread <-> pooled output; a wave reads 512 contiguous bytes of y and writes 256 of p.
+__global__ __launch_bounds__(kBlock) void bn_relu_pool_fwd_kernel(
+    const float *__restrict__ y, const float *__restrict__ gamma, const float *__restrict__ beta,
+    const float *__restrict__ mean, const float *__restrict__ invstd, float *__restrict__ p,
+    int C, int L, int Lp, size_t total) {
+    size_t idx = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    if (idx >= total) return;
+    size_t row = idx / Lp;
+    int j = (int)(idx - row * Lp);
+    int c = (int)(row % C);
+    float sc = invstd[c] * gamma[c], mu = mean[c], be = beta[c];
+    const float *r = y + row * L + 2 * j;
+    float a0 = bn_apply1(r[0], mu, sc, be), a1 = bn_apply1(r[1], mu, sc, be);
+    float m = a1 > a0 ? a1 : a0;
+    p[idx] = m > 0.f ? m : 0.f;
+}
+
+__global__ __launch_bounds__(kBlock) void bn_apply_fwd_kernel(
+    const float *__restrict__ y, const float *__restrict__ gamma, const float *__restrict__ beta,
+    const float *__restrict__ mean, const float *__restrict__ invstd, float *__restrict__ out,
+    int C, int L, size_t total) {
+    size_t idx = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    if (idx >= total) return;
+    int c = (int)((idx / L) % C);
+    out[idx] = bn_apply1(y[idx], mean[c], invstd[c] * gamma[c], beta[c]);
+}
+
+// ---------------------------------------------------------------------------------------
+// backward
+// ---------------------------------------------------------------------------------------
+// da for the pair (2j, 2j+1): returns the arg-max slot am (0/1) and whether the gradient passes.
+__device__ __forceinline__ bool pool_route(float y0, float y1, float mu, float sc, float be, int &am) {
+    float a0 = bn_apply1(y0, mu, sc, be), a1 = bn_apply1(y1, mu, sc, be);
+    am = a1 > a0 ? 1 : 0;          // first element wins a tie (max_pool1d keeps the first index)
+    return (am ? a1 : a0) > 0.f;   // ReLU backward: output > 0
+}
+
+// partials[c][s][2] = (sum da, sum da*xhat).  FUSED: da routed from dp through pool+ReLU;
+// otherwise da = dout (plain BatchNorm backward).  grid = (C, S)
+template <bool FUSED>
+__global__ __launch_bounds__(kBlock) void bn_bwd_reduce_kernel(
+    const float *__restrict__ y, const float *__restrict__ g, const float *__restrict__ gamma,
+    const float *__restrict__ beta, const float *__restrict__ mean,
+    const float *__restrict__ invstd, float *__restrict__ partials, int N, int C, int L, int S) {
+    __shared__ float red[4][2];
+    const int c = blockIdx.x, s = blockIdx.y, tl = threadIdx.x;
+    const int n0 = (int)((long long)N * s / S), n1 = (int)((long long)N * (s + 1) / S);
+    const float mu = mean[c], is = invstd[c], sc = is * gamma[c], be = FUSED ? beta[c] : 0.f;
+    const int Lp = L >> 1;
+    float a = 0.f, q = 0.f;
+    for (int n = n0; n < n1; ++n) {
+        const float *r = y + ((size_t)n * C + c) * L;
+        if (FUSED) {
+            const float *gr = g + ((size_t)n * C + c) * Lp;
+            for (int j = tl; j < Lp; j += kBlock) {
+                float y0 = r[2 * j], y1 = r[2 * j + 1];
+                int am;
+                if (pool_route(y0, y1, mu, sc, be, am)) {
+                    float d = gr[j];
+                    a += d;
+                    q = __fmaf_rn(d, ((am ? y1 : y0) - mu) * is, q);
+                }
+            }
+        } else {
+            const float *gr = g + ((size_t)n * C + c) * L;
+            for (int t = tl; t < L; t += kBlock) {
+                float d = gr[t];
+                a += d;
+                q = __fmaf_rn(d, (r[t] - mu) * is, q);
+            }
+        }
+    }
+    a = wave_sum(a); q = wave_sum(q);
+    if ((tl & 63) == 0) { red[tl >> 6][0] = a; red[tl >> 6][1] = q; }
+    __syncthreads();
+    if (tl < 2)
+        partials[((size_t)c * S + s) * 2 + tl] = red[0][tl] + red[1][tl] + red[2][tl] + red[3][tl];
+}
+
+// sums[c][0] = dbeta, sums[c][1] = dgamma (also written to dbeta/dgamma);  coef[c] = (k1, k2) =
+// (dbeta/M, dgamma/M) in train mode, (0, 0) in eval mode.
+__global__ __launch_bounds__(64) void bn_bwd_finalize_kernel(
+    const float *__restrict__ partials, int S, double M, float *__restrict__ dgamma,
+    float *__restrict__ dbeta, float *__restrict__ coef, int train) {
+    const int c = blockIdx.x, lane = threadIdx.x;
+    double a = 0.0, q = 0.0;
+    for (int p = lane; p < S; p += 64) {
+        a += (double)partials[((size_t)c * S + p) * 2];
+        q += (double)partials[((size_t)c * S + p) * 2 + 1];
+    }
+    a = wave_sum(a); q = wave_sum(q);
+    if (lane == 0) {
+        if (dbeta) dbeta[c] = (float)a;
+        if (dgamma) dgamma[c] = (float)q;
+        coef[2 * c] = train ? (float)(a / M) : 0.f;
+        coef[2 * c + 1] = train ? (float)(q / M) : 0.f;
+    }
+}
+
+// dy[t] = gamma*invstd * (da[t] - k1 - xhat[t]*k2).  thread <-> output pair (2j, 2j+1).
+template <bool FUSED>
+__global__ __launch_bounds__(kBlock) void bn_bwd_dx_kernel(
+    const float *__restrict__ y, const float *__restrict__ g, const float *__restrict__ gamma,
+    const float *__restrict__ beta, const float *__restrict__ mean,
+    const float *__restrict__ invstd, const float *__restrict__ coef, float *__restrict__ dy,
+    int C, int L, int Lh, size_t total) {
+    size_t idx = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    if (idx >= total) return;
+    size_t row = idx / Lh;
+    int j = (int)(idx - row * Lh);
+    int c = (int)(row % C);
+    const float mu = mean[c], is = invstd[c], ga = gamma[c], sc = is * ga;
+    const float k1 = coef[2 * c], k2 = coef[2 * c + 1], gi = ga * is;
+    const float *r = y + row * L;
+    float *d = dy + row * L;
+    const int t0 = 2 * j;
+    const bool has1 = t0 + 1 < L;
+    float y0 = r[t0], y1 = has1 ? r[t0 + 1] : 0.f;
+    float da0 = 0.f, da1 = 0.f;
+    if (FUSED) {
+        if (has1) {   // an odd tail sample never reaches the pool: da = 0
+            int am;
+            if (pool_route(y0, y1, mu, sc, beta[c], am)) {
+                float v = g[row * (size_t)(L >> 1) + j];
+                if (am) da1 = v; else da0 = v;
+            }
+        }
+    } else {
+        da0 = g[row * L + t0];
+        if (has1) da1 = g[row * L + t0 + 1];
+    }
+    d[t0] = gi * (da0 - k1 - (y0 - mu) * is * k2);
+    if (has1) d[t0 + 1] = gi * (da1 - k1 - (y1 - mu) * is * k2);
+}
+
+// ---------------------------------------------------------------------------------------
+// unfused ReLU / MaxPool leaves
+// ---------------------------------------------------------------------------------------
+__global__ void relu_fwd_kernel(const float *__restrict__ x, float *__restrict__ out, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { float v = x[i]; out[i] = v > 0.f ? v : 0.f; }
+}
+__global__ void relu_bwd_kernel(const float *__restrict__ out, const float *__restrict__ dout,
+                                float *__restrict__ dx, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dx[i] = out[i] > 0.f ? dout[i] : 0.f;
+}
+__global__ void maxpool2_fwd_kernel(const float *__restrict__ x, float *__restrict__ p, int L,
+                                    int Lp, size_t total) {
+    size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    size_t row = idx / Lp;
+    int j = (int)(idx - row * Lp);
+    const float *r = x + row * L + 2 * j;
+    p[idx] = r[1] > r[0] ? r[1] : r[0];
+}
+__global__ void maxpool2_bwd_kernel(const float *__restrict__ x, const float *__restrict__ dp,
+                                    float *__restrict__ dx, int L, int Lh, size_t total) {
+    size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    size_t row = idx / Lh;
+    int j = (int)(idx - row * Lh);
+    int t0 = 2 * j;
+    const float *r = x + row * L;
+    float *d = dx + row * L;
+    if (t0 + 1 < L) {
+        float v = dp[row * (size_t)(L >> 1) + j];
+        bool am = r[t0 + 1] > r[t0];
+        d[t0] = am ? 0.f : v;
+        d[t0 + 1] = am ? v : 0.f;
+    } else {
+        d[t0] = 0.f;
+    }
+}
+
+}  // namespace ecg
+
+using namespace ecg;
+
+static int check_ncl(const char *who, int N, int C, int L) {
+    ECG_REQUIRE(N > 0 && C > 0 && L > 0, "%s: N=%d C=%d L=%d must be > 0", who, N, C, L);
+    ECG_REQUIRE(C <= 65535 && N <= 65535, "%s: N/C exceed grid limits", who);
+    return ECG_OK;
+}
+
+ECG_API int ecg_bn_stat_partials_count(int N, int C, int L) { (void)L; return stat_splits(N, C); }
+
+ECG_API int ecg_bn_stat_partials(const float *y, float *stat_partials, int N, int C, int L,
+                                 ecg_stream_t stream) {
+    int rc = check_ncl("bn_stat_partials", N, C, L);
+    if (rc) return rc;
+    ECG_REQUIRE(y && stat_partials, "bn_stat_partials: null pointer");
+    int S = stat_splits(N, C);
+    hipLaunchKernelGGL(bn_stat_partials_kernel, dim3(C, S), dim3(kBlock), 0, as_stream(stream), y,
+                       stat_partials, N, C, L, S);
+    return check_launch("bn_stat_partials_kernel");
+}
+
+ECG_API int ecg_bn_finalize(const float *stat_partials, int P, long long count, float *mean,
+                            float *invstd, float *running_mean, float *running_var,
+                            long long *num_batches_tracked, int C, float momentum, float eps,
+                            ecg_stream_t stream) {
+    ECG_REQUIRE(stat_partials && mean && invstd, "bn_finalize: null pointer");
+    ECG_REQUIRE(P > 0 && C > 0 && count > 0, "bn_finalize: P=%d C=%d count=%lld", P, C, count);
+    ECG_REQUIRE((running_mean == nullptr) == (running_var == nullptr),
+                "bn_finalize: running_mean/var must both be given or both NULL");
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(64), 0, as_stream(stream), stat_partials,
+                       P, (double)count, mean, invstd, running_mean, running_var,
+                       num_batches_tracked, momentum, eps);
+    return check_launch("bn_finalize_kernel");
+}
+
+ECG_API int ecg_bn_invstd(const float *var, float *invstd, int C, float eps, ecg_stream_t stream) {
+    ECG_REQUIRE(var && invstd && C > 0, "bn_invstd: bad argument");
+    hipLaunchKernelGGL(bn_invstd_kernel, dim3(cdiv(C, 256)), dim3(256), 0, as_stream(stream), var,
+                       invstd, C, eps);
+    return check_launch("bn_invstd_kernel");
+}
+
+ECG_API int ecg_bn_relu_pool_fwd(const float *y, const float *gamma, const float *beta,
+                                 const float *mean, const float *invstd, float *p, int N, int C,
+                                 int L, ecg_stream_t stream) {
+    int rc = check_ncl("bn_relu_pool_fwd", N, C, L);
+    if (rc) return rc;
+    ECG_REQUIRE(y && gamma && beta && mean && invstd && p, "bn_relu_pool_fwd: null pointer");
+    const int Lp = L / 2;
+    if (Lp == 0) return ECG_OK;   // MaxPool1d(2) of a length-1 row is empty
+    size_t total = (size_t)N * C * Lp;
+    hipLaunchKernelGGL(bn_relu_pool_fwd_kernel, dim3(cdiv(total, kBlock)), dim3(kBlock), 0,
+                       as_stream(stream), y, gamma, beta, mean, invstd, p, C, L, Lp, total);
+    return check_launch("bn_relu_pool_fwd_kernel");
+}
+
+ECG_API size_t ecg_bn_relu_pool_bwd_ws_floats(int N, int C, int L) {
+    (void)L;
+    return (size_t)C * stat_splits(N, C) * 2 + (size_t)C * 2;
+}
+ECG_API size_t ecg_bn_bwd_ws_floats(int N, int C, int L) { return ecg_bn_relu_pool_bwd_ws_floats(N, C, L); }
+
+template <bool FUSED>
+static int bn_bwd_impl(const float *y, const float *g, const float *gamma, const float *beta,
+                       const float *mean, const float *invstd, float *dy, float *dgamma,
+                       float *dbeta, float *ws, int N, int C, int L, int train, hipStream_t st) {
+    const int S = stat_splits(N, C);
+    float *partials = ws, *coef = ws + (size_t)C * S * 2;
+    hipLaunchKernelGGL((bn_bwd_reduce_kernel<FUSED>), dim3(C, S), dim3(kBlock), 0, st, y, g, gamma,
+                       beta, mean, invstd, partials, N, C, L, S);
+    int rc = check_launch("bn_bwd_reduce_kernel");
+    if (rc) return rc;
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(64), 0, st, partials, S,
+                       (double)N * L, dgamma, dbeta, coef, train);
+    rc = check_launch("bn_bwd_finalize_kernel");
+    if (rc) return rc;
+    const int Lh = (L + 1) / 2;
+    size_t total = (size_t)N * C * Lh;
+    hipLaunchKernelGGL((bn_bwd_dx_kernel<FUSED>), dim3(cdiv(total, kBlock)), dim3(kBlock), 0, st, y,
+                       g, gamma, beta, mean, invstd, coef, dy, C, L, Lh, total);
+    return check_launch("bn_bwd_dx_kernel");
+}
+
+ECG_API int ecg_bn_relu_pool_bwd(const float *y, const float *dp, const float *gamma,
+                                 const float *beta, const float *mean, const float *invstd,
+                                 float *dy, float *dgamma, float *dbeta, float *ws, int N, int C,
+                                 int L, int train, ecg_stream_t stream) {
+    int rc = check_ncl("bn_relu_pool_bwd", N, C, L);
+    if (rc) return rc;
+    ECG_REQUIRE(y && gamma && beta && mean && invstd && dy && ws, "bn_relu_pool_bwd: null pointer");
+    ECG_REQUIRE(dp || L < 2, "bn_relu_pool_bwd: dp is NULL");
+    return bn_bwd_impl<true>(y, dp, gamma, beta, mean, invstd, dy, dgamma, dbeta, ws, N, C, L,
+                             train, as_stream(stream));
+}
+
+ECG_API int ecg_bn_apply_fwd(const float *y, const float *gamma, const float *beta,
+                             const float *mean, const float *invstd, float *out, int N, int C,
+                             int L, ecg_stream_t stream) {
+    int rc = check_ncl("bn_apply_fwd", N, C, L);
+    if (rc) return rc;
+    ECG_REQUIRE(y && gamma && beta && mean && invstd && out, "bn_apply_fwd: null pointer");
+    size_t total = (size_t)N * C * L;
+    hipLaunchKernelGGL(bn_apply_fwd_kernel, dim3(cdiv(total, kBlock)), dim3(kBlock), 0,
+                       as_stream(stream), y, gamma, beta, mean, invstd, out, C, L, total);
+    return check_launch("bn_apply_fwd_kernel");
+}
+
+ECG_API int ecg_bn_bwd(const float *y, const float *dout, const float *gamma, const float *mean,
+                       const float *invstd, float *dy, float *dgamma, float *dbeta, float *ws,
+                       int N, int C, int L, int train, ecg_stream_t stream) {
+    int rc = check_ncl("bn_bwd", N, C, L);
+    if (rc) return rc;
+    ECG_REQUIRE(y && dout && gamma && mean && invstd && dy && ws, "bn_bwd: null pointer");
+    return bn_bwd_impl<false>(y, dout, gamma, nullptr, mean, invstd, dy, dgamma, dbeta, ws, N, C, L,
+                              train, as_stream(stream));
+}
+
+ECG_API int ecg_relu_fwd(const float *x, float *out, size_t n, ecg_stream_t stream) {
+    ECG_REQUIRE(x && out, "relu_fwd: null pointer");
+    if (n == 0) return ECG_OK;
+    hipLaunchKernelGGL(relu_fwd_kernel, dim3(cdiv(n, 256)), dim3(256), 0, as_stream(stream), x, out, n);
+    return check_launch("relu_fwd_kernel");
+}
+ECG_API int ecg_relu_bwd(const float *out, const float *dout, float *dx, size_t n,
+                         ecg_stream_t stream) {
+    ECG_REQUIRE(out && dout && dx, "relu_bwd: null pointer");
+    if (n == 0) return ECG_OK;
+    hipLaunchKernelGGL(relu_bwd_kernel, dim3(cdiv(n, 256)), dim3(256), 0, as_stream(stream), out,
+                       dout, dx, n);
+    return check_launch("relu_bwd_kernel");
+}
+ECG_API int ecg_maxpool2_fwd(const float *x, float *p, int rows, int L, ecg_stream_t stream) {
+    ECG_REQUIRE(x && rows > 0 && L > 0, "maxpool2_fwd: bad argument");
+    int Lp = L / 2;
+    if (Lp == 0) return ECG_OK;
+    ECG_REQUIRE(p, "maxpool2_fwd: null output");
+    size_t total = (size_t)rows * Lp;
+    hipLaunchKernelGGL(maxpool2_fwd_kernel, dim3(cdiv(total, 256)), dim3(256), 0, as_stream(stream),
+                       x, p, L, Lp, total);
+    return check_launch("maxpool2_fwd_kernel");
+}
+ECG_API int ecg_maxpool2_bwd(const float *x, const float *dp, float *dx, int rows, int L,
+                             ecg_stream_t stream) {
+    ECG_REQUIRE(x && dx && rows > 0 && L > 0, "maxpool2_bwd: bad argument");
+    ECG_REQUIRE(dp || L < 2, "maxpool2_bwd: dp is NULL");
+    int Lh = (L + 1) / 2;
+    size_t total = (size_t)rows * Lh;
+    hipLaunchKernelGGL(maxpool2_bwd_kernel, dim3(cdiv(total, 256)), dim3(256), 0, as_stream(stream),
+                       x, dp, dx, L, Lh, total);
+    return check_launch("maxpool2_bwd_kernel");
+}

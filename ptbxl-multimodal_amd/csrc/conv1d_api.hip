@@ -1,0 +1,89 @@
+// conv1d_api.hip — C-ABI entry points for Conv1d and the shape dispatch between the
+// MFMA implicit-GEMM kernels (conv1d_mfma.hip) and the direct VALU kernels (conv1d_direct.hip).
+#include "common.h"
+
+namespace ecg {
+// conv1d_direct.hip
+int direct_fwd_stat_partials(int N, int Lo);
+int direct_fwd(const float *x, const float *wp, const float *bias, float *y, float *partials,
+               int N, int Cin, int Cout, int L, int K, int pad, hipStream_t st);
+size_t direct_wgrad_ws_floats(int N, int Cin, int Cout, int K);
+int direct_wgrad(const float *dy, const float *x, float *dw, float *db, float *ws, int N, int Cin,
+                 int Cout, int L, int K, int pad, hipStream_t st);
+int pack_weights(const float *w, float *w_fwd, float *w_bwd, int Co, int Ci, int K,
+                 hipStream_t st);
+// conv1d_mfma.hip
+bool mfma_fwd_supported(int Cin, int Cout, int K, int pad);
+int mfma_fwd_stat_partials(int N, int Cin, int Cout, int Lo);
+int mfma_fwd(const float *x, const float *wp, const float *bias, float *y, float *partials, int N,
+             int Cin, int Cout, int L, int K, int pad, hipStream_t st);
+bool mfma_wgrad_supported(int Cin, int Cout, int K, int pad);
+size_t mfma_wgrad_ws_floats(int N, int Cin, int Cout, int L, int K);
+int mfma_wgrad(const float *dy, const float *x, float *dw, float *db, float *ws, int N, int Cin,
+               int Cout, int L, int K, int pad, hipStream_t st);
+
+static int check_conv_shape(int N, int Cin, int Cout, int L, int K, int pad) {
+    ECG_REQUIRE(N > 0 && Cin > 0 && Cout > 0 && L > 0, "conv1d: N=%d C_in=%d C_out=%d L=%d must be > 0",
+                N, Cin, Cout, L);
+    ECG_REQUIRE(K >= 1 && K <= 31, "conv1d: kernel size %d outside [1,31]", K);
+    ECG_REQUIRE(pad >= 0 && pad < K, "conv1d: padding %d outside [0,K)", pad);
+    ECG_REQUIRE(L + 2 * pad - K + 1 > 0, "conv1d: empty output (L=%d K=%d pad=%d)", L, K, pad);
+    ECG_REQUIRE(N <= 65535, "conv1d: N=%d exceeds grid.z limit 65535", N);
+    return ECG_OK;
+}
+}  // namespace ecg
+
+using namespace ecg;
+
+ECG_API int ecg_conv1d_pack_weights(const float *w, float *w_fwd, float *w_bwd, int C_out,
+                                    int C_in, int K, ecg_stream_t stream) {
+    ECG_REQUIRE(w && (w_fwd || w_bwd), "pack_weights: null pointer");
+    ECG_REQUIRE(C_out > 0 && C_in > 0 && K >= 1 && K <= 31, "pack_weights: bad shape");
+    return pack_weights(w, w_fwd, w_bwd, C_out, C_in, K, as_stream(stream));
+}
+
+ECG_API int ecg_conv1d_fwd_stat_partials(int N, int C_in, int C_out, int L, int K, int pad) {
+    int Lo = L + 2 * pad - K + 1;
+    if (mfma_fwd_supported(C_in, C_out, K, pad)) return mfma_fwd_stat_partials(N, C_in, C_out, Lo);
+    return direct_fwd_stat_partials(N, Lo);
+}
+
+ECG_API int ecg_conv1d_fwd(const float *x, const float *w_fwd, const float *bias, float *y,
+                           float *stat_partials, int N, int C_in, int C_out, int L, int K, int pad,
+                           ecg_stream_t stream) {
+    int rc = check_conv_shape(N, C_in, C_out, L, K, pad);
+    if (rc) return rc;
+    ECG_REQUIRE(x && w_fwd && y, "conv1d_fwd: null pointer");
+    if (mfma_fwd_supported(C_in, C_out, K, pad))
+        return mfma_fwd(x, w_fwd, bias, y, stat_partials, N, C_in, C_out, L, K, pad, as_stream(stream));
+    return direct_fwd(x, w_fwd, bias, y, stat_partials, N, C_in, C_out, L, K, pad, as_stream(stream));
+}
+
+// Input gradient = forward conv of dy with the tap-flipped, channel-transposed weights
+// (w_bwd [K][C_out][C_in]) and padding K-1-pad: roles of C_in / C_out swap.
+ECG_API int ecg_conv1d_bwd_data(const float *dy, const float *w_bwd, float *dx, int N, int C_in,
+                                int C_out, int L, int K, int pad, ecg_stream_t stream) {
+    int rc = check_conv_shape(N, C_in, C_out, L, K, pad);
+    if (rc) return rc;
+    ECG_REQUIRE(dy && w_bwd && dx, "conv1d_bwd_data: null pointer");
+    const int Lo = L + 2 * pad - K + 1, padb = K - 1 - pad;
+    if (mfma_fwd_supported(C_out, C_in, K, padb))
+        return mfma_fwd(dy, w_bwd, nullptr, dx, nullptr, N, C_out, C_in, Lo, K, padb, as_stream(stream));
+    return direct_fwd(dy, w_bwd, nullptr, dx, nullptr, N, C_out, C_in, Lo, K, padb, as_stream(stream));
+}
+
+ECG_API size_t ecg_conv1d_bwd_weight_ws_floats(int N, int C_in, int C_out, int L, int K, int pad) {
+    if (mfma_wgrad_supported(C_in, C_out, K, pad)) return mfma_wgrad_ws_floats(N, C_in, C_out, L, K);
+    return direct_wgrad_ws_floats(N, C_in, C_out, K);
+}
+
+ECG_API int ecg_conv1d_bwd_weight_bias(const float *dy, const float *x, float *dw, float *db,
+                                       float *ws, int N, int C_in, int C_out, int L, int K, int pad,
+                                       ecg_stream_t stream) {
+    int rc = check_conv_shape(N, C_in, C_out, L, K, pad);
+    if (rc) return rc;
+    ECG_REQUIRE(dy && x && dw && ws, "conv1d_bwd_weight_bias: null pointer");
+    if (mfma_wgrad_supported(C_in, C_out, K, pad))
+        return mfma_wgrad(dy, x, dw, db, ws, N, C_in, C_out, L, K, pad, as_stream(stream));
+    return direct_wgrad(dy, x, dw, db, ws, N, C_in, C_out, L, K, pad, as_stream(stream));
+}

@@ -1,0 +1,313 @@
+// conv1d_direct.hip — im2col-free direct Conv1d (forward / input-grad / weight-grad) on the
+// fp32 VALU for gfx950.  This is the shape-generic path (any C_in/C_out, 1 <= K <= 31);
+// the MFMA implicit-GEMM kernels in conv1d_mfma.hip take over the block geometries of the
+// ECG backbone.
+//
+// Replaces the ATen work behind ConvBlock.net[0] (reference src/models/ecg_cnn.py:13) and its
+// autograd (src/training/loop.py:33).
+//
+// Data layout: activations NCL fp32, so the (N*C, L) view is row-contiguous and every wave
+// reads/writes 256 contiguous bytes of one row.  Weights are consumed in the packed
+// [K][C_in][C_out] form (ecg_conv1d_pack_weights): for a fixed (tap, ci) the C_out values a
+// workgroup needs are contiguous and wave-uniform, so they arrive through the scalar cache
+// (s_load_dwordx8/x16) and feed v_fma_f32 as SGPR operands — one LDS read of x feeds CO_T FMAs.
+#include "common.h"
+
+namespace ecg {
+
+constexpr int kTT = 256;      // outputs (t) per workgroup = threads per workgroup
+constexpr int kKMax = 31;
+constexpr int kCiChunk = 8;   // input channels staged in LDS per pass
+
+// ---------------------------------------------------------------------------------------
+__global__ void pack_weights_kernel(const float *__restrict__ w, float *__restrict__ w_fwd,
+                                    float *__restrict__ w_bwd, int Co, int Ci, int K) {
+    int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    int total = Co * Ci * K;
+    if (idx >= total) return;
+    int k = idx % K;
+    int ci = (idx / K) % Ci;
+    int co = idx / (K * Ci);
+    float v = w[idx];
+    if (w_fwd) w_fwd[((size_t)k * Ci + ci) * Co + co] = v;
+    if (w_bwd) w_bwd[((size_t)(K - 1 - k) * Co + co) * Ci + ci] = v;
+}
+
+// ---------------------------------------------------------------------------------------
+// y[n,co,t] = bias[co] + sum_{ci,k} wp[k][ci][co] * x[n,ci,t+k-pad]
+// grid = (ceil(Lo/256), Cout/CO_T, N); block = 256 (thread <-> t).
+template <int CO_T, bool STATS>
+__global__ __launch_bounds__(kTT) void conv1d_direct_kernel(
+    const float *__restrict__ x, const float *__restrict__ wp, const float *__restrict__ bias,
+    float *__restrict__ y, float *__restrict__ partials, int Cin, int Cout, int L, int Lo, int K,
+    int pad, int P) {
+    __shared__ float xs[kCiChunk][kTT + kKMax - 1];
+    __shared__ float red[4][CO_T * 2];
+
+    const int tl = threadIdx.x;
+    const int t0 = blockIdx.x * kTT;
+    const int co0 = blockIdx.y * CO_T;
+    const int n = blockIdx.z;
+    const int span = kTT + K - 1;
+
+    float acc[CO_T];
+#pragma unroll
+    for (int j = 0; j < CO_T; ++j) acc[j] = 0.f;
+
+    const float *xn = x + (size_t)n * Cin * L;
+    for (int ci0 = 0; ci0 < Cin; ci0 += kCiChunk) {
+        const int nci = min(kCiChunk, Cin - ci0);
+        // stage x[n, ci0:ci0+nci, t0-pad : t0-pad+span) with zero padding; lanes walk t
+        for (int c = 0; c < nci; ++c) {
+            const float *xr = xn + (size_t)(ci0 + c) * L;
+            for (int i = tl; i < span; i += kTT) {
+                int s = t0 - pad + i;
+                xs[c][i] = (s >= 0 && s < L) ? xr[s] : 0.f;
+            }
+        }
+        __syncthreads();
+        for (int c = 0; c < nci; ++c) {
+            for (int k = 0; k < K; ++k) {
+                const float xv = xs[c][tl + k];
+                const float *wr = wp + ((size_t)k * Cin + (ci0 + c)) * Cout + co0;  // wave-uniform
+#pragma unroll
+                for (int j = 0; j < CO_T; ++j) acc[j] = __fmaf_rn(wr[j], xv, acc[j]);
+            }
+        }
+        __syncthreads();
+    }
+
+    const int t = t0 + tl;
+    const bool valid = t < Lo;
+#pragma unroll
+    for (int j = 0; j < CO_T; ++j) {
+        if (bias) acc[j] += bias[co0 + j];
+        if (valid) y[((size_t)n * Cout + co0 + j) * Lo + t] = acc[j];
+    }
+
+    if (STATS) {
+        // per-workgroup (sum, sum^2) per channel -> partials[co][pidx][2]
+        const int wave = tl >> 6, lane = tl & 63;
+#pragma unroll
+        for (int j = 0; j < CO_T; ++j) {
+            float v = valid ? acc[j] : 0.f;
+            float s = wave_sum(v), q = wave_sum(v * v);
+            if (lane == 0) { red[wave][2 * j] = s; red[wave][2 * j + 1] = q; }
+        }
+        __syncthreads();
+        if (tl < CO_T * 2) {
+            float s = red[0][tl] + red[1][tl] + red[2][tl] + red[3][tl];
+            int j = tl >> 1;
+            int pidx = n * gridDim.x + blockIdx.x;
+            partials[((size_t)(co0 + j) * P + pidx) * 2 + (tl & 1)] = s;
+        }
+    }
+}
+
+static int pick_co_tile(int Cout) {
+    for (int c : {16, 8, 4, 2}) if (Cout % c == 0) return c;
+    return 1;
+}
+
+template <bool STATS>
+static void launch_direct(const float *x, const float *wp, const float *bias, float *y,
+                          float *partials, int N, int Cin, int Cout, int L, int Lo, int K, int pad,
+                          int P, hipStream_t st) {
+    int cot = pick_co_tile(Cout);
+    dim3 grid(cdiv(Lo, kTT), Cout / cot, N), block(kTT);
+#define ECG_LAUNCH(CT) \
+    hipLaunchKernelGGL((conv1d_direct_kernel<CT, STATS>), grid, block, 0, st, x, wp, bias, y, \
+                       partials, Cin, Cout, L, Lo, K, pad, P)
+    switch (cot) {
+        case 16: ECG_LAUNCH(16); break;
+        case 8: ECG_LAUNCH(8); break;
+        case 4: ECG_LAUNCH(4); break;
+        case 2: ECG_LAUNCH(2); break;
+        default: ECG_LAUNCH(1); break;
+    }
+#undef ECG_LAUNCH
+}
+
+int direct_fwd_stat_partials(int N, int Lo) { return N * cdiv(Lo, kTT); }
+
+int direct_fwd(const float *x, const float *wp, const float *bias, float *y, float *partials,
+               int N, int Cin, int Cout, int L, int K, int pad, hipStream_t st) {
+    const int Lo = L + 2 * pad - K + 1;
+    const int P = direct_fwd_stat_partials(N, Lo);
+    if (partials)
+        launch_direct<true>(x, wp, bias, y, partials, N, Cin, Cout, L, Lo, K, pad, P, st);
+    else
+        launch_direct<false>(x, wp, bias, y, nullptr, N, Cin, Cout, L, Lo, K, pad, P, st);
+    return check_launch("conv1d_direct_kernel");
+}
+
+// ---------------------------------------------------------------------------------------
+// Weight gradient, direct form.  thread <-> t (the reduction axis lives on the lanes), each
+// thread keeps CO_R x KK accumulators; the K-wide window of x is read once from LDS and
+// reused by CO_R output channels; lanes are reduced at the end with wavefront shuffles.
+// grid = (C_in, C_out/CO_R, S) ; slab[s][co][ci][k], bias slab[s][co] after the weight slabs.
+template <int KK, int CO_R>
+__global__ __launch_bounds__(kTT) void conv1d_wgrad_direct_kernel(
+    const float *__restrict__ dy, const float *__restrict__ x, float *__restrict__ slab,
+    int N, int Cin, int Cout, int L, int Lo, int pad, int S) {
+    __shared__ float xs[kTT + KK - 1];
+    __shared__ float red[4][CO_R * KK + CO_R];
+
+    const int tl = threadIdx.x;
+    const int ci = blockIdx.x;
+    const int co0 = blockIdx.y * CO_R;
+    const int s = blockIdx.z;
+    const int n_begin = (int)((long long)N * s / S), n_end = (int)((long long)N * (s + 1) / S);
+
+    float acc[CO_R][KK];
+    float bacc[CO_R];
+#pragma unroll
+    for (int j = 0; j < CO_R; ++j) {
+        bacc[j] = 0.f;
+#pragma unroll
+        for (int k = 0; k < KK; ++k) acc[j][k] = 0.f;
+    }
+
+    for (int n = n_begin; n < n_end; ++n) {
+        const float *xr = x + ((size_t)n * Cin + ci) * L;
+        const float *dyn = dy + ((size_t)n * Cout + co0) * Lo;
+        for (int t0 = 0; t0 < Lo; t0 += kTT) {
+            __syncthreads();
+            for (int i = tl; i < kTT + KK - 1; i += kTT) {
+                int sidx = t0 - pad + i;
+                xs[i] = (sidx >= 0 && sidx < L) ? xr[sidx] : 0.f;
+            }
+            __syncthreads();
+            const int t = t0 + tl;
+            float xv[KK];
+#pragma unroll
+            for (int k = 0; k < KK; ++k) xv[k] = xs[tl + k];
+#pragma unroll
+            for (int j = 0; j < CO_R; ++j) {
+                float d = (t < Lo) ? dyn[(size_t)j * Lo + t] : 0.f;
+                bacc[j] += d;
+#pragma unroll
+                for (int k = 0; k < KK; ++k) acc[j][k] = __fmaf_rn(d, xv[k], acc[j][k]);
+            }
+        }
+    }
+
+    const int wave = tl >> 6, lane = tl & 63;
+#pragma unroll
+    for (int j = 0; j < CO_R; ++j) {
+#pragma unroll
+        for (int k = 0; k < KK; ++k) {
+            float v = wave_sum(acc[j][k]);
+            if (lane == 0) red[wave][j * KK + k] = v;
+        }
+        float b = wave_sum(bacc[j]);
+        if (lane == 0) red[wave][CO_R * KK + j] = b;
+    }
+    __syncthreads();
+    const size_t wslab = (size_t)Cout * Cin * KK;
+    if (tl < CO_R * KK) {
+        int j = tl / KK, k = tl % KK;
+        float v = red[0][tl] + red[1][tl] + red[2][tl] + red[3][tl];
+        slab[(size_t)s * wslab + ((size_t)(co0 + j) * Cin + ci) * KK + k] = v;
+    } else if (tl < CO_R * KK + CO_R && ci == 0) {
+        int j = tl - CO_R * KK;
+        float v = red[0][tl] + red[1][tl] + red[2][tl] + red[3][tl];
+        slab[(size_t)S * wslab + (size_t)s * Cout + co0 + j] = v;
+    }
+}
+
+// Shape-generic fallback (any K <= 31, any C_out): one workgroup per (co, ci), S == 1.
+__global__ __launch_bounds__(kTT) void conv1d_wgrad_generic_kernel(
+    const float *__restrict__ dy, const float *__restrict__ x, float *__restrict__ slab,
+    int N, int Cin, int Cout, int L, int Lo, int K, int pad) {
+    __shared__ double red[4];
+    const int ci = blockIdx.x, co = blockIdx.y, tl = threadIdx.x;
+    const int wave = tl >> 6, lane = tl & 63;
+    const size_t wslab = (size_t)Cout * Cin * K;
+    for (int k = 0; k <= K; ++k) {   // k == K: the bias column (sum of dy), only for ci == 0
+        if (k == K && ci != 0) break;
+        double a = 0.0;
+        for (int n = 0; n < N; ++n) {
+            const float *dyr = dy + ((size_t)n * Cout + co) * Lo;
+            const float *xr = x + ((size_t)n * Cin + ci) * L;
+            for (int t = tl; t < Lo; t += kTT) {
+                if (k == K) { a += dyr[t]; continue; }
+                int sidx = t + k - pad;
+                if (sidx >= 0 && sidx < L) a += (double)dyr[t] * (double)xr[sidx];
+            }
+        }
+        a = wave_sum(a);
+        __syncthreads();
+        if (lane == 0) red[wave] = a;
+        __syncthreads();
+        if (tl == 0) {
+            float v = (float)(red[0] + red[1] + red[2] + red[3]);
+            if (k == K) slab[wslab + co] = v;
+            else slab[((size_t)co * Cin + ci) * K + k] = v;
+        }
+    }
+}
+
+// dw[i] = sum_s slab[s][i] (fixed order -> bitwise reproducible); db likewise.
+__global__ void wgrad_reduce_kernel(const float *__restrict__ slab, float *__restrict__ dw,
+                                    float *__restrict__ db, size_t wslab, int Cout, int S) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < wslab) {
+        double a = 0.0;
+        for (int s = 0; s < S; ++s) a += slab[(size_t)s * wslab + i];
+        dw[i] = (float)a;
+    } else if (db && i < wslab + Cout) {
+        size_t c = i - wslab;
+        double a = 0.0;
+        for (int s = 0; s < S; ++s) a += slab[(size_t)S * wslab + (size_t)s * Cout + c];
+        db[c] = (float)a;
+    }
+}
+
+static bool wgrad_fast_ok(int Cout, int K) { return K == 15 && Cout % 8 == 0; }
+
+int direct_wgrad_splits(int N, int Cin, int Cout, int K) {
+    if (!wgrad_fast_ok(Cout, K)) return 1;
+    long long base = (long long)Cin * (Cout / 8);
+    long long s = (2048 + base - 1) / base;
+    if (s < 1) s = 1;
+    if (s > N) s = N;
+    return (int)s;
+}
+
+size_t direct_wgrad_ws_floats(int N, int Cin, int Cout, int K) {
+    int S = direct_wgrad_splits(N, Cin, Cout, K);
+    return (size_t)S * ((size_t)Cout * Cin * K + Cout);
+}
+
+int direct_wgrad(const float *dy, const float *x, float *dw, float *db, float *ws, int N, int Cin,
+                 int Cout, int L, int K, int pad, hipStream_t st) {
+    const int Lo = L + 2 * pad - K + 1;
+    const int S = direct_wgrad_splits(N, Cin, Cout, K);
+    const size_t wslab = (size_t)Cout * Cin * K;
+    if (wgrad_fast_ok(Cout, K)) {
+        dim3 grid(Cin, Cout / 8, S), block(kTT);
+        hipLaunchKernelGGL((conv1d_wgrad_direct_kernel<15, 8>), grid, block, 0, st, dy, x, ws, N,
+                           Cin, Cout, L, Lo, pad, S);
+    } else {
+        dim3 grid(Cin, Cout), block(kTT);
+        hipLaunchKernelGGL(conv1d_wgrad_generic_kernel, grid, block, 0, st, dy, x, ws, N, Cin,
+                           Cout, L, Lo, K, pad);
+    }
+    int rc = check_launch("conv1d_wgrad kernel");
+    if (rc) return rc;
+    size_t total = wslab + Cout;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st, ws, dw, db,
+                       wslab, Cout, S);
+    return check_launch("wgrad_reduce_kernel");
+}
+
+int pack_weights(const float *w, float *w_fwd, float *w_bwd, int Co, int Ci, int K,
+                 hipStream_t st) {
+    int total = Co * Ci * K;
+    hipLaunchKernelGGL(pack_weights_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st, w, w_fwd,
+                       w_bwd, Co, Ci, K);
+    return check_launch("pack_weights_kernel");
+}
+
+}  // namespace ecg

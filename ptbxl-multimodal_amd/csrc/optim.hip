@@ -1,0 +1,105 @@
+// optim.hip — flat-buffer AdamW step and the per-lead z-score of the input pipeline.
+//   AdamW:   torch.optim.AdamW(model.parameters(), lr, weight_decay) with torch defaults —
+//            reference scripts/03_train_ecg_baseline.py:130-133, 04:158-162, 05:130.
+//   z-score: PTBXLDataset._normalize("per_lead") — reference src/datasets/ptbxl.py:122-127.
+// Both are pure HBM streams (AdamW: 16 B read + 12 B written per parameter).
+#include "common.h"
+
+namespace ecg {
+
+struct AdamArgs {
+    float decay;      // 1 - lr*wd
+    float b1, b2;
+    float step_size;  // lr / (1 - b1^t)
+    float bc2_sqrt;   // sqrt(1 - b2^t)
+    float eps;
+    float gscale;
+};
+
+__device__ __forceinline__ void adam1(float &p, float g, float &m, float &v, const AdamArgs &a) {
+    g *= a.gscale;
+    p *= a.decay;
+    m = m + (g - m) * (1.0f - a.b1);                 // exp_avg.lerp_(grad, 1-beta1)
+    v = __fmaf_rn(v, a.b2, (1.0f - a.b2) * g * g);   // exp_avg_sq.mul_(b2).addcmul_(g, g, 1-b2)
+    float denom = sqrtf(v) / a.bc2_sqrt + a.eps;
+    p = p - a.step_size * (m / denom);
+}
+
+__global__ __launch_bounds__(256) void adamw_kernel(float *__restrict__ p,
+                                                    const float *__restrict__ g,
+                                                    float *__restrict__ m, float *__restrict__ v,
+                                                    size_t n, AdamArgs a) {
+    size_t i4 = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i4 + 3 < n) {
+        float4 pp = *reinterpret_cast<float4 *>(p + i4);
+        float4 gg = *reinterpret_cast<const float4 *>(g + i4);
+        float4 mm = *reinterpret_cast<float4 *>(m + i4);
+        float4 vv = *reinterpret_cast<float4 *>(v + i4);
+        adam1(pp.x, gg.x, mm.x, vv.x, a);
+        adam1(pp.y, gg.y, mm.y, vv.y, a);
+        adam1(pp.z, gg.z, mm.z, vv.z, a);
+        adam1(pp.w, gg.w, mm.w, vv.w, a);
+        *reinterpret_cast<float4 *>(p + i4) = pp;
+        *reinterpret_cast<float4 *>(m + i4) = mm;
+        *reinterpret_cast<float4 *>(v + i4) = vv;
+    } else {
+        for (size_t i = i4; i < n; ++i) adam1(p[i], g[i], m[i], v[i], a);
+    }
+}
+
+// One workgroup per (window, lead) row: mean and population std in double, then the affine.
+__global__ __launch_bounds__(256) void zscore_rows_kernel(const float *__restrict__ x,
+                                                          float *__restrict__ out, int T) {
+    __shared__ double red[4];
+    __shared__ double bc[2];
+    const float *r = x + (size_t)blockIdx.x * T;
+    float *o = out + (size_t)blockIdx.x * T;
+    const int tl = threadIdx.x, wave = tl >> 6, lane = tl & 63;
+    double a = 0.0;
+    for (int t = tl; t < T; t += 256) a += (double)r[t];
+    a = wave_sum(a);
+    if (lane == 0) red[wave] = a;
+    __syncthreads();
+    if (tl == 0) bc[0] = (red[0] + red[1] + red[2] + red[3]) / (double)T;
+    __syncthreads();
+    const double mu = bc[0];
+    double q = 0.0;
+    for (int t = tl; t < T; t += 256) { double d = (double)r[t] - mu; q += d * d; }
+    q = wave_sum(q);
+    if (lane == 0) red[wave] = q;
+    __syncthreads();
+    if (tl == 0) bc[1] = sqrt((red[0] + red[1] + red[2] + red[3]) / (double)T) + 1e-6;
+    __syncthreads();
+    const double sd = bc[1];
+    for (int t = tl; t < T; t += 256) o[t] = (float)(((double)r[t] - mu) / sd);
+}
+
+}  // namespace ecg
+
+using namespace ecg;
+
+ECG_API int ecg_adamw_step(float *p, const float *g, float *m, float *v, size_t n, int step,
+                           float lr, float beta1, float beta2, float eps, float weight_decay,
+                           float grad_scale, ecg_stream_t stream) {
+    ECG_REQUIRE(p && g && m && v, "adamw_step: null pointer");
+    ECG_REQUIRE(step >= 1, "adamw_step: step=%d must be >= 1", step);
+    ECG_REQUIRE(((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) % 16 == 0,
+                "adamw_step: buffers must be 16-byte aligned");
+    if (n == 0) return ECG_OK;
+    AdamArgs a;
+    double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
+    a.decay = (float)(1.0 - (double)lr * (double)weight_decay);
+    a.b1 = beta1; a.b2 = beta2;
+    a.step_size = (float)((double)lr / bc1);
+    a.bc2_sqrt = (float)sqrt(bc2);
+    a.eps = eps; a.gscale = grad_scale;
+    hipLaunchKernelGGL(adamw_kernel, dim3(cdiv((long long)((n + 3) / 4), 256)), dim3(256), 0,
+                       as_stream(stream), p, g, m, v, n, a);
+    return check_launch("adamw_kernel");
+}
+
+ECG_API int ecg_zscore_rows(const float *x, float *out, int rows, int T, ecg_stream_t stream) {
+    ECG_REQUIRE(x && out && rows > 0 && T > 0, "zscore_rows: bad argument");
+    hipLaunchKernelGGL(zscore_rows_kernel, dim3(rows), dim3(256), 0, as_stream(stream), x, out, T);
+    return check_launch("zscore_rows_kernel");
+}

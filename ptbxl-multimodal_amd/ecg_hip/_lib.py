@@ -1,0 +1,150 @@
+"""ctypes binding of libecg_hip.so (include/ecg_hip.h).
+
+The product path has no CPU fallback: if the shared library is missing, or a tensor is not
+a contiguous float32 CUDA tensor, the call raises.  Every wrapper launches on torch's
+current HIP stream and never synchronises.
+"""
+import ctypes
+import os
+import threading
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libecg_hip.so")
+
+_vp, _i, _f, _sz, _ll = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_size_t, ctypes.c_longlong
+
+# name -> (restype, argtypes); mirrors include/ecg_hip.h one to one
+SIGNATURES = {
+    "ecg_version": (_i, []),
+    "ecg_last_error": (ctypes.c_char_p, []),
+    "ecg_check_device": (_i, []),
+    "ecg_conv1d_pack_weights": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),
+    "ecg_conv1d_fwd_stat_partials": (_i, [_i, _i, _i, _i, _i, _i]),
+    "ecg_conv1d_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "ecg_conv1d_bwd_data": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "ecg_conv1d_bwd_weight_ws_floats": (_sz, [_i, _i, _i, _i, _i, _i]),
+    "ecg_conv1d_bwd_weight_bias": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "ecg_bn_stat_partials_count": (_i, [_i, _i, _i]),
+    "ecg_bn_stat_partials": (_i, [_vp, _vp, _i, _i, _i, _vp]),
+    "ecg_bn_finalize": (_i, [_vp, _i, _ll, _vp, _vp, _vp, _vp, _vp, _i, _f, _f, _vp]),
+    "ecg_bn_invstd": (_i, [_vp, _vp, _i, _f, _vp]),
+    "ecg_bn_relu_pool_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
+    "ecg_bn_relu_pool_bwd_ws_floats": (_sz, [_i, _i, _i]),
+    "ecg_bn_relu_pool_bwd": (_i, [_vp] * 10 + [_i, _i, _i, _i, _vp]),
+    "ecg_bn_apply_fwd": (_i, [_vp] * 6 + [_i, _i, _i, _vp]),
+    "ecg_bn_bwd_ws_floats": (_sz, [_i, _i, _i]),
+    "ecg_bn_bwd": (_i, [_vp] * 9 + [_i, _i, _i, _i, _vp]),
+    "ecg_relu_fwd": (_i, [_vp, _vp, _sz, _vp]),
+    "ecg_relu_bwd": (_i, [_vp, _vp, _vp, _sz, _vp]),
+    "ecg_maxpool2_fwd": (_i, [_vp, _vp, _i, _i, _vp]),
+    "ecg_maxpool2_bwd": (_i, [_vp, _vp, _vp, _i, _i, _vp]),
+    "ecg_gap_fwd": (_i, [_vp, _vp, _i, _i, _vp]),
+    "ecg_gap_bwd": (_i, [_vp, _vp, _i, _i, _vp]),
+    "ecg_linear_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "ecg_linear_bwd_ws_floats": (_sz, [_i, _i, _i]),
+    "ecg_linear_bwd": (_i, [_vp] * 8 + [_i, _i, _i, _i, _vp]),
+    "ecg_film_fwd": (_i, [_vp, _vp, _vp, _i, _i, _vp]),
+    "ecg_film_bwd": (_i, [_vp] * 5 + [_i, _i, _vp]),
+    "ecg_bce_logits_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _vp]),
+    "ecg_sigmoid_fwd": (_i, [_vp, _vp, _sz, _vp]),
+    "ecg_adamw_step": (_i, [_vp, _vp, _vp, _vp, _sz, _i, _f, _f, _f, _f, _f, _f, _vp]),
+    "ecg_zscore_rows": (_i, [_vp, _vp, _i, _i, _vp]),
+}
+
+_lock = threading.Lock()
+_lib = None
+
+
+class EcgHipError(RuntimeError):
+    pass
+
+
+def load():
+    """dlopen libecg_hip.so and bind every symbol of the header.  Raises if it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is None:
+            if not os.path.exists(LIB_PATH):
+                raise EcgHipError(
+                    f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                    "(or `make -C ptbxl-multimodal_amd/csrc`). There is no CPU fallback.")
+            lib = ctypes.CDLL(LIB_PATH)
+            for name, (res, args) in SIGNATURES.items():
+                fn = getattr(lib, name)          # AttributeError if the .so lacks a declared symbol
+                fn.restype, fn.argtypes = res, args
+            _lib = lib
+    return _lib
+
+
+def last_error():
+    return load().ecg_last_error().decode("utf-8", "replace")
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def ptr(t):
+    """Device pointer of a tensor that satisfies the ABI contract (or None)."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise EcgHipError("ecg_hip kernels need CUDA(HIP) tensors; got a CPU tensor "
+                          "(move the model and inputs to 'cuda' — there is no CPU fallback)")
+    if not t.is_contiguous():
+        raise EcgHipError("ecg_hip kernels need contiguous tensors")
+    return t.data_ptr()
+
+
+def f32(t):
+    if t is not None and t.dtype != torch.float32:
+        raise EcgHipError(f"ecg_hip kernels compute in float32; got {t.dtype}")
+    return ptr(t)
+
+
+_events = None     # when a list: (name, int-args, start, end) per launch — see kernel_timing()
+
+
+def call(name, *args):
+    """Invoke an int-returning entry point; raise with ecg_last_error() on failure."""
+    lib = load()
+    if _events is None:
+        rc = getattr(lib, name)(*args)
+    else:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        rc = getattr(lib, name)(*args)
+        e1.record()
+        _events.append((name, tuple(a for a in args[:-1] if isinstance(a, int) and abs(a) < (1 << 31)), e0, e1))
+    if rc != 0:
+        raise EcgHipError(f"{name} failed (code {rc}): {last_error()}")
+
+
+class kernel_timing:
+    """Context manager: brackets every ABI launch with HIP events on the launch stream and
+    returns {(entry point, shape ints): [ms, ...]} — the live per-kernel durations bench.py
+    reports against the roofline.  Adds two event records per launch, so it is used in a
+    separate pass, never inside the timed throughput region."""
+
+    def __enter__(self):
+        global _events
+        _events = []
+        self.result = {}
+        return self
+
+    def __exit__(self, *exc):
+        global _events
+        ev, _events = _events, None
+        torch.cuda.synchronize()
+        for name, sig, e0, e1 in ev:
+            self.result.setdefault((name, sig), []).append(e0.elapsed_time(e1))
+        return False
+
+
+def query(name, *args):
+    """Invoke a size/count helper (no error channel)."""
+    return getattr(load(), name)(*args)

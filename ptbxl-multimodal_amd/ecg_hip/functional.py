@@ -1,0 +1,347 @@
+"""torch.autograd.Function wrappers over the C ABI (include/ecg_hip.h).
+
+Each Function's forward/backward is a straight sequence of libecg_hip.so launches on
+torch's current stream; torch only owns the memory.  Hand-written backward formulas are
+the ones restated (and pinned against the reference) in oracle/ecg_oracle.c.
+"""
+import torch
+
+from . import _lib as L
+
+_call, _query, _f32, _st = L.call, L.query, L.f32, L.stream
+
+
+def _empty(ref, *shape):
+    return torch.empty(shape, dtype=torch.float32, device=ref.device)
+
+
+def _contig(t):
+    return t if t.is_contiguous() else t.contiguous()
+
+
+# --------------------------------------------------------------------------------------
+# raw launches (no autograd) — shared by the Functions below
+# --------------------------------------------------------------------------------------
+def conv1d_pack(w, need_bwd=True):
+    Co, Ci, K = w.shape
+    w_fwd = torch.empty_like(w).view(K, Ci, Co)
+    w_bwd = torch.empty_like(w).view(K, Co, Ci) if need_bwd else None
+    _call("ecg_conv1d_pack_weights", _f32(w), _f32(w_fwd), _f32(w_bwd), Co, Ci, K, _st())
+    return w_fwd, w_bwd
+
+
+def conv1d_forward_raw(x, w_fwd, bias, Co, K, pad, want_stats):
+    N, Ci, Lin = x.shape
+    Lo = Lin + 2 * pad - K + 1
+    if Lo <= 0:
+        raise L.EcgHipError(f"conv1d: empty output for L={Lin}, K={K}, pad={pad}")
+    y = _empty(x, N, Co, Lo)
+    partials, P = None, 0
+    if want_stats:
+        P = _query("ecg_conv1d_fwd_stat_partials", N, Ci, Co, Lin, K, pad)
+        partials = _empty(x, Co * P * 2)
+    _call("ecg_conv1d_fwd", _f32(x), _f32(w_fwd), _f32(bias), _f32(y), _f32(partials),
+          N, Ci, Co, Lin, K, pad, _st())
+    return y, partials, P
+
+
+def conv1d_backward_raw(x, dy, w_shape, w_bwd, pad, need_dx, need_db=True):
+    N, Ci, Lin = x.shape
+    Co, _, K = w_shape
+    dw = _empty(x, Co, Ci, K)
+    db = _empty(x, Co) if need_db else None
+    ws = _empty(x, max(1, _query("ecg_conv1d_bwd_weight_ws_floats", N, Ci, Co, Lin, K, pad)))
+    _call("ecg_conv1d_bwd_weight_bias", _f32(dy), _f32(x), _f32(dw), _f32(db), _f32(ws),
+          N, Ci, Co, Lin, K, pad, _st())
+    dx = None
+    if need_dx:
+        dx = torch.empty_like(x)
+        _call("ecg_conv1d_bwd_data", _f32(dy), _f32(w_bwd), _f32(dx), N, Ci, Co, Lin, K, pad, _st())
+    return dx, dw, db
+
+
+def bn_batch_stats(y, partials, P, running_mean, running_var, nbt, momentum, eps):
+    """mean/invstd of y [N,C,L] (+ running-stat / counter update) from conv-epilogue partials,
+    or from a standalone pass when partials is None."""
+    N, C, Lo = y.shape
+    if partials is None:
+        P = _query("ecg_bn_stat_partials_count", N, C, Lo)
+        partials = _empty(y, C * P * 2)
+        _call("ecg_bn_stat_partials", _f32(y), _f32(partials), N, C, Lo, _st())
+    mean, invstd = _empty(y, C), _empty(y, C)
+    if nbt is not None and nbt.dtype != torch.int64:
+        raise L.EcgHipError("num_batches_tracked must be int64")
+    _call("ecg_bn_finalize", _f32(partials), P, N * Lo, _f32(mean), _f32(invstd),
+          _f32(running_mean), _f32(running_var), L.ptr(nbt), C, float(momentum), float(eps), _st())
+    return mean, invstd
+
+
+def bn_eval_stats(running_mean, running_var, eps):
+    invstd = torch.empty_like(running_var)
+    _call("ecg_bn_invstd", _f32(running_var), _f32(invstd), running_var.numel(), float(eps), _st())
+    return running_mean, invstd
+
+
+def _bn_momentum(momentum, nbt):
+    if momentum is None:      # cumulative moving average: factor = 1/(count+1) (host read)
+        return 1.0 / (int(nbt.item()) + 1) if nbt is not None else 0.0
+    return float(momentum)
+
+
+# --------------------------------------------------------------------------------------
+# Fused ConvBlock: Conv1d -> BatchNorm1d -> ReLU -> MaxPool1d(2)
+# --------------------------------------------------------------------------------------
+class ConvBlockFn(torch.autograd.Function):
+    """reference src/models/ecg_cnn.py:12-17 as 3 launches forward (conv + BN-statistics
+    epilogue, finalize, BN-apply+ReLU+pool) and 5-6 backward."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, gamma, beta, running_mean, running_var, nbt, training, momentum,
+                eps, pad):
+        x, w = _contig(x), _contig(w)
+        Co, _, K = w.shape
+        use_batch = training or running_mean is None
+        need_grad = any(ctx.needs_input_grad)
+        w_fwd, w_bwd = conv1d_pack(w, need_bwd=need_grad and ctx.needs_input_grad[0])
+        y, partials, P = conv1d_forward_raw(x, w_fwd, b, Co, K, pad, want_stats=use_batch)
+        if use_batch:
+            rm, rv, cnt = (running_mean, running_var, nbt) if training else (None, None, None)
+            mean, invstd = bn_batch_stats(y, partials, P, rm, rv, cnt, _bn_momentum(momentum, nbt), eps)
+        else:
+            mean, invstd = bn_eval_stats(running_mean, running_var, eps)
+        N, _, Lo = y.shape
+        p = _empty(x, N, Co, Lo // 2)
+        _call("ecg_bn_relu_pool_fwd", _f32(y), _f32(gamma), _f32(beta), _f32(mean), _f32(invstd),
+              _f32(p), N, Co, Lo, _st())
+        ctx.save_for_backward(x, w, y, gamma, beta, mean, invstd)
+        ctx.w_bwd, ctx.pad, ctx.batch_stats = w_bwd, pad, use_batch
+        return p
+
+    @staticmethod
+    def backward(ctx, dp):
+        x, w, y, gamma, beta, mean, invstd = ctx.saved_tensors
+        dp = _contig(dp)
+        N, Co, Lo = y.shape
+        dy = torch.empty_like(y)
+        dgamma, dbeta = _empty(y, Co), _empty(y, Co)
+        ws = _empty(y, _query("ecg_bn_relu_pool_bwd_ws_floats", N, Co, Lo))
+        _call("ecg_bn_relu_pool_bwd", _f32(y), _f32(dp), _f32(gamma), _f32(beta), _f32(mean),
+              _f32(invstd), _f32(dy), _f32(dgamma), _f32(dbeta), _f32(ws), N, Co, Lo,
+              1 if ctx.batch_stats else 0, _st())
+        dx, dw, db = conv1d_backward_raw(x, dy, w.shape, ctx.w_bwd, ctx.pad, ctx.needs_input_grad[0])
+        return dx, dw, db, dgamma, dbeta, None, None, None, None, None, None, None
+
+
+# --------------------------------------------------------------------------------------
+# Unfused leaves (hook-compatible path)
+# --------------------------------------------------------------------------------------
+class Conv1dFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, b, pad):
+        x, w = _contig(x), _contig(w)
+        Co, _, K = w.shape
+        w_fwd, w_bwd = conv1d_pack(w, need_bwd=ctx.needs_input_grad[0])
+        y, _, _ = conv1d_forward_raw(x, w_fwd, b, Co, K, pad, want_stats=False)
+        ctx.save_for_backward(x, w)
+        ctx.w_bwd, ctx.pad, ctx.has_bias = w_bwd, pad, b is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        dx, dw, db = conv1d_backward_raw(x, _contig(dy), w.shape, ctx.w_bwd, ctx.pad,
+                                         ctx.needs_input_grad[0], need_db=ctx.has_bias)
+        return dx, dw, db, None
+
+
+class BatchNormFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, y, gamma, beta, running_mean, running_var, nbt, training, momentum, eps):
+        y = _contig(y)
+        N, C, Lo = y.shape
+        use_batch = training or running_mean is None
+        if use_batch:
+            rm, rv, cnt = (running_mean, running_var, nbt) if training else (None, None, None)
+            mean, invstd = bn_batch_stats(y, None, 0, rm, rv, cnt, _bn_momentum(momentum, nbt), eps)
+        else:
+            mean, invstd = bn_eval_stats(running_mean, running_var, eps)
+        out = torch.empty_like(y)
+        _call("ecg_bn_apply_fwd", _f32(y), _f32(gamma), _f32(beta), _f32(mean), _f32(invstd),
+              _f32(out), N, C, Lo, _st())
+        ctx.save_for_backward(y, gamma, mean, invstd)
+        ctx.batch_stats = use_batch
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        y, gamma, mean, invstd = ctx.saved_tensors
+        N, C, Lo = y.shape
+        dy = torch.empty_like(y)
+        dgamma, dbeta = _empty(y, C), _empty(y, C)
+        ws = _empty(y, _query("ecg_bn_bwd_ws_floats", N, C, Lo))
+        _call("ecg_bn_bwd", _f32(y), _f32(_contig(dout)), _f32(gamma), _f32(mean), _f32(invstd),
+              _f32(dy), _f32(dgamma), _f32(dbeta), _f32(ws), N, C, Lo,
+              1 if ctx.batch_stats else 0, _st())
+        return dy, dgamma, dbeta, None, None, None, None, None, None
+
+
+class ReLUFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = _contig(x)
+        out = torch.empty_like(x)
+        _call("ecg_relu_fwd", _f32(x), _f32(out), x.numel(), _st())
+        ctx.save_for_backward(out)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        (out,) = ctx.saved_tensors
+        dx = torch.empty_like(out)
+        _call("ecg_relu_bwd", _f32(out), _f32(_contig(dout)), _f32(dx), out.numel(), _st())
+        return dx
+
+
+class MaxPool2Fn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = _contig(x)
+        Lin = x.shape[-1]
+        rows = x.numel() // Lin
+        p = _empty(x, *x.shape[:-1], Lin // 2)
+        _call("ecg_maxpool2_fwd", _f32(x), _f32(p), rows, Lin, _st())
+        ctx.save_for_backward(x)
+        return p
+
+    @staticmethod
+    def backward(ctx, dp):
+        (x,) = ctx.saved_tensors
+        Lin = x.shape[-1]
+        dx = torch.empty_like(x)
+        _call("ecg_maxpool2_bwd", _f32(x), _f32(_contig(dp)), _f32(dx), x.numel() // Lin, Lin, _st())
+        return dx
+
+
+# --------------------------------------------------------------------------------------
+# Tail
+# --------------------------------------------------------------------------------------
+class GapFn(torch.autograd.Function):
+    """AdaptiveAvgPool1d(1): [N,C,L] -> [N,C,1] (reference src/models/ecg_cnn.py:46)."""
+
+    @staticmethod
+    def forward(ctx, p):
+        p = _contig(p)
+        N, C, Lp = p.shape
+        g = _empty(p, N, C, 1)
+        _call("ecg_gap_fwd", _f32(p), _f32(g), N * C, Lp, _st())
+        ctx.shape = (N, C, Lp)
+        return g
+
+    @staticmethod
+    def backward(ctx, dg):
+        N, C, Lp = ctx.shape
+        dp = _empty(dg, N, C, Lp)
+        _call("ecg_gap_bwd", _f32(_contig(dg)), _f32(dp), N * C, Lp, _st())
+        return dp
+
+
+class LinearFn(torch.autograd.Function):
+    """y = act(x W^T + b); act = ReLU when relu (reference src/models/ecg_multimodal.py:52-55)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, relu):
+        x, w = _contig(x), _contig(w)
+        if x.dim() != 2:
+            raise L.EcgHipError(f"linear: expected a [M, In] input, got {tuple(x.shape)}")
+        M, In = x.shape
+        Out = w.shape[0]
+        y = _empty(x, M, Out)
+        _call("ecg_linear_fwd", _f32(x), _f32(w), _f32(b), _f32(y), M, In, Out, int(relu), _st())
+        ctx.save_for_backward(x, w, y if relu else None)
+        ctx.relu, ctx.has_bias = bool(relu), b is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, y = ctx.saved_tensors
+        M, In = x.shape
+        Out = w.shape[0]
+        dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        dw = torch.empty_like(w) if ctx.needs_input_grad[1] else None
+        db = _empty(x, Out) if ctx.has_bias and ctx.needs_input_grad[2] else None
+        _call("ecg_linear_bwd", _f32(x), _f32(w), _f32(y), _f32(_contig(dy)), _f32(dx), _f32(dw),
+              _f32(db), None, M, In, Out, int(ctx.relu), _st())
+        return dx, dw, db, None
+
+
+class FilmFn(torch.autograd.Function):
+    """zc = (1 + tanh(film[:, :F])) * z + film[:, F:] (reference src/models/ecg_multimodal.py:92-96)."""
+
+    @staticmethod
+    def forward(ctx, z, film):
+        z, film = _contig(z), _contig(film)
+        M, F = z.shape
+        if film.shape != (M, 2 * F):
+            raise L.EcgHipError(f"film: expected film of shape {(M, 2 * F)}, got {tuple(film.shape)}")
+        zc = torch.empty_like(z)
+        _call("ecg_film_fwd", _f32(z), _f32(film), _f32(zc), M, F, _st())
+        ctx.save_for_backward(z, film)
+        return zc
+
+    @staticmethod
+    def backward(ctx, dzc):
+        z, film = ctx.saved_tensors
+        M, F = z.shape
+        dz, dfilm = torch.empty_like(z), torch.empty_like(film)
+        _call("ecg_film_bwd", _f32(z), _f32(film), _f32(_contig(dzc)), _f32(dz), _f32(dfilm), M, F, _st())
+        return dz, dfilm
+
+
+class BceWithLogitsFn(torch.autograd.Function):
+    """mean BCE-with-logits; the gradient is produced by the same launch as the loss."""
+
+    @staticmethod
+    def forward(ctx, logits, target):
+        logits, target = _contig(logits), _contig(target)
+        if logits.shape != target.shape:
+            raise ValueError(f"Target size ({tuple(target.shape)}) must be the same as input size ({tuple(logits.shape)})")
+        loss = _empty(logits, 1)
+        dx = torch.empty_like(logits) if ctx.needs_input_grad[0] else None
+        _call("ecg_bce_logits_fwd", _f32(logits), _f32(target), _f32(loss), _f32(dx), logits.numel(), _st())
+        ctx.save_for_backward(dx)
+        return loss.view(())
+
+    @staticmethod
+    def backward(ctx, dloss):
+        (dx,) = ctx.saved_tensors
+        return dx * dloss, None
+
+
+# --------------------------------------------------------------------------------------
+# functional entry points
+# --------------------------------------------------------------------------------------
+def conv_block(x, conv, bn):
+    return ConvBlockFn.apply(x, conv.weight, conv.bias, bn.weight, bn.bias, bn.running_mean,
+                             bn.running_var, bn.num_batches_tracked, bn.training, bn.momentum,
+                             bn.eps, conv.padding[0])
+
+
+def binary_cross_entropy_with_logits(logits, target):
+    """Drop-in for F.binary_cross_entropy_with_logits(logits, y) (mean reduction only)."""
+    return BceWithLogitsFn.apply(logits, target)
+
+
+def sigmoid(x):
+    x = _contig(x.detach())
+    out = torch.empty_like(x)
+    _call("ecg_sigmoid_fwd", _f32(x), _f32(out), x.numel(), _st())
+    return out
+
+
+def zscore_per_lead(x):
+    """(x - mean)/(std + 1e-6) per lead row, population std (reference src/datasets/ptbxl.py:122-127)."""
+    x = _contig(x)
+    T = x.shape[-1]
+    out = torch.empty_like(x)
+    _call("ecg_zscore_rows", _f32(x), _f32(out), x.numel() // T, T, _st())
+    return out

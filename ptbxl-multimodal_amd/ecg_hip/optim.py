@@ -1,0 +1,104 @@
+"""FlatAdamW — torch.optim.AdamW semantics (defaults betas=(0.9, 0.999), eps=1e-8, decoupled
+weight decay on every parameter: reference scripts/03_train_ecg_baseline.py:130-133) as ONE
+launch over one flat fp32 buffer (ecg_adamw_step), instead of 20-28 per-tensor updates.
+
+On construction the parameters are re-pointed as views into a single contiguous buffer
+(values unchanged, so state_dicts and checkpoints are unaffected).  `step()` gathers the
+per-parameter gradients into a flat gradient with one concatenation, optionally all-reduces
+it over a process group (the data-parallel exchange of SURVEY §8e: one RCCL collective per
+step on 3 MB) and applies the update; averaging by 1/world is folded into the kernel.
+"""
+import torch
+
+from . import _lib as L
+
+
+def flatten_tensors_(tensors):
+    """Re-point each tensor's storage into one flat buffer (same dtype/device); returns it."""
+    tensors = list(tensors)
+    if not tensors:
+        raise ValueError("nothing to flatten")
+    dev, dt = tensors[0].device, tensors[0].dtype
+    if any(t.device != dev or t.dtype != dt for t in tensors):
+        raise ValueError("all tensors must share device and dtype")
+    flat = torch.empty(sum(t.numel() for t in tensors), dtype=dt, device=dev)
+    off = 0
+    for t in tensors:
+        n = t.numel()
+        view = flat[off:off + n].view(t.shape)
+        view.copy_(t.detach())
+        t.data = view
+        off += n
+    return flat
+
+
+class FlatAdamW(torch.optim.Optimizer):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2,
+                 process_group=None, world_size=None):
+        defaults = dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)
+        super().__init__(params, defaults)
+        if len(self.param_groups) != 1:
+            raise ValueError("FlatAdamW keeps one flat buffer: pass a single parameter group "
+                             "(the reference passes model.parameters())")
+        self._params = [p for p in self.param_groups[0]["params"] if p.requires_grad]
+        for p in self._params:
+            if p.dtype != torch.float32:
+                raise L.EcgHipError("FlatAdamW: float32 parameters only")
+        self.flat_param = flatten_tensors_(self._params)
+        self.flat_m = torch.zeros_like(self.flat_param)
+        self.flat_v = torch.zeros_like(self.flat_param)
+        self.flat_grad = None
+        self._step = 0
+        self.process_group = process_group
+        if world_size is None:
+            world_size = 1
+            if process_group is not None or (torch.distributed.is_available()
+                                             and torch.distributed.is_initialized()):
+                world_size = torch.distributed.get_world_size(process_group)
+        self.world_size = world_size
+
+    def _gather_grads(self):
+        parts = []
+        for p in self._params:
+            g = p.grad
+            parts.append(torch.zeros_like(p).view(-1) if g is None else g.reshape(-1))
+        return torch.cat(parts)
+
+    @torch.no_grad()
+    def reduce_gradients(self):
+        """Flat gradient of this step, summed over ranks by ONE all-reduce; returns (flat, scale)
+        where scale = 1/world is applied inside the AdamW kernel."""
+        self.flat_grad = g = self._gather_grads()
+        if self.world_size > 1:
+            torch.distributed.all_reduce(g, group=self.process_group)
+            return g, 1.0 / self.world_size
+        return g, 1.0
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        grp = self.param_groups[0]
+        g, scale = self.reduce_gradients()
+        self._step += 1
+        b1, b2 = grp["betas"]
+        if g.is_cuda:
+            L.call("ecg_adamw_step", L.f32(self.flat_param), L.f32(g), L.f32(self.flat_m),
+                   L.f32(self.flat_v), g.numel(), self._step, float(grp["lr"]), float(b1), float(b2),
+                   float(grp["eps"]), float(grp["weight_decay"]), scale, L.stream())
+        else:
+            raise L.EcgHipError("FlatAdamW: parameters must live on the GPU (no CPU fallback)")
+        return loss
+
+    # checkpointing of optimizer state (the reference saves none; kept for completeness)
+    def state_dict(self):
+        return {"step": self._step, "exp_avg": self.flat_m, "exp_avg_sq": self.flat_v,
+                "param_groups": [{k: v for k, v in self.param_groups[0].items() if k != "params"}]}
+
+    def load_state_dict(self, sd):
+        self._step = int(sd["step"])
+        self.flat_m.copy_(sd["exp_avg"])
+        self.flat_v.copy_(sd["exp_avg_sq"])
+        self.param_groups[0].update(sd["param_groups"][0])

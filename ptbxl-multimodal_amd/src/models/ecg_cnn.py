@@ -1,0 +1,65 @@
+"""MI355X-native counterpart of the reference's `src/models/ecg_cnn.py`.
+
+Same classes, constructor arguments, attribute names, module tree and state_dict keys as
+the reference (ConvBlock: src/models/ecg_cnn.py:10-20, ECGCNN: :32-68), so checkpoints load
+with strict=True and `scripts/03,05,06,08,11,13` run unchanged with this package first on
+PYTHONPATH.  The leaves are `ecg_hip.nn` modules (subclasses of the stock torch.nn layers)
+and a ConvBlock normally runs as ONE fused autograd node — conv + BN-statistics epilogue,
+finalize, BN-apply+ReLU+MaxPool — instead of four ATen dispatches.  When somebody has
+hooked an inner module (Grad-CAM on `backbone[-1].net[0]`), the block falls back to calling
+the four HIP leaves one by one so hooks observe the same tensors as in the reference.
+"""
+import torch
+import torch.nn as nn
+
+from ecg_hip import functional as hipF
+from ecg_hip import nn as hipnn
+
+BACKBONE_WIDTHS = (32, 64, 128, 256)
+
+
+class ConvBlock(nn.Module):
+    """Conv1d(k, padding=k//2) -> BatchNorm1d -> ReLU -> MaxPool1d(p); `.net` is the
+    indexable [conv, bn, relu, pool] sequence the Grad-CAM scripts address."""
+
+    def __init__(self, in_ch: int, out_ch: int, k: int = 15, p: int = 2):
+        super().__init__()
+        self.net = nn.Sequential(
+            hipnn.HipConv1d(in_ch, out_ch, kernel_size=k, padding=k // 2),
+            hipnn.HipBatchNorm1d(out_ch),
+            hipnn.HipReLU(inplace=True),
+            hipnn.HipMaxPool1d(kernel_size=p),
+        )
+        self._fusable = (p == 2)
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        conv, bn, relu, pool = self.net[0], self.net[1], self.net[2], self.net[3]
+        if self._fusable and not hipnn.has_hooks(self.net, conv, bn, relu, pool):
+            return hipF.conv_block(x, conv, bn)
+        return self.net(x)
+
+
+def make_backbone(in_leads: int) -> nn.Sequential:
+    widths = (in_leads,) + BACKBONE_WIDTHS
+    return nn.Sequential(*(ConvBlock(a, b) for a, b in zip(widths, widths[1:])))
+
+
+class ECGCNN(nn.Module):
+    """12-lead ECG classifier: 4 ConvBlocks -> global average pool -> proj -> head.
+
+    Args mirror the reference: in_leads (12), feat_dim (latent size), num_labels.
+    """
+
+    def __init__(self, in_leads: int = 12, feat_dim: int = 256, num_labels: int = 3):
+        super().__init__()
+        self.backbone = make_backbone(in_leads)
+        self.gap = hipnn.HipAdaptiveAvgPool1d(1)
+        self.proj = hipnn.HipLinear(BACKBONE_WIDTHS[-1], feat_dim)
+        self.head = hipnn.HipLinear(feat_dim, num_labels)
+
+    def forward(self, x: torch.Tensor, return_features: bool = False):
+        """x: [B, in_leads, T] -> logits [B, num_labels] (or (logits, z) if return_features)."""
+        pooled = self.gap(self.backbone(x)).squeeze(-1)
+        z = self.proj(pooled)
+        logits = self.head(z)
+        return (logits, z) if return_features else logits

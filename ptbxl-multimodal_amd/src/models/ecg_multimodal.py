@@ -1,0 +1,58 @@
+"""MI355X-native counterpart of the reference's `src/models/ecg_multimodal.py`.
+
+ECGBackbone (:19-41), DemoEncoder (:44-59) and the FiLM-conditioned ECGMultimodal (:67-99)
+with identical constructor signatures, attribute names and state_dict keys.  The FiLM fusion
+`(1 + tanh(gamma)) * z + beta` is one HIP launch each way (ecg_film_fwd / ecg_film_bwd) and
+the two ReLUs of the demographic MLP are folded into their Linear launches.
+"""
+import torch
+import torch.nn as nn
+
+from ecg_hip import functional as hipF
+from ecg_hip import nn as hipnn
+from src.models.ecg_cnn import BACKBONE_WIDTHS, ConvBlock, make_backbone  # noqa: F401  (ConvBlock re-exported)
+
+
+class ECGBackbone(nn.Module):
+    """[B, in_leads, T] -> [B, feat_dim]: the ECGCNN trunk without the classification head."""
+
+    def __init__(self, in_leads: int = 12, feat_dim: int = 256):
+        super().__init__()
+        self.backbone = make_backbone(in_leads)
+        self.gap = hipnn.HipAdaptiveAvgPool1d(1)
+        self.proj = hipnn.HipLinear(BACKBONE_WIDTHS[-1], feat_dim)
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        return self.proj(self.gap(self.backbone(x)).squeeze(-1))
+
+
+class DemoEncoder(nn.Module):
+    """MLP over [age_norm, sex_id, height_norm, weight_norm, pacemaker]; first layer is 64 wide."""
+
+    def __init__(self, demo_dim: int = 5, hidden_dim: int = 64):
+        super().__init__()
+        fc1, fc2 = hipnn.HipLinear(demo_dim, 64), hipnn.HipLinear(64, hidden_dim)
+        fc1.fuse_relu = fc2.fuse_relu = True     # ReLU runs inside the Linear launch
+        self.mlp = nn.Sequential(fc1, hipnn.HipFusedReLU(inplace=True), fc2, hipnn.HipFusedReLU(inplace=True))
+
+    def forward(self, x_demo: torch.Tensor) -> torch.Tensor:
+        return self.mlp(x_demo)
+
+
+class ECGMultimodal(nn.Module):
+    """ECG embedding modulated feature-wise (FiLM) by the demographic embedding."""
+
+    def __init__(self, in_leads: int = 12, feat_dim: int = 256, demo_dim: int = 5,
+                 num_labels: int = 5, demo_hidden_dim: int = 64, ecg_feat_dim: int = None, **kwargs):
+        super().__init__()
+        if ecg_feat_dim is not None:          # config key `ecg_feat_dim` overrides feat_dim
+            feat_dim = ecg_feat_dim
+        self.ecg_backbone = ECGBackbone(in_leads=in_leads, feat_dim=feat_dim)
+        self.demo_encoder = DemoEncoder(demo_dim=demo_dim, hidden_dim=demo_hidden_dim)
+        self.film_gen = hipnn.HipLinear(demo_hidden_dim, 2 * feat_dim)
+        self.head = hipnn.HipLinear(feat_dim, num_labels)
+
+    def forward(self, x_ecg: torch.Tensor, x_demo: torch.Tensor) -> torch.Tensor:
+        z = self.ecg_backbone(x_ecg)
+        film = self.film_gen(self.demo_encoder(x_demo))      # [B, 2F]: gamma-raw | beta
+        return self.head(hipF.FilmFn.apply(z, film))

@@ -1,0 +1,59 @@
+"""Single-input train / eval epochs with the semantics of the reference's src/training/loop.py
+(train_one_epoch :14-38, eval_one_epoch :41-73), running the loss and the sigmoid on the HIP
+path (ecg_bce_logits_fwd / ecg_sigmoid_fwd).
+
+Epoch loss is sample-weighted: sum(loss_b * B_b) / len(loader.dataset).  The reference reads
+`loss.item()` every step (a device sync per step); here the same double-precision running sum
+is kept on the device and read once per epoch — same value, no per-step stall.
+"""
+from typing import Dict
+
+import numpy as np
+import torch
+from torch.utils.data import DataLoader
+
+from ecg_hip import functional as hipF
+from src.training.metrics import compute_metrics
+
+try:
+    from tqdm import tqdm
+except ImportError:                      # progress bars are cosmetic
+    def tqdm(it, **_):
+        return it
+
+
+def _logits(out):
+    # models may return logits or (logits, features, ...)
+    return out[0] if isinstance(out, tuple) else out
+
+
+def train_one_epoch(model, loader: DataLoader, optimizer, device) -> float:
+    model.train()
+    weighted = None
+    for x, y in tqdm(loader, desc="Train", leave=False):
+        x, y = x.to(device), y.to(device)
+        optimizer.zero_grad()
+        loss = hipF.binary_cross_entropy_with_logits(_logits(model(x)), y)
+        loss.backward()
+        optimizer.step()
+        term = loss.detach().double() * x.size(0)
+        weighted = term if weighted is None else weighted + term
+    return (0.0 if weighted is None else weighted.item()) / len(loader.dataset)
+
+
+def eval_one_epoch(model, loader: DataLoader, device) -> Dict[str, float]:
+    model.eval()
+    targets, probs, weighted = [], [], None
+    with torch.no_grad():
+        for x, y in tqdm(loader, desc="Eval", leave=False):
+            x, y = x.to(device), y.to(device)
+            logits = _logits(model(x))
+            term = hipF.binary_cross_entropy_with_logits(logits, y).double() * x.size(0)
+            weighted = term if weighted is None else weighted + term
+            probs.append(hipF.sigmoid(logits))
+            targets.append(y)
+    y_true = torch.cat(targets).cpu().numpy()
+    y_prob = torch.cat(probs).cpu().numpy()
+    out = compute_metrics(y_true, y_prob, threshold=0.5)
+    out["bce_loss"] = (0.0 if weighted is None else weighted.item()) / len(loader.dataset)
+    return out

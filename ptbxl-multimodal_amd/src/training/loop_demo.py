@@ -1,0 +1,58 @@
+"""ECG + demographics train / eval epochs with the semantics of the reference's
+src/training/loop_demo.py (train_one_epoch_demo :13-43, eval_one_epoch_demo :46-85).
+
+Unlike loop.py the epoch loss here is the plain mean of per-batch means, and a module-level
+`bce_loss_fn` object is kept because callers import it.  The running sum lives on the device
+in double precision and is read once per epoch (the reference syncs twice per step).
+"""
+import numpy as np
+import torch
+
+from ecg_hip import functional as hipF
+from src.training.metrics import compute_metrics
+
+try:
+    from tqdm import tqdm
+except ImportError:
+    def tqdm(it, **_):
+        return it
+
+
+class _HipBCEWithLogits(torch.nn.Module):
+    """BCEWithLogitsLoss() (mean) on the HIP path."""
+
+    def forward(self, logits, target):
+        return hipF.binary_cross_entropy_with_logits(logits, target)
+
+
+bce_loss_fn = _HipBCEWithLogits()
+
+
+def train_one_epoch_demo(model, loader, optimizer, device):
+    model.train()
+    running, batches = None, 0
+    for x_ecg, x_demo, y in tqdm(loader, desc="Train-ECG+Demo", leave=False):
+        x_ecg, x_demo, y = x_ecg.to(device), x_demo.to(device), y.to(device)
+        optimizer.zero_grad()
+        loss = bce_loss_fn(model(x_ecg, x_demo), y)
+        loss.backward()
+        optimizer.step()
+        term = loss.detach().double()
+        running, batches = (term if running is None else running + term), batches + 1
+    return (0.0 if running is None else running.item()) / max(1, batches)
+
+
+def eval_one_epoch_demo(model, loader, device):
+    model.eval()
+    running, batches, probs, targets = None, 0, [], []
+    with torch.no_grad():
+        for x_ecg, x_demo, y in tqdm(loader, desc="Val-ECG+Demo", leave=False):
+            x_ecg, x_demo, y = x_ecg.to(device), x_demo.to(device), y.to(device)
+            logits = model(x_ecg, x_demo)
+            term = bce_loss_fn(logits, y).double()
+            running, batches = (term if running is None else running + term), batches + 1
+            probs.append(hipF.sigmoid(logits))
+            targets.append(y)
+    out = compute_metrics(torch.cat(targets).cpu().numpy(), torch.cat(probs).cpu().numpy())
+    out["bce_loss"] = float((0.0 if running is None else running.item()) / max(1, batches))
+    return out

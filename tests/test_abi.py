@@ -1,0 +1,72 @@
+"""CPU-side checks of the C-ABI boundary: libecg_hip.so loads, exports every symbol that
+include/ecg_hip.h declares, and validates arguments on the host before any launch."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    import __graft_entry__ as g
+    from ecg_hip import _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        g.build()
+    return _lib.load()
+
+
+def _header_symbols():
+    text = open(os.path.join(ROOT, "include", "ecg_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(ecg_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_every_declared_symbol_is_exported_and_bound(lib):
+    from ecg_hip import _lib
+    declared = _header_symbols()
+    assert len(declared) >= 30
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in include/ecg_hip.h but not exported"
+    assert sorted(_lib.SIGNATURES) == declared, "ctypes table and header disagree"
+
+
+def test_version_and_error_channel(lib):
+    assert lib.ecg_version() == 100
+    rc = lib.ecg_conv1d_fwd(None, None, None, None, None, 1, 12, 32, 100, 40, 7, None)
+    assert rc == 1      # ECG_EINVAL: kernel size outside [1,31]; rejected before any launch
+    assert b"kernel size" in lib.ecg_last_error()
+    rc = lib.ecg_conv1d_fwd(None, None, None, None, None, 1, 12, 32, 100, 15, 7, None)
+    assert rc == 1 and b"null pointer" in lib.ecg_last_error()
+    rc = lib.ecg_conv1d_fwd(None, None, None, None, None, 1, 12, 32, 3, 15, 2, None)
+    assert rc == 1 and b"empty output" in lib.ecg_last_error()
+    rc = lib.ecg_adamw_step(None, None, None, None, 16, 1, 1e-3, 0.9, 0.999, 1e-8, 0.0, 1.0, None)
+    assert rc == 1
+
+
+def test_size_helpers_are_pure(lib):
+    assert lib.ecg_conv1d_fwd_stat_partials(256, 12, 32, 1000, 15, 7) > 0
+    assert lib.ecg_conv1d_bwd_weight_ws_floats(256, 12, 32, 1000, 15, 7) >= 32 * 12 * 15 + 32
+    assert lib.ecg_bn_relu_pool_bwd_ws_floats(256, 32, 1000) >= 32 * 2
+    assert lib.ecg_bn_stat_partials_count(4, 32, 100) >= 1
+
+
+def test_product_path_refuses_cpu_tensors():
+    import torch
+    from ecg_hip import EcgHipError
+    from src.models.ecg_cnn import ECGCNN
+    from src.training.loop_demo import bce_loss_fn
+    with pytest.raises(EcgHipError, match="no CPU fallback"):
+        ECGCNN(num_labels=5)(torch.randn(2, 12, 64))
+    with pytest.raises(EcgHipError):
+        bce_loss_fn(torch.zeros(2, 5), torch.zeros(2, 5))
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    from ecg_hip import _lib
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
+    with pytest.raises(_lib.EcgHipError, match="missing"):
+        _lib.load()

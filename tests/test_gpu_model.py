@@ -1,0 +1,232 @@
+"""GPU parity of the whole drop-in path (src.models + src.training on the HIP kernels) against
+the golden fixtures captured from the reference and against the CPU oracle.
+Bar (north_star): logits within 1e-4 in fp32; integer outputs (y_pred, num_batches_tracked) exact."""
+import copy
+
+import numpy as np
+import pytest
+import torch
+
+from util import check_put, golden, sd_from_npz, sub
+from oracle import ref_models as R
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _ctors():
+    from src.models.ecg_cnn import ECGCNN
+    from src.models.ecg_multimodal import ECGMultimodal
+    return {"cnn5": (lambda: ECGCNN(num_labels=5), lambda: R.RefECGCNN(num_labels=5), 5, False),
+            "cnn1": (lambda: ECGCNN(num_labels=1), lambda: R.RefECGCNN(num_labels=1), 1, False),
+            "mm": (lambda: ECGMultimodal(), lambda: R.RefECGMultimodal(), 5, True)}
+
+
+class _DS(torch.utils.data.Dataset):
+    def __init__(self, *t):
+        self.t = t
+
+    def __len__(self):
+        return self.t[0].shape[0]
+
+    def __getitem__(self, i):
+        return tuple(a[i] for a in self.t)
+
+
+def test_g3_eval_known_answer():
+    """Committed checkpoints x demo windows (12x5000): logits vs the reference CPU re-run (1e-4),
+    committed CSV probabilities (5e-4) and thresholded predictions (exact away from 0.5)."""
+    from src.models.ecg_cnn import ECGCNN
+    from src.models.ecg_multimodal import ECGMultimodal
+    g = golden("g3_eval_known_answer")
+    x, demo = torch.from_numpy(g["ecg"]).to(DEV), torch.from_numpy(g["demo"]).to(DEV)
+    for name, ctor in [("baseline", lambda: ECGCNN(num_labels=5)), ("multimodal", lambda: ECGMultimodal()),
+                       ("af", lambda: ECGCNN(num_labels=1))]:
+        m = ctor()
+        m.load_state_dict(sd_from_npz(golden("g3_ckpt_" + name)), strict=True)
+        m.to(DEV).eval()
+        with torch.no_grad():
+            logits = m(x, demo) if name == "multimodal" else m(x)
+        np.testing.assert_allclose(logits.cpu().numpy(), g[name + "_logits"], atol=1e-4, err_msg=name)
+        from ecg_hip import functional as hipF
+        prob = hipF.sigmoid(logits).cpu().numpy()
+        np.testing.assert_allclose(prob, g[name + "_csv_prob"], atol=5e-4)
+        far = np.abs(g[name + "_csv_prob"] - 0.5) > 5e-4
+        assert np.array_equal((prob >= 0.5).astype(np.int64)[far], g[name + "_csv_pred"][far])
+        # BN counters are untouched by eval forwards (int64, exact)
+        key = [k for k in m.state_dict() if k.endswith("num_batches_tracked")][0]
+        assert int(m.state_dict()[key].item()) == int(golden("g3_ckpt_" + name)[key])
+
+
+@pytest.mark.parametrize("B", [4, 32])
+@pytest.mark.parametrize("name", ["cnn5", "cnn1", "mm"])
+@pytest.mark.parametrize("optim", ["torch", "flat"])
+def test_g4_train_steps_through_reference_loop_api(name, B, optim):
+    """3 AdamW steps through src.training.{loop,loop_demo} exactly as scripts/03-05 drive them."""
+    from ecg_hip.optim import FlatAdamW
+    from src.training.loop import train_one_epoch
+    from src.training.loop_demo import train_one_epoch_demo
+    from src.utils.seed import set_seed
+    g = golden("g4_train_step")
+    ctor, _, C, demo = _ctors()[name]
+    p = f"{name}_B{B}_"
+    lr = float(g[p + "lr"])
+    set_seed(42)
+    model = ctor().to(DEV)
+    batch = R.synthetic_batch(B, 1000, C, demo=demo)
+    if B == 4 and name == "cnn5":
+        np.testing.assert_array_equal(batch[0].numpy(), g["x_B4"])
+    loader = torch.utils.data.DataLoader(_DS(*batch), batch_size=B, shuffle=False)
+    Opt = FlatAdamW if optim == "flat" else torch.optim.AdamW
+    opt = Opt(model.parameters(), lr=lr, weight_decay=1e-4)
+    fn = train_one_epoch_demo if demo else train_one_epoch
+    # first forward, train mode, on a copy so BN buffers of `model` are not advanced
+    m2 = copy.deepcopy(model).train()
+    with torch.no_grad():
+        out = m2(*[t.to(DEV) for t in batch[:-1]])
+    np.testing.assert_allclose(out.cpu().numpy(), g[p + "logits0"], atol=1e-4)
+    for step in (1, 2, 3):
+        ep = fn(model, loader, opt, DEV)
+        assert abs(ep - float(g[p + f"epoch_loss{step}"])) < 2e-5, (step, ep)
+        if step in (1, 3):
+            q = p + f"s{step}_"
+            sd = model.state_dict()
+            for k, v in sd.items():
+                if k.endswith("num_batches_tracked"):
+                    assert int(v.item()) == int(g[q + "sd_" + k]) == step     # int64, exact
+                    continue
+                # conv biases have a mathematically-zero gradient under train-mode BN (noise ~1e-9):
+                # Adam normalises that noise to +-lr, so they are only bounded by step*lr.
+                tol = step * lr * 1.01 if (".net.0.bias" in k) else (1e-4 if step == 1 else 3e-4)
+                check_put(g, q + "sd_" + k, v, atol=tol)
+            if optim == "torch":
+                for k, prm in model.named_parameters():
+                    tol = 1e-6 if ".net.0.bias" in k else 1e-4
+                    check_put(g, q + "grad_" + k, prm.grad, atol=tol)
+
+
+def test_g6_gradcam_hooks_and_demo_gradient():
+    """Hooks on the last Conv1d (forward + full backward) see the same tensors as in the
+    reference; CAM and d logit / d x_demo match (reference scripts/00_demo_inference.py:36-43,
+    scripts/12:78-97)."""
+    import torch.nn.functional as F
+    from src.models.ecg_cnn import ECGCNN
+    from src.models.ecg_multimodal import ECGMultimodal
+    g = golden("g6_hooks")
+    ga = golden("g3_eval_known_answer")
+    x = torch.from_numpy(ga["ecg"][:1]).to(DEV)
+    for name, ctor in [("baseline", lambda: ECGCNN(num_labels=5)), ("multimodal", lambda: ECGMultimodal())]:
+        m = ctor()
+        m.load_state_dict(sd_from_npz(golden("g3_ckpt_" + name)))
+        m.to(DEV).eval()
+        convs = [c for c in m.modules() if isinstance(c, torch.nn.Conv1d)]
+        last = convs[-1]
+        store = {}
+        h1 = last.register_forward_hook(lambda mod, i, o: store.__setitem__("act", o.detach().clone()))
+        h2 = last.register_full_backward_hook(lambda mod, gi, go: store.__setitem__("grad", go[0].detach().clone()))
+        demo = torch.from_numpy(ga["demo"][:1]).to(DEV).requires_grad_(True)
+        m.zero_grad()
+        logits = m(x, demo) if name == "multimodal" else m(x)
+        logits[:, 0].sum().backward()
+        h1.remove(), h2.remove()
+        np.testing.assert_allclose(logits.detach().cpu().numpy(), g[name + "_logits"], atol=1e-4)
+        A, G = store["act"][0], store["grad"][0]
+        check_put(g, name + "_act", A, atol=1e-4)
+        check_put(g, name + "_grad", G, atol=1e-6)
+        cam = torch.relu((G.mean(dim=1, keepdim=True) * A).sum(dim=0))
+        np.testing.assert_allclose(cam.cpu().numpy(), g[name + "_cam"], atol=1e-5)
+        up = F.interpolate(cam[None, None], size=5000, mode="linear", align_corners=False)[0, 0]
+        np.testing.assert_allclose(up.cpu().numpy(), g[name + "_cam_up"], atol=1e-5)
+        if name == "multimodal":
+            np.testing.assert_allclose(demo.grad.cpu().numpy(), g["multimodal_dlogit_ddemo"], atol=1e-5)
+        # and the fused path (no hooks) gives the same logits
+        with torch.no_grad():
+            l2 = m(x, demo.detach()) if name == "multimodal" else m(x)
+        np.testing.assert_allclose(l2.cpu().numpy(), logits.detach().cpu().numpy(), atol=2e-5)
+
+
+@pytest.mark.parametrize("name", ["cnn5", "mm"])
+def test_full_size_train_step_vs_cpu_oracle(name):
+    """BASELINE.json size (B=256, 12x1000): one train step vs the stock-torch CPU restatement."""
+    from ecg_hip.optim import FlatAdamW
+    from src.utils.seed import set_seed
+    from ecg_hip import functional as hipF
+    ctor, rctor, C, demo = _ctors()[name]
+    set_seed(42)
+    model = ctor().to(DEV).train()
+    R.seed_all(42)
+    ref = rctor().train()
+    batch = R.synthetic_batch(256, 1000, C, demo=demo)
+    opt = FlatAdamW(model.parameters(), lr=1e-4, weight_decay=1e-4)
+    ropt = R.make_adamw(ref, 1e-4, 1e-4)
+    opt.zero_grad()
+    logits = model(*[t.to(DEV) for t in batch[:-1]])
+    loss = hipF.binary_cross_entropy_with_logits(logits, batch[-1].to(DEV))
+    loss.backward()
+    grads = {k: p.grad.detach().cpu() for k, p in model.named_parameters()}
+    opt.step()
+    rlogits, rloss = R.train_step(ref, ropt, batch)
+    np.testing.assert_allclose(logits.detach().cpu().numpy(), rlogits.numpy(), atol=1e-4)
+    assert abs(loss.item() - rloss) < 1e-5
+    assert np.array_equal((logits.detach().cpu() >= 0).numpy(), (rlogits >= 0).numpy())     # y_pred, exact
+    for k, prm in ref.named_parameters():
+        tol = 1e-6 if ".net.0.bias" in k else 5e-5
+        np.testing.assert_allclose(grads[k].numpy(), prm.grad.numpy(), atol=tol, err_msg=k)
+    for (k, a), (_, b) in zip(model.state_dict().items(), ref.state_dict().items()):
+        if k.endswith("num_batches_tracked"):
+            assert int(a.item()) == int(b.item()) == 1
+        elif "running_" in k:
+            np.testing.assert_allclose(a.cpu().numpy(), b.numpy(), atol=1e-5, err_msg=k)
+
+
+@pytest.mark.parametrize("B,T", [(1, 1000), (3, 16), (5, 17), (2, 5000), (7, 999)])
+def test_ragged_batches_and_lengths_vs_cpu_oracle(B, T):
+    """Last batch is ragged (drop_last unset), Grad-CAM uses B=1, any T >= 16 must work
+    (SURVEY §8b); T=5000 is the real window length."""
+    from src.utils.seed import set_seed
+    from ecg_hip import functional as hipF
+    ctor, rctor, C, demo = _ctors()["mm"]
+    set_seed(1)
+    model = ctor().to(DEV)
+    R.seed_all(1)
+    ref = rctor()
+    x, xd, y = R.synthetic_batch(B, T, C, gen_seed=B * 100 + T, demo=True)
+    for train in ([True, False] if B > 1 else [False]):
+        model.train(train), ref.train(train)
+        model.zero_grad(), ref.zero_grad()
+        logits = model(x.to(DEV), xd.to(DEV))
+        rlogits = ref(x, xd)
+        np.testing.assert_allclose(logits.detach().cpu().numpy(), rlogits.detach().numpy(), atol=1e-4)
+        hipF.binary_cross_entropy_with_logits(logits, y.to(DEV)).backward()
+        torch.nn.functional.binary_cross_entropy_with_logits(rlogits, y).backward()
+        for (k, a), (_, b) in zip(model.named_parameters(), ref.named_parameters()):
+            tol = 1e-6 if ".net.0.bias" in k and train else 1e-4
+            np.testing.assert_allclose(a.grad.cpu().numpy(), b.grad.numpy(), atol=tol, err_msg=f"{k} train={train}")
+
+
+def test_eval_loop_api_and_device_side_loss():
+    """eval_one_epoch / eval_one_epoch_demo: metrics dict + BCE, ragged last batch."""
+    from src.models.ecg_cnn import ECGCNN
+    from src.training.loop import eval_one_epoch
+    from src.training.metrics import compute_metrics
+    g = golden("g3_eval_known_answer")
+    m = ECGCNN(num_labels=5)
+    ck = sd_from_npz(golden("g3_ckpt_baseline"))
+    m.load_state_dict(ck)
+    m.to(DEV)
+    ref = R.RefECGCNN(num_labels=5)
+    ref.load_state_dict(ck)
+    ref.eval()
+    x = torch.from_numpy(g["ecg"])[:, :, :2000]
+    x = torch.cat([x, x.flip(-1)])[:5]
+    y = (torch.arange(25).reshape(5, 5) % 3 == 0).float()
+    loader = torch.utils.data.DataLoader(_DS(x, y), batch_size=2, shuffle=False)   # batches 2,2,1
+    out = eval_one_epoch(m, loader, DEV)
+    with torch.no_grad():
+        rl = ref(x)
+    rloss = torch.nn.functional.binary_cross_entropy_with_logits(rl, y).item()
+    # sample-weighted mean of per-batch means == global mean for this loss
+    assert abs(out["bce_loss"] - rloss) < 1e-5
+    refm = compute_metrics(y.numpy(), torch.sigmoid(rl).numpy())
+    for k in ("auroc_macro", "auprc_macro", "f1_macro"):
+        assert abs(out[k] - refm[k]) < 1e-6 or (np.isnan(out[k]) and np.isnan(refm[k]))

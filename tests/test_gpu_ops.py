@@ -1,0 +1,263 @@
+"""GPU parity of every kernel, called through the C ABI (ecg_hip._lib / functional raw
+launches), against the CPU oracle on the same seeded inputs and against the golden fixtures.
+Tolerances: fp32 kernels vs a double-accumulating oracle; north_star bar is 1e-4 on logits."""
+import numpy as np
+import pytest
+import torch
+
+from util import check_put, golden
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def hip():
+    assert torch.cuda.is_available()
+    import ecg_hip
+    from ecg_hip import _lib, functional
+    ecg_hip.load()
+    _lib.call("ecg_check_device")
+    return functional
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def host(t):
+    return t.detach().cpu().numpy()
+
+
+def conv_all(hip, x, w, b, dy, pad=7):
+    """fwd / dgrad / wgrad through the ABI; returns numpy y, dx, dw, db."""
+    xd, wd, bd, dyd = dev(x), dev(w), dev(b), dev(dy)
+    Co, Ci, K = w.shape
+    w_fwd, w_bwd = hip.conv1d_pack(wd)
+    y, _, _ = hip.conv1d_forward_raw(xd, w_fwd, bd, Co, K, pad, want_stats=False)
+    dx, dw, db = hip.conv1d_backward_raw(xd, dyd, w.shape, w_bwd, pad, need_dx=True)
+    return host(y), host(dx), host(dw), host(db)
+
+
+def test_g1_conv_golden(hip):
+    g = golden("g1_conv_ops")
+    for c in range(int(g["ncases"])):
+        p = f"c{c}_"
+        blk = int(g[p + "blk"])
+        y, dx, dw, db = conv_all(hip, g[p + "x"], g[f"w_blk{blk}"], g[f"b_blk{blk}"], g[p + "dy"])
+        np.testing.assert_allclose(y, g[p + "y"], atol=2e-5, err_msg=f"case {c} y")
+        np.testing.assert_allclose(dx, g[p + "dx"], atol=5e-5, err_msg=f"case {c} dx")
+        check_put(g, p + "dw", dw, atol=5e-5)
+        np.testing.assert_allclose(db, g[p + "db"], atol=5e-5, err_msg=f"case {c} db")
+
+
+# (N, Ci, Co, L, K, pad): block geometries, ragged tiles, generic kernel sizes, tiny L
+CONV_CASES = [
+    (3, 12, 32, 300, 15, 7), (2, 32, 64, 257, 15, 7), (2, 64, 128, 130, 15, 7), (2, 128, 256, 70, 15, 7),
+    (1, 12, 32, 1, 15, 7), (2, 12, 32, 16, 15, 7), (5, 3, 5, 77, 15, 7), (2, 7, 12, 50, 3, 1),
+    (2, 4, 8, 40, 5, 0), (1, 1, 1, 33, 1, 0), (2, 6, 10, 64, 31, 15), (2, 8, 16, 90, 9, 8),
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv_vs_oracle(hip, oracle, case):
+    N, Ci, Co, L, K, pad = case
+    rng = np.random.default_rng(hash(case) % (2 ** 31))
+    x = rng.standard_normal((N, Ci, L)).astype(np.float32)
+    w = (rng.standard_normal((Co, Ci, K)) / np.sqrt(Ci * K)).astype(np.float32)
+    b = rng.standard_normal(Co).astype(np.float32)
+    Lo = L + 2 * pad - K + 1
+    dy = rng.standard_normal((N, Co, Lo)).astype(np.float32)
+    y, dx, dw, db = conv_all(hip, x, w, b, dy, pad)
+    np.testing.assert_allclose(y, oracle.conv1d_fwd(x, w, b, pad), atol=2e-5)
+    np.testing.assert_allclose(dx, oracle.conv1d_bwd_data(dy, w, L, pad), atol=5e-5)
+    rdw, rdb = oracle.conv1d_bwd_weight(dy, x, K, pad)
+    scale = np.sqrt(N * Lo)
+    np.testing.assert_allclose(dw, rdw, atol=2e-6 * scale + 2e-5)
+    np.testing.assert_allclose(db, rdb, atol=2e-6 * scale + 2e-5)
+
+
+def test_conv_stats_epilogue_and_finalize(hip, oracle):
+    from ecg_hip import _lib as L
+    rng = np.random.default_rng(3)
+    for (N, Ci, Co, Lin) in [(4, 12, 32, 300), (3, 32, 64, 125), (2, 128, 256, 33)]:
+        x = rng.standard_normal((N, Ci, Lin)).astype(np.float32)
+        w = (rng.standard_normal((Co, Ci, 15)) / np.sqrt(Ci * 15)).astype(np.float32)
+        b = rng.standard_normal(Co).astype(np.float32)
+        w_fwd, _ = hip.conv1d_pack(dev(w), need_bwd=False)
+        y, partials, P = hip.conv1d_forward_raw(dev(x), w_fwd, dev(b), Co, 15, 7, want_stats=True)
+        rm, rv = torch.zeros(Co).cuda(), torch.ones(Co).cuda()
+        nbt = torch.zeros((), dtype=torch.int64).cuda()
+        mean, invstd = hip.bn_batch_stats(y, partials, P, rm, rv, nbt, 0.1, 1e-5)
+        ry = oracle.conv1d_fwd(x, w, b, 7)
+        orm, orv, onbt = np.zeros(Co, np.float32), np.ones(Co, np.float32), np.zeros((), np.int64)
+        omean, oinv = oracle.bn_stats(ry, orm, orv, onbt)
+        np.testing.assert_allclose(host(mean), omean, atol=2e-6)
+        np.testing.assert_allclose(host(invstd), oinv, rtol=2e-5)
+        np.testing.assert_allclose(host(rm), orm, atol=1e-6)
+        np.testing.assert_allclose(host(rv), orv, rtol=1e-5, atol=1e-6)
+        assert int(nbt.item()) == int(onbt) == 1                 # integer: exact
+        # standalone statistics pass gives the same answer
+        mean2, invstd2 = hip.bn_batch_stats(y, None, 0, None, None, None, 0.1, 1e-5)
+        np.testing.assert_allclose(host(mean2), omean, atol=2e-6)
+        np.testing.assert_allclose(host(invstd2), oinv, rtol=2e-5)
+
+
+@pytest.mark.parametrize("shape", [(3, 32, 50), (2, 64, 33), (4, 256, 125), (2, 5, 1), (2, 7, 2), (1, 3, 1001)])
+@pytest.mark.parametrize("train", [True, False])
+def test_bn_relu_pool_fwd_bwd(hip, oracle, shape, train):
+    from ecg_hip import _lib as L
+    N, C, Lo = shape
+    rng = np.random.default_rng(N * 1000 + C + Lo)
+    y = (rng.standard_normal(shape) * 1.5 + 0.3).astype(np.float32)
+    gamma = (1 + 0.2 * rng.standard_normal(C)).astype(np.float32)
+    beta = (0.2 * rng.standard_normal(C)).astype(np.float32)
+    dp = rng.standard_normal((N, C, Lo // 2)).astype(np.float32)
+    if train:
+        mean, invstd = oracle.bn_stats(y)
+    else:
+        mean = (0.1 * rng.standard_normal(C)).astype(np.float32)
+        invstd = (1.0 / np.sqrt(rng.uniform(0.5, 2.0, C) + 1e-5)).astype(np.float32)
+    yd, gd, bd, md, isd, dpd = map(dev, (y, gamma, beta, mean, invstd, dp))
+    p = torch.empty(N, C, Lo // 2, device="cuda")
+    L.call("ecg_bn_relu_pool_fwd", *map(L.f32, (yd, gd, bd, md, isd, p)), N, C, Lo, L.stream())
+    rp = oracle.bn_relu_pool_fwd(y, gamma, beta, mean, invstd)
+    # same fmaf expression on both sides: pooled values and routing are bit-identical
+    np.testing.assert_array_equal(host(p), rp)
+    dy = torch.empty_like(yd)
+    dgam, dbet = torch.empty(C, device="cuda"), torch.empty(C, device="cuda")
+    ws = torch.empty(L.query("ecg_bn_relu_pool_bwd_ws_floats", N, C, Lo), device="cuda")
+    L.call("ecg_bn_relu_pool_bwd", *map(L.f32, (yd, dpd, gd, bd, md, isd, dy, dgam, dbet, ws)),
+           N, C, Lo, int(train), L.stream())
+    rdy, rdg, rdb = oracle.bn_relu_pool_bwd(y, dp, gamma, beta, mean, invstd, train)
+    tol = 2e-6 * np.sqrt(N * Lo) + 1e-5
+    np.testing.assert_allclose(host(dgam), rdg, atol=tol * 4)
+    np.testing.assert_allclose(host(dbet), rdb, atol=tol * 4)
+    np.testing.assert_allclose(host(dy), rdy, atol=2e-5)
+    # exact zeros: positions that lost the max or were clipped by ReLU carry no da
+    if not train and Lo >= 2:
+        assert np.array_equal(host(dy) == 0, rdy == 0)
+
+
+def test_unfused_leaves_compose_to_fused(hip, oracle):
+    """BatchNormFn -> ReLUFn -> MaxPool2Fn (hook path) equals the fused kernel, fwd and bwd."""
+    torch.manual_seed(0)
+    N, C, Lo = 3, 32, 51
+    y = (torch.randn(N, C, Lo) * 1.3 + 0.2).cuda().requires_grad_(True)
+    gamma = (1 + 0.1 * torch.randn(C)).cuda().requires_grad_(True)
+    beta = (0.1 * torch.randn(C)).cuda().requires_grad_(True)
+    rm, rv, nbt = torch.zeros(C).cuda(), torch.ones(C).cuda(), torch.zeros((), dtype=torch.int64).cuda()
+    out = hip.MaxPool2Fn.apply(hip.ReLUFn.apply(hip.BatchNormFn.apply(y, gamma, beta, rm, rv, nbt, True, 0.1, 1e-5)))
+    dp = torch.randn_like(out)
+    out.backward(dp)
+    yn = host(y)
+    mean, invstd = oracle.bn_stats(yn)
+    rp = oracle.bn_relu_pool_fwd(yn, host(gamma), host(beta), mean, invstd)
+    np.testing.assert_allclose(host(out), rp, atol=2e-6)
+    rdy, rdg, rdb = oracle.bn_relu_pool_bwd(yn, host(dp), host(gamma), host(beta), mean, invstd, True)
+    np.testing.assert_allclose(host(y.grad), rdy, atol=2e-5)
+    np.testing.assert_allclose(host(gamma.grad), rdg, atol=1e-4)
+    np.testing.assert_allclose(host(beta.grad), rdb, atol=1e-4)
+    assert int(nbt.item()) == 1
+
+
+def test_tail_ops_vs_oracle(hip, oracle):
+    from ecg_hip import _lib as L
+    rng = np.random.default_rng(5)
+    # GAP
+    for (N, C, Lp) in [(4, 256, 62), (2, 5, 1), (3, 7, 312)]:
+        p = rng.standard_normal((N, C, Lp)).astype(np.float32)
+        pd = dev(p).requires_grad_(True)
+        g = hip.GapFn.apply(pd)
+        np.testing.assert_allclose(host(g)[..., 0], oracle.gap_fwd(p), atol=1e-6)
+        dg = rng.standard_normal((N, C, 1)).astype(np.float32)
+        g.backward(dev(dg))
+        np.testing.assert_allclose(host(pd.grad), oracle.gap_bwd(dg[..., 0], Lp), atol=1e-7)
+    # Linear (+ReLU), ragged sizes
+    for (M, In, Out, relu) in [(256, 256, 256, False), (37, 5, 64, True), (4, 64, 512, False), (3, 256, 1, False), (1, 7, 3, True)]:
+        x = rng.standard_normal((M, In)).astype(np.float32)
+        w = (rng.standard_normal((Out, In)) / np.sqrt(In)).astype(np.float32)
+        b = rng.standard_normal(Out).astype(np.float32)
+        dy = rng.standard_normal((M, Out)).astype(np.float32)
+        xd, wd, bd = (dev(a).requires_grad_(True) for a in (x, w, b))
+        y = hip.LinearFn.apply(xd, wd, bd, relu)
+        ry = oracle.linear_fwd(x, w, b, relu)
+        np.testing.assert_allclose(host(y), ry, atol=5e-6)
+        y.backward(dev(dy))
+        rdx, rdw, rdb = oracle.linear_bwd(x, w, ry, dy, relu)
+        np.testing.assert_allclose(host(xd.grad), rdx, atol=2e-5)
+        np.testing.assert_allclose(host(wd.grad), rdw, atol=5e-5)
+        np.testing.assert_allclose(host(bd.grad), rdb, atol=5e-5)
+    # FiLM
+    z = rng.standard_normal((9, 256)).astype(np.float32)
+    film = rng.standard_normal((9, 512)).astype(np.float32)
+    dzc = rng.standard_normal((9, 256)).astype(np.float32)
+    zd, fd = dev(z).requires_grad_(True), dev(film).requires_grad_(True)
+    zc = hip.FilmFn.apply(zd, fd)
+    np.testing.assert_allclose(host(zc), oracle.film_fwd(z, film), atol=2e-6)
+    zc.backward(dev(dzc))
+    rdz, rdf = oracle.film_bwd(z, film, dzc)
+    np.testing.assert_allclose(host(zd.grad), rdz, atol=2e-6)
+    np.testing.assert_allclose(host(fd.grad), rdf, atol=2e-6)
+    # BCE with logits (+ its gradient) and sigmoid, incl. large |x|
+    x = np.concatenate([rng.standard_normal(1270) * 3, [-40, 40, 0, 1e-8, -90, 90, 15, -15, 5, -5]]).astype(np.float32).reshape(256, 5)
+    t = (rng.random((256, 5)) < 0.3).astype(np.float32)
+    xd = dev(x).requires_grad_(True)
+    loss = hip.binary_cross_entropy_with_logits(xd, dev(t))
+    assert abs(loss.item() - oracle.bce_fwd(x, t)) < 2e-6
+    (loss * 2.0).backward()
+    np.testing.assert_allclose(host(xd.grad), oracle.bce_bwd(x, t, 2.0), atol=1e-8, rtol=1e-5)
+    np.testing.assert_allclose(host(hip.sigmoid(dev(x))), 1 / (1 + np.exp(-x.astype(np.float64))), atol=1e-7)
+
+
+def test_adamw_flat_step_vs_oracle_and_torch(hip, oracle):
+    from ecg_hip import _lib as L
+    rng = np.random.default_rng(9)
+    n = 757221                                     # multimodal parameter count (ragged tail: n % 4 = 1)
+    p0 = rng.standard_normal(n).astype(np.float32)
+    p, m, v = dev(p0), torch.zeros(n).cuda(), torch.zeros(n).cuda()
+    tp = torch.nn.Parameter(torch.from_numpy(p0.copy()))
+    topt = torch.optim.AdamW([tp], lr=1.5e-3, weight_decay=1e-4)
+    for step in (1, 2, 3):
+        g = rng.standard_normal(n).astype(np.float32)
+        L.call("ecg_adamw_step", L.f32(p), L.f32(dev(g)), L.f32(m), L.f32(v), n, step,
+               1.5e-3, 0.9, 0.999, 1e-8, 1e-4, 1.0, L.stream())
+        tp.grad = torch.from_numpy(g.copy())
+        topt.step()
+        np.testing.assert_allclose(host(p), tp.detach().numpy(), atol=2e-7, rtol=2e-6)
+
+
+def test_zscore_rows(hip):
+    g = golden("g3_eval_known_answer")
+    x = (g["ecg"][0] * 37.5 + 4.0).astype(np.float32)          # un-normalised-looking leads
+    out = host(hip.zscore_per_lead(dev(x)))
+    x64 = x.astype(np.float64)
+    ref = (x64 - x64.mean(axis=1, keepdims=True)) / (x64.std(axis=1, keepdims=True) + 1e-6)
+    np.testing.assert_allclose(out, ref, atol=2e-6)
+
+
+FULL = [(256, 12, 32, 1000), (256, 32, 64, 500), (256, 64, 128, 250), (256, 128, 256, 125)]
+
+
+@pytest.mark.parametrize("shape", FULL)
+def test_conv_full_size_vs_torch_restatement(hip, shape):
+    """BASELINE.json sizes (B=256, 12x1000): compare with the stock-torch CPU conv (validated by
+    G1/G2/G4) and check linearity, a size-independent property."""
+    import torch.nn.functional as F
+    N, Ci, Co, Lin = shape
+    g = torch.Generator().manual_seed(Ci)
+    x = torch.randn(N, Ci, Lin, generator=g)
+    w = torch.randn(Co, Ci, 15, generator=g) / (Ci * 15) ** 0.5
+    b = torch.randn(Co, generator=g)
+    dy = torch.randn(N, Co, Lin, generator=g)
+    xr, wr, br = x.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    ry = F.conv1d(xr, wr, br, padding=7)
+    ry.backward(dy)
+    y, dx, dw, db = conv_all(hip, x.numpy(), w.numpy(), b.numpy(), dy.numpy())
+    np.testing.assert_allclose(y, ry.detach().numpy(), atol=3e-5)
+    np.testing.assert_allclose(dx, xr.grad.numpy(), atol=1e-4)
+    scale = (N * Lin) ** 0.5
+    np.testing.assert_allclose(dw, wr.grad.numpy(), atol=4e-6 * scale)
+    np.testing.assert_allclose(db, br.grad.numpy(), atol=4e-6 * scale)
+    # linearity: conv(2x, w, 0) == 2*(conv(x, w, b) - b)
+    y2, _, _, _ = conv_all(hip, (2 * x).numpy(), w.numpy(), np.zeros(Co, np.float32), dy.numpy())
+    np.testing.assert_allclose(y2, 2 * (y - b.numpy()[None, :, None]), atol=2e-5)
