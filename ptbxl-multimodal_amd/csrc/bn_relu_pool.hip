@@ -299,9 +299,10 @@ ECG_API int ecg_bn_relu_pool_fwd(const float *y, const float *gamma, const float
                                  int L, ecg_stream_t stream) {
     int rc = check_ncl("bn_relu_pool_fwd", N, C, L);
     if (rc) return rc;
-    ECG_REQUIRE(y && gamma && beta && mean && invstd && p, "bn_relu_pool_fwd: null pointer");
+    ECG_REQUIRE(y && gamma && beta && mean && invstd, "bn_relu_pool_fwd: null pointer");
     const int Lp = L / 2;
     if (Lp == 0) return ECG_OK;   // MaxPool1d(2) of a length-1 row is empty
+    ECG_REQUIRE(p, "bn_relu_pool_fwd: null output");
     size_t total = (size_t)N * C * Lp;
     hipLaunchKernelGGL(bn_relu_pool_fwd_kernel, dim3(cdiv(total, kBlock)), dim3(kBlock), 0,
                        as_stream(stream), y, gamma, beta, mean, invstd, p, C, L, Lp, total);

@@ -37,3 +37,11 @@ def sd_from_npz(z, prefix=""):
     import torch
     return {k[len(prefix):]: torch.from_numpy(np.array(z[k])) for k in z.files
             if k.startswith(prefix) and not k.startswith("meta_")}
+
+
+def paired(g, name, value):
+    """(value, reference) as flat float64 arrays, subsampled like the fixture entry."""
+    v = to_np(value).astype(np.float64)
+    if name in g.files:
+        return v.reshape(-1), np.asarray(g[name], dtype=np.float64).reshape(-1)
+    return sub(v), np.asarray(g[name + "__sub"], dtype=np.float64)
