@@ -248,20 +248,26 @@ __global__ __launch_bounds__(kTT) void conv1d_wgrad_generic_kernel(
     }
 }
 
-// dw[i] = sum_s slab[s][i] (fixed order -> bitwise reproducible); db likewise.
-__global__ void wgrad_reduce_kernel(const float *__restrict__ slab, float *__restrict__ dw,
-                                    float *__restrict__ db, size_t wslab, int Cout, int S) {
+// dw[i] = sum_s slab[s][i] (fixed order -> bitwise reproducible); db likewise.  Each thread owns
+// one output and walks the S slabs with 4 independent loads in flight per iteration.
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float *__restrict__ slab,
+                                                          float *__restrict__ dw,
+                                                          float *__restrict__ db, size_t wslab,
+                                                          int Cout, int S) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < wslab) {
-        double a = 0.0;
-        for (int s = 0; s < S; ++s) a += slab[(size_t)s * wslab + i];
-        dw[i] = (float)a;
-    } else if (db && i < wslab + Cout) {
-        size_t c = i - wslab;
-        double a = 0.0;
-        for (int s = 0; s < S; ++s) a += slab[(size_t)S * wslab + (size_t)s * Cout + c];
-        db[c] = (float)a;
+    const size_t total = wslab + Cout;
+    if (i >= total || (i >= wslab && !db)) return;
+    const float *src = i < wslab ? slab + i : slab + (size_t)S * wslab + (i - wslab);
+    const size_t stride = i < wslab ? wslab : (size_t)Cout;
+    double a = 0.0;
+    int s = 0;
+    for (; s + 4 <= S; s += 4) {
+        float v0 = src[(size_t)s * stride], v1 = src[(size_t)(s + 1) * stride];
+        float v2 = src[(size_t)(s + 2) * stride], v3 = src[(size_t)(s + 3) * stride];
+        a += (double)v0; a += (double)v1; a += (double)v2; a += (double)v3;
     }
+    for (; s < S; ++s) a += (double)src[(size_t)s * stride];
+    if (i < wslab) dw[i] = (float)a; else db[i - wslab] = (float)a;
 }
 
 int wgrad_reduce(const float *ws, float *dw, float *db, size_t wslab, int Cout, int S,

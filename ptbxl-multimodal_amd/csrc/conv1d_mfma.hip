@@ -23,6 +23,7 @@
 namespace ecg {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));   // native vector: stays in VGPRs (HIP's float4 struct did not)
 
 constexpr int kKM = 15;   // largest kernel size the MFMA path stages (the reference uses 15)
 
@@ -37,7 +38,8 @@ __device__ __forceinline__ int acc_row(int r, int half) { return (r & 3) + 8 * (
 // forward (and input-grad with flipped/transposed packed weights)
 // =======================================================================================
 // grid = (ceil(Lo/T_T), Cout/CO_T, N), 256 threads = 4 waves laid out WCO x WT over the tile.
-template <int CO_T, int T_T, int WCO, int WT, int CI_C, bool STATS>
+// KK > 0: kernel size known at compile time (fully unrolled tap loop); KK == 0: runtime K <= 15.
+template <int CO_T, int T_T, int WCO, int WT, int CI_C, int KK, bool STATS>
 __global__ __launch_bounds__(256, 2) void conv1d_mfma_fwd_kernel(
     const float *__restrict__ x, const float *__restrict__ wp, const float *__restrict__ bias,
     float *__restrict__ y, float *__restrict__ partials, int Cin, int Cout, int L, int Lo, int K,
@@ -45,6 +47,7 @@ __global__ __launch_bounds__(256, 2) void conv1d_mfma_fwd_kernel(
     static_assert(WCO * WT == 4, "4 waves per workgroup");
     constexpr int MC = CO_T / WCO / 32, MT = T_T / WT / 32;
     static_assert(MC >= 1 && MT >= 1, "wave tile must hold at least one 32x32 accumulator");
+    static_assert(256 % (CO_T / 4) == 0, "weight rows per pass");
     constexpr int XS = T_T + 32;                 // x-tile row stride (span T_T + K - 1 <= T_T + 14)
     constexpr int WF4 = kKM * CI_C * CO_T / 4;   // float4s of one weight chunk [K][CI_C][CO_T]
     constexpr int WLOADS = (WF4 + 255) / 256;
@@ -60,7 +63,6 @@ __global__ __launch_bounds__(256, 2) void conv1d_mfma_fwd_kernel(
     const int half = lane >> 5, l31 = lane & 31;
     const int t0 = blockIdx.x * T_T, co0 = blockIdx.y * CO_T, n = blockIdx.z;
     const int wco = (wave / WT) * (CO_T / WCO), wt = (wave % WT) * (T_T / WT);
-    const int span = T_T + K - 1;
     const float *xn = x + (size_t)n * Cin * L;
 
     f32x16 acc[MC][MT];
@@ -71,40 +73,50 @@ __global__ __launch_bounds__(256, 2) void conv1d_mfma_fwd_kernel(
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
-    float4 wreg[WLOADS];
+    f32x4 wreg[WLOADS];
     float xreg[XLOADS];
+
+    // Staging loads are UNCONDITIONAL: every address is clamped into the tensor and the zero
+    // padding is applied later, at commit time, by AND-ing with a per-thread bit mask.  (A load
+    // whose value is only used under a condition gets sunk into a branch by hipcc and followed
+    // by s_waitcnt vmcnt(0) — one serialised L2 round trip per element.)  Weights are never
+    // masked: rows past the chunk multiply x rows that ARE zeroed.
+    constexpr int RPP = 256 / C4;                 // weight rows fetched per pass of 256 threads
+    const int wrow0 = tid / C4, wc4 = (tid % C4) * 4;
+    unsigned xmask = 0;
 
     auto prefetch = [&](int ci0) {
         const int nci = min(CI_C, Cin - ci0);
 #pragma unroll
         for (int j = 0; j < WLOADS; ++j) {
-            const int f = tid + 256 * j;
-            const int row = f / C4, c4 = f - row * C4;
+            const int row = min(wrow0 + j * RPP, kKM * CI_C - 1);
             const int k = row / CI_C, ci = row - k * CI_C;
-            if (f < WF4 && k < K && ci < nci)
-                wreg[j] = *reinterpret_cast<const float4 *>(
-                    wp + ((size_t)k * Cin + ci0 + ci) * Cout + co0 + c4 * 4);
+            const int kc = min(k, K - 1), cic = min(ci, nci - 1);
+            wreg[j] = *reinterpret_cast<const f32x4 *>(
+                wp + ((size_t)kc * Cin + ci0 + cic) * Cout + co0 + wc4);
         }
+        xmask = 0;
 #pragma unroll
         for (int j = 0; j < XLOADS; ++j) {
             const int e = tid + 256 * j;
             const int ci = e / XS, pos = e - ci * XS;
             const int s = t0 - pad + pos;
-            float v = 0.f;
-            if (e < XEL && ci < nci && pos < span && s >= 0 && s < L) v = xn[(size_t)(ci0 + ci) * L + s];
-            xreg[j] = v;
+            const int cic = min(ci, nci - 1), sc = min(max(s, 0), L - 1);
+            xreg[j] = xn[(size_t)(ci0 + cic) * L + sc];
+            xmask |= ((ci < nci) && (s >= 0) && (s < L)) ? (1u << j) : 0u;
         }
     };
     auto commit = [&]() {
 #pragma unroll
         for (int j = 0; j < WLOADS; ++j) {
             const int f = tid + 256 * j;
-            if (f < WF4) *reinterpret_cast<float4 *>(ws + 4 * f) = wreg[j];
+            if (256 * (j + 1) <= WF4 || f < WF4) *reinterpret_cast<f32x4 *>(ws + 4 * f) = wreg[j];
         }
 #pragma unroll
         for (int j = 0; j < XLOADS; ++j) {
             const int e = tid + 256 * j;
-            if (e < XEL) xs[e] = xreg[j];
+            const unsigned keep = 0u - ((xmask >> j) & 1u);
+            if (256 * (j + 1) <= XEL || e < XEL) xs[e] = __uint_as_float(__float_as_uint(xreg[j]) & keep);
         }
     };
 
@@ -114,24 +126,32 @@ __global__ __launch_bounds__(256, 2) void conv1d_mfma_fwd_kernel(
         commit();
         __syncthreads();
         if (ci0 + CI_C < Cin) prefetch(ci0 + CI_C);   // global loads fly under the MFMAs below
-        const int nci = min(CI_C, Cin - ci0);
-        for (int k = 0; k < K; ++k) {
+        // one reduction step = one (tap, ci-pair): MC + MT LDS reads feed MC*MT MFMAs
+        auto step = [&](int k, int cp) {
+            const float *wrow = ws + ((k * CI_C + 2 * cp + half) * CO_T + wco + l31);
+            const float *xrow = xs + (2 * cp + half) * XS + wt + l31 + k;
+            float a[MC], b[MT];
 #pragma unroll
-            for (int cp = 0; cp < CI_C / 2; ++cp) {
-                if (2 * cp < nci) {
-                    const float *wrow = ws + ((k * CI_C + 2 * cp + half) * CO_T + wco + l31);
-                    const float *xrow = xs + (2 * cp + half) * XS + wt + l31 + k;
-                    float a[MC], b[MT];
+            for (int i = 0; i < MC; ++i) a[i] = wrow[32 * i];
 #pragma unroll
-                    for (int i = 0; i < MC; ++i) a[i] = wrow[32 * i];
+            for (int i = 0; i < MT; ++i) b[i] = xrow[32 * i];
 #pragma unroll
-                    for (int i = 0; i < MT; ++i) b[i] = xrow[32 * i];
+            for (int i = 0; i < MC; ++i)
 #pragma unroll
-                    for (int i = 0; i < MC; ++i)
+                for (int j = 0; j < MT; ++j) acc[i][j] = mfma32(a[i], b[j], acc[i][j]);
+        };
+        if (KK > 0) {
+            // The tap loop stays rolled: a fully unrolled 60-step body makes hipcc hoist dozens of
+            // LDS reads, run out of VGPRs and park the prefetched chunk in scratch (which also
+            // forces an early vmcnt wait: no load/MFMA overlap).
+#pragma unroll 1
+            for (int k = 0; k < KK; ++k)
 #pragma unroll
-                        for (int j = 0; j < MT; ++j) acc[i][j] = mfma32(a[i], b[j], acc[i][j]);
-                }
-            }
+                for (int cp = 0; cp < CI_C / 2; ++cp) step(k, cp);
+        } else {
+            for (int k = 0; k < K; ++k)
+#pragma unroll
+                for (int cp = 0; cp < CI_C / 2; ++cp) step(k, cp);
         }
     }
 
@@ -183,9 +203,14 @@ __global__ __launch_bounds__(256, 2) void conv1d_mfma_fwd_kernel(
 
 struct FwdCfg { int co_t, t_t; };
 
-static FwdCfg fwd_cfg(int Cout, int Lo) {
-    if (Cout % 128 == 0) return {128, 128};
-    if (Cout % 64 == 0) return Lo > 128 ? FwdCfg{64, 256} : FwdCfg{64, 128};
+// Tile choice: the largest channel tile that still gives >= 2 workgroups per CU (512), so two
+// workgroups can overlap each other's staging on every CU.
+static FwdCfg fwd_cfg(int N, int Cout, int Lo) {
+    if (Cout % 128 == 0 && (long long)(Cout / 128) * cdiv(Lo, 128) * N >= 512) return {128, 128};
+    if (Cout % 64 == 0) {
+        if (Lo > 128 && (long long)(Cout / 64) * cdiv(Lo, 256) * N >= 512) return {64, 256};
+        return {64, 128};
+    }
     return {32, 256};
 }
 
@@ -196,7 +221,7 @@ bool mfma_fwd_supported(int Cin, int Cout, int K, int pad) {
 
 int mfma_fwd_stat_partials(int N, int Cin, int Cout, int Lo) {
     (void)Cin;
-    return N * cdiv(Lo, fwd_cfg(Cout, Lo).t_t);
+    return N * cdiv(Lo, fwd_cfg(N, Cout, Lo).t_t);
 }
 
 template <int CO_T, int T_T, int WCO, int WT, int CI_C>
@@ -205,18 +230,18 @@ static void launch_fwd(const float *x, const float *wp, const float *bias, float
                        hipStream_t st) {
     dim3 grid(cdiv(Lo, T_T), Cout / CO_T, N), block(256);
     const int P = N * (int)grid.x;
-    if (partials)
-        hipLaunchKernelGGL((conv1d_mfma_fwd_kernel<CO_T, T_T, WCO, WT, CI_C, true>), grid, block, 0,
-                           st, x, wp, bias, y, partials, Cin, Cout, L, Lo, K, pad, P);
-    else
-        hipLaunchKernelGGL((conv1d_mfma_fwd_kernel<CO_T, T_T, WCO, WT, CI_C, false>), grid, block, 0,
-                           st, x, wp, bias, y, partials, Cin, Cout, L, Lo, K, pad, P);
+#define ECG_FWD(KKV, ST) \
+    hipLaunchKernelGGL((conv1d_mfma_fwd_kernel<CO_T, T_T, WCO, WT, CI_C, KKV, ST>), grid, block, 0, \
+                       st, x, wp, bias, y, partials, Cin, Cout, L, Lo, K, pad, P)
+    if (K == kKM) { if (partials) ECG_FWD(kKM, true); else ECG_FWD(kKM, false); }
+    else          { if (partials) ECG_FWD(0, true);   else ECG_FWD(0, false); }
+#undef ECG_FWD
 }
 
 int mfma_fwd(const float *x, const float *wp, const float *bias, float *y, float *partials, int N,
              int Cin, int Cout, int L, int K, int pad, hipStream_t st) {
     const int Lo = L + 2 * pad - K + 1;
-    const FwdCfg c = fwd_cfg(Cout, Lo);
+    const FwdCfg c = fwd_cfg(N, Cout, Lo);
     if (c.co_t == 128)
         launch_fwd<128, 128, 2, 2, 8>(x, wp, bias, y, partials, N, Cin, Cout, L, Lo, K, pad, st);
     else if (c.co_t == 64 && c.t_t == 256)
@@ -247,7 +272,8 @@ __global__ __launch_bounds__(256, 2) void conv1d_mfma_wgrad_kernel(
     constexpr int XSPAN = T_T + KK - 1;
     constexpr int XS = ((XSPAN - KK + 31) / 32) * 32 + KK;   // >= XSPAN and == KK (mod 32)
     constexpr int NCI = (R_T + KK - 2) / KK + 1;        // input channels a column tile can touch
-    constexpr int DEL = M_T * T_T, DLOADS = (DEL + 255) / 256;
+    constexpr int DEL = M_T * T_T, DLOADS = DEL / 256;
+    static_assert(DEL % 256 == 0, "dY tile must be a whole number of 256-thread passes");
     constexpr int XEL = NCI * XS, XLOADS = (XEL + 255) / 256;
     constexpr int ACCF = MC * MR * 16 * 64;             // floats of one wave's accumulators
     constexpr int STAGEF = M_T * DS + NCI * XS;
@@ -292,40 +318,48 @@ __global__ __launch_bounds__(256, 2) void conv1d_mfma_wgrad_kernel(
     const int ntt = (Lo + T_T - 1) / T_T;
     const int total = (n_end - n_begin) * ntt;
 
+    // unconditional staging loads, zero padding applied at commit (see the forward kernel)
+    static_assert(256 % T_T == 0 || T_T % 256 == 0, "dY tile rows per pass");
+    constexpr int RPP = (T_T >= 256) ? 1 : 256 / T_T;       // dY rows fetched per pass
+    constexpr int PPR = (T_T >= 256) ? T_T / 256 : 1;       // passes per dY row
+    const int drow0 = (T_T >= 256) ? 0 : tid / T_T, dtt = (T_T >= 256) ? tid : tid % T_T;
+    unsigned xmask = 0, dmask = 0;
+
     auto prefetch = [&](int it) {
         const int n = n_begin + it / ntt, t0 = (it % ntt) * T_T;
         const float *dyn = dy + ((size_t)n * Cout + co0) * Lo;
         const float *xn = x + (size_t)n * Cin * L;
+        dmask = 0;
 #pragma unroll
         for (int j = 0; j < DLOADS; ++j) {
-            const int e = tid + 256 * j;
-            const int row = e / T_T, tt = e - row * T_T;
-            float v = 0.f;
-            if (e < DEL && t0 + tt < Lo) v = dyn[(size_t)row * Lo + t0 + tt];
-            dreg[j] = v;
+            const int row = drow0 + (j / PPR) * RPP, tt = dtt + (j % PPR) * 256;
+            const int t = t0 + tt;
+            dreg[j] = dyn[(size_t)row * Lo + min(t, Lo - 1)];
+            dmask |= (t < Lo) ? (1u << (j % PPR)) : 0u;
         }
+        xmask = 0;
 #pragma unroll
         for (int j = 0; j < XLOADS; ++j) {
             const int e = tid + 256 * j;
             const int ci = e / XS, pos = e - ci * XS;
             const int sidx = t0 - pad + pos;
-            float v = 0.f;
-            if (e < XEL && ci_base + ci < Cin && pos < XSPAN && sidx >= 0 && sidx < L)
-                v = xn[(size_t)(ci_base + ci) * L + sidx];
-            xreg[j] = v;
+            const int cic = min(ci_base + ci, Cin - 1), sc = min(max(sidx, 0), L - 1);
+            xreg[j] = xn[(size_t)cic * L + sc];
+            xmask |= ((sidx >= 0) && (sidx < L)) ? (1u << j) : 0u;
         }
     };
     auto commit = [&]() {
 #pragma unroll
         for (int j = 0; j < DLOADS; ++j) {
-            const int e = tid + 256 * j;
-            const int row = e / T_T, tt = e - row * T_T;
-            if (e < DEL) dys[row * DS + tt] = dreg[j];
+            const int row = drow0 + (j / PPR) * RPP, tt = dtt + (j % PPR) * 256;
+            const unsigned keep = 0u - ((dmask >> (j % PPR)) & 1u);
+            dys[row * DS + tt] = __uint_as_float(__float_as_uint(dreg[j]) & keep);
         }
 #pragma unroll
         for (int j = 0; j < XLOADS; ++j) {
             const int e = tid + 256 * j;
-            if (e < XEL) xs[e] = xreg[j];
+            const unsigned keep = 0u - ((xmask >> j) & 1u);
+            if (256 * (j + 1) <= XEL || e < XEL) xs[e] = __uint_as_float(__float_as_uint(xreg[j]) & keep);
         }
     };
 
@@ -337,17 +371,15 @@ __global__ __launch_bounds__(256, 2) void conv1d_mfma_wgrad_kernel(
         if (it + 1 < total) prefetch(it + 1);
         const float *arow = dys + (wm0 + l31) * DS + wt0 + half;
         const float *brow = xs + wt0 + half;
-#pragma unroll 2
-        for (int tp = 0; tp < TW; tp += 2) {
+#pragma unroll 8
+        for (int tp = 0; tp < TW; tp += 2) {     // straight-line: TW/2 steps of (MC+MR reads, MC*MR MFMAs)
             float a[MC], b[MR];
 #pragma unroll
             for (int i = 0; i < MC; ++i) a[i] = arow[32 * i * DS + tp];
 #pragma unroll
             for (int j = 0; j < MR; ++j) b[j] = brow[xoff[j] + tp];
-            if (want_bias) {
 #pragma unroll
-                for (int i = 0; i < MC; ++i) bsum[i] += a[i];
-            }
+            for (int i = 0; i < MC; ++i) bsum[i] += a[i];     // bias-grad rides on the A fragments (VALU idle anyway)
 #pragma unroll
             for (int i = 0; i < MC; ++i)
 #pragma unroll

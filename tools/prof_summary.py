@@ -1,0 +1,29 @@
+#!/usr/bin/env python3
+"""Summarise a rocprofv3 --kernel-trace --stats run: per-kernel time per step, plus gaps.
+usage: tools/prof_summary.py <dir with *_kernel_stats.csv> <steps in the run> [top]"""
+import csv
+import glob
+import sys
+
+
+def main():
+    d, steps = sys.argv[1], float(sys.argv[2])
+    top = int(sys.argv[3]) if len(sys.argv) > 3 else 30
+    f = glob.glob(d + "/**/*_kernel_stats.csv", recursive=True)[0]
+    rows = list(csv.DictReader(open(f)))
+    tot = sum(float(r["TotalDurationNs"]) for r in rows)
+    print(f"kernel time per step: {tot / 1e6 / steps:.3f} ms over {sum(int(r['Calls']) for r in rows) / steps:.1f} launches/step")
+    for r in rows[:top]:
+        name = r["Name"].replace("void ecg::", "").replace("ecg::", "")[:64]
+        print(f"{name:64s} calls/step={int(r['Calls']) / steps:5.1f} avg_us={float(r['AverageNs']) / 1e3:8.1f} "
+              f"us/step={float(r['TotalDurationNs']) / 1e3 / steps:8.1f} {float(r['Percentage']):5.1f}%")
+    tr = glob.glob(d + "/**/*_kernel_trace.csv", recursive=True)
+    if tr:
+        ev = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"])) for r in csv.DictReader(open(tr[0])))
+        busy = sum(e - s for s, e in ev)
+        span = ev[-1][1] - ev[0][0]
+        print(f"trace: {len(ev)} dispatches, busy {busy / 1e6:.2f} ms of span {span / 1e6:.2f} ms ({100 * busy / span:.1f}% busy)")
+
+
+if __name__ == "__main__":
+    main()
