@@ -38,25 +38,38 @@ __device__ __forceinline__ int acc_row(int r, int half) { return (r & 3) + 8 * (
 // forward (and input-grad with flipped/transposed packed weights)
 // =======================================================================================
 // grid = (ceil(Lo/T_T), Cout/CO_T, N), 256 threads = 4 waves laid out WCO x WT over the tile.
-// KK > 0: kernel size known at compile time (fully unrolled tap loop); KK == 0: runtime K <= 15.
-template <int CO_T, int T_T, int WCO, int WT, int CI_C, int KK, bool STATS>
+//
+// Pipeline (per chunk of CI_C = 4 input channels = 30 reduction steps = 120 MFMAs per wave):
+//   LDS holds TWO chunk images.  While the MFMAs of chunk c run out of image c&1,
+//     steps  0..14: the registers holding chunk c+1 are written into image (c+1)&1,
+//     steps 15..29: the global loads of chunk c+2 are issued into those registers,
+//   one ds_write / global_load at a time between MFMA groups, and ONE barrier closes the chunk.
+//   So the matrix pipe never waits for a staging phase, and global latency has half a chunk
+//   (~4k cycles) plus the next commit window to land.
+// Staging loads are UNCONDITIONAL (clamped addresses; zero padding applied at commit time by
+// AND-ing with a bit mask): a load that is only used under a condition gets sunk into a branch
+// by hipcc and followed by s_waitcnt vmcnt(0) — one serialised L2 round trip per element.
+template <int CO_T, int T_T, int WCO, int WT, bool STATS>
 __global__ __launch_bounds__(256, 2) void conv1d_mfma_fwd_kernel(
     const float *__restrict__ x, const float *__restrict__ wp, const float *__restrict__ bias,
-    float *__restrict__ y, float *__restrict__ partials, int Cin, int Cout, int L, int Lo, int K,
-    int pad, int P) {
+    float *__restrict__ y, float *__restrict__ partials, int Cin, int Cout, int L, int Lo, int pad,
+    int P) {
     static_assert(WCO * WT == 4, "4 waves per workgroup");
+    constexpr int KK = kKM, CI_C = 4, NST = KK * CI_C / 2, HALF = NST / 2;
     constexpr int MC = CO_T / WCO / 32, MT = T_T / WT / 32;
     static_assert(MC >= 1 && MT >= 1, "wave tile must hold at least one 32x32 accumulator");
-    static_assert(256 % (CO_T / 4) == 0, "weight rows per pass");
-    constexpr int XS = T_T + 32;                 // x-tile row stride (span T_T + K - 1 <= T_T + 14)
-    constexpr int WF4 = kKM * CI_C * CO_T / 4;   // float4s of one weight chunk [K][CI_C][CO_T]
+    constexpr int XS = T_T + 16;                 // x-tile row stride (span T_T + 14)
+    constexpr int C4 = CO_T / 4;
+    constexpr int WF4 = KK * CI_C * C4;          // 16-byte pieces of one weight chunk [K][CI_C][CO_T]
     constexpr int WLOADS = (WF4 + 255) / 256;
     constexpr int XEL = CI_C * XS;
     constexpr int XLOADS = (XEL + 255) / 256;
-    constexpr int C4 = CO_T / 4;
+    constexpr int NOPS = WLOADS + XLOADS;        // staging operations per chunk (per thread)
+    constexpr int WSZ = KK * CI_C * CO_T, IMG = WSZ + XEL;
+    static_assert(256 % C4 == 0, "weight rows per pass");
+    static_assert(XLOADS <= 32, "x mask bits");
 
-    __shared__ __attribute__((aligned(16))) float ws[kKM * CI_C * CO_T];
-    __shared__ float xs[CI_C * XS];
+    __shared__ __attribute__((aligned(16))) float lds[2 * IMG];
     __shared__ float red[STATS ? 4 * (CO_T / WCO) * 2 : 1];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -75,84 +88,100 @@ __global__ __launch_bounds__(256, 2) void conv1d_mfma_fwd_kernel(
 
     f32x4 wreg[WLOADS];
     float xreg[XLOADS];
-
-    // Staging loads are UNCONDITIONAL: every address is clamped into the tensor and the zero
-    // padding is applied later, at commit time, by AND-ing with a per-thread bit mask.  (A load
-    // whose value is only used under a condition gets sunk into a branch by hipcc and followed
-    // by s_waitcnt vmcnt(0) — one serialised L2 round trip per element.)  Weights are never
-    // masked: rows past the chunk multiply x rows that ARE zeroed.
+    unsigned xmask = 0;
     constexpr int RPP = 256 / C4;                 // weight rows fetched per pass of 256 threads
     const int wrow0 = tid / C4, wc4 = (tid % C4) * 4;
-    unsigned xmask = 0;
 
-    auto prefetch = [&](int ci0) {
+    // ---- one staging op = one global load (issue) or one LDS write (commit) ----------------
+    auto load_op = [&](int o, int ci0) {
         const int nci = min(CI_C, Cin - ci0);
-#pragma unroll
-        for (int j = 0; j < WLOADS; ++j) {
-            const int row = min(wrow0 + j * RPP, kKM * CI_C - 1);
+        if (o < WLOADS) {
+            const int row = min(wrow0 + o * RPP, KK * CI_C - 1);
             const int k = row / CI_C, ci = row - k * CI_C;
-            const int kc = min(k, K - 1), cic = min(ci, nci - 1);
-            wreg[j] = *reinterpret_cast<const f32x4 *>(
-                wp + ((size_t)kc * Cin + ci0 + cic) * Cout + co0 + wc4);
-        }
-        xmask = 0;
-#pragma unroll
-        for (int j = 0; j < XLOADS; ++j) {
+            wreg[o] = *reinterpret_cast<const f32x4 *>(
+                wp + ((size_t)k * Cin + ci0 + min(ci, nci - 1)) * Cout + co0 + wc4);
+        } else {
+            const int j = o - WLOADS;
             const int e = tid + 256 * j;
             const int ci = e / XS, pos = e - ci * XS;
             const int s = t0 - pad + pos;
-            const int cic = min(ci, nci - 1), sc = min(max(s, 0), L - 1);
-            xreg[j] = xn[(size_t)(ci0 + cic) * L + sc];
-            xmask |= ((ci < nci) && (s >= 0) && (s < L)) ? (1u << j) : 0u;
+            xreg[j] = xn[(size_t)(ci0 + min(ci, nci - 1)) * L + min(max(s, 0), L - 1)];
+            const unsigned bit = ((ci < nci) && (s >= 0) && (s < L)) ? (1u << j) : 0u;
+            xmask = (j == 0) ? bit : (xmask | bit);
         }
     };
-    auto commit = [&]() {
-#pragma unroll
-        for (int j = 0; j < WLOADS; ++j) {
-            const int f = tid + 256 * j;
-            if (256 * (j + 1) <= WF4 || f < WF4) *reinterpret_cast<f32x4 *>(ws + 4 * f) = wreg[j];
-        }
-#pragma unroll
-        for (int j = 0; j < XLOADS; ++j) {
+    auto commit_op = [&](int o, float *img) {
+        if (o < WLOADS) {
+            const int f = tid + 256 * o;
+            if (256 * (o + 1) <= WF4 || f < WF4) *reinterpret_cast<f32x4 *>(img + 4 * f) = wreg[o];
+        } else {
+            const int j = o - WLOADS;
             const int e = tid + 256 * j;
             const unsigned keep = 0u - ((xmask >> j) & 1u);
-            if (256 * (j + 1) <= XEL || e < XEL) xs[e] = __uint_as_float(__float_as_uint(xreg[j]) & keep);
+            if (256 * (j + 1) <= XEL || e < XEL)
+                img[WSZ + e] = __uint_as_float(__float_as_uint(xreg[j]) & keep);
         }
     };
 
-    prefetch(0);
-    for (int ci0 = 0; ci0 < Cin; ci0 += CI_C) {
-        __syncthreads();          // everyone is done reading the previous chunk
-        commit();
-        __syncthreads();
-        if (ci0 + CI_C < Cin) prefetch(ci0 + CI_C);   // global loads fly under the MFMAs below
-        // one reduction step = one (tap, ci-pair): MC + MT LDS reads feed MC*MT MFMAs
-        auto step = [&](int k, int cp) {
+    const int nchunks = (Cin + CI_C - 1) / CI_C;
+    // prologue: chunk 0 -> image 0, chunk 1 -> registers
+#pragma unroll
+    for (int o = 0; o < NOPS; ++o) load_op(o, 0);
+#pragma unroll
+    for (int o = 0; o < NOPS; ++o) commit_op(o, lds);
+    if (nchunks > 1) {
+#pragma unroll
+        for (int o = 0; o < NOPS; ++o) load_op(o, CI_C);
+    }
+    __syncthreads();
+
+    for (int c = 0; c < nchunks; ++c) {
+        const float *ws = lds + (c & 1) * IMG, *xs = ws + WSZ;
+        float *nxt = lds + ((c + 1) & 1) * IMG;
+        const bool do_commit = c + 1 < nchunks, do_load = c + 2 < nchunks;
+        const int ci_next2 = (c + 2) * CI_C;
+
+        // One reduction step = one (tap, ci-pair): MC + MT LDS reads feed MC*MT MFMAs; the
+        // fragments of step s+1 are read BEFORE the MFMAs of step s are issued.
+        auto ld = [&](int st, float *a, float *b) {
+            const int k = st / (CI_C / 2), cp = st % (CI_C / 2);
             const float *wrow = ws + ((k * CI_C + 2 * cp + half) * CO_T + wco + l31);
             const float *xrow = xs + (2 * cp + half) * XS + wt + l31 + k;
-            float a[MC], b[MT];
 #pragma unroll
             for (int i = 0; i < MC; ++i) a[i] = wrow[32 * i];
 #pragma unroll
             for (int i = 0; i < MT; ++i) b[i] = xrow[32 * i];
+        };
+        float a_c[MC], b_c[MT], a_n[MC], b_n[MT];
+        ld(0, a_c, b_c);
+#pragma unroll
+        for (int st = 0; st < NST; ++st) {
+            ld(st + 1 < NST ? st + 1 : 0, a_n, b_n);
+            // staging ops of this step: commits in the first half, load issues in the second
+            if (st < HALF) {
+                if (do_commit) {
+#pragma unroll
+                    for (int o = st * NOPS / HALF; o < (st + 1) * NOPS / HALF; ++o) commit_op(o, nxt);
+                }
+            } else {
+                if (do_load) {
+#pragma unroll
+                    for (int o = (st - HALF) * NOPS / (NST - HALF); o < (st - HALF + 1) * NOPS / (NST - HALF); ++o)
+                        load_op(o, ci_next2);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);     // keep reads + staging ABOVE this step's MFMAs
 #pragma unroll
             for (int i = 0; i < MC; ++i)
 #pragma unroll
-                for (int j = 0; j < MT; ++j) acc[i][j] = mfma32(a[i], b[j], acc[i][j]);
-        };
-        if (KK > 0) {
-            // The tap loop stays rolled: a fully unrolled 60-step body makes hipcc hoist dozens of
-            // LDS reads, run out of VGPRs and park the prefetched chunk in scratch (which also
-            // forces an early vmcnt wait: no load/MFMA overlap).
-#pragma unroll 1
-            for (int k = 0; k < KK; ++k)
+                for (int j = 0; j < MT; ++j) acc[i][j] = mfma32(a_c[i], b_c[j], acc[i][j]);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int cp = 0; cp < CI_C / 2; ++cp) step(k, cp);
-        } else {
-            for (int k = 0; k < K; ++k)
+            for (int i = 0; i < MC; ++i) a_c[i] = a_n[i];
 #pragma unroll
-                for (int cp = 0; cp < CI_C / 2; ++cp) step(k, cp);
+            for (int i = 0; i < MT; ++i) b_c[i] = b_n[i];
         }
+        __syncthreads();      // image c&1 free for chunk c+2's commit; image (c+1)&1 complete
     }
 
     // ---- epilogue: bias, store, per-channel (sum, sum^2) partials --------------------------
@@ -216,7 +245,7 @@ static FwdCfg fwd_cfg(int N, int Cout, int Lo) {
 
 bool mfma_fwd_supported(int Cin, int Cout, int K, int pad) {
     (void)pad;
-    return K <= kKM && Cin % 2 == 0 && Cout % 32 == 0;
+    return K == kKM && Cin % 2 == 0 && Cout % 32 == 0;   // other kernel sizes take the direct path
 }
 
 int mfma_fwd_stat_partials(int N, int Cin, int Cout, int Lo) {
@@ -224,18 +253,18 @@ int mfma_fwd_stat_partials(int N, int Cin, int Cout, int Lo) {
     return N * cdiv(Lo, fwd_cfg(N, Cout, Lo).t_t);
 }
 
-template <int CO_T, int T_T, int WCO, int WT, int CI_C>
+template <int CO_T, int T_T, int WCO, int WT>
 static void launch_fwd(const float *x, const float *wp, const float *bias, float *y,
-                       float *partials, int N, int Cin, int Cout, int L, int Lo, int K, int pad,
+                       float *partials, int N, int Cin, int Cout, int L, int Lo, int pad,
                        hipStream_t st) {
     dim3 grid(cdiv(Lo, T_T), Cout / CO_T, N), block(256);
     const int P = N * (int)grid.x;
-#define ECG_FWD(KKV, ST) \
-    hipLaunchKernelGGL((conv1d_mfma_fwd_kernel<CO_T, T_T, WCO, WT, CI_C, KKV, ST>), grid, block, 0, \
-                       st, x, wp, bias, y, partials, Cin, Cout, L, Lo, K, pad, P)
-    if (K == kKM) { if (partials) ECG_FWD(kKM, true); else ECG_FWD(kKM, false); }
-    else          { if (partials) ECG_FWD(0, true);   else ECG_FWD(0, false); }
-#undef ECG_FWD
+    if (partials)
+        hipLaunchKernelGGL((conv1d_mfma_fwd_kernel<CO_T, T_T, WCO, WT, true>), grid, block, 0, st, x,
+                           wp, bias, y, partials, Cin, Cout, L, Lo, pad, P);
+    else
+        hipLaunchKernelGGL((conv1d_mfma_fwd_kernel<CO_T, T_T, WCO, WT, false>), grid, block, 0, st, x,
+                           wp, bias, y, partials, Cin, Cout, L, Lo, pad, P);
 }
 
 int mfma_fwd(const float *x, const float *wp, const float *bias, float *y, float *partials, int N,
@@ -243,15 +272,13 @@ int mfma_fwd(const float *x, const float *wp, const float *bias, float *y, float
     const int Lo = L + 2 * pad - K + 1;
     const FwdCfg c = fwd_cfg(N, Cout, Lo);
     if (c.co_t == 128)
-        launch_fwd<128, 128, 2, 2, 8>(x, wp, bias, y, partials, N, Cin, Cout, L, Lo, K, pad, st);
+        launch_fwd<128, 128, 2, 2>(x, wp, bias, y, partials, N, Cin, Cout, L, Lo, pad, st);
     else if (c.co_t == 64 && c.t_t == 256)
-        launch_fwd<64, 256, 1, 4, 8>(x, wp, bias, y, partials, N, Cin, Cout, L, Lo, K, pad, st);
+        launch_fwd<64, 256, 1, 4>(x, wp, bias, y, partials, N, Cin, Cout, L, Lo, pad, st);
     else if (c.co_t == 64)
-        launch_fwd<64, 128, 2, 2, 8>(x, wp, bias, y, partials, N, Cin, Cout, L, Lo, K, pad, st);
-    else if (Cin % 12 == 0 && Cin % 8 != 0)
-        launch_fwd<32, 256, 1, 4, 12>(x, wp, bias, y, partials, N, Cin, Cout, L, Lo, K, pad, st);
+        launch_fwd<64, 128, 2, 2>(x, wp, bias, y, partials, N, Cin, Cout, L, Lo, pad, st);
     else
-        launch_fwd<32, 256, 1, 4, 8>(x, wp, bias, y, partials, N, Cin, Cout, L, Lo, K, pad, st);
+        launch_fwd<32, 256, 1, 4>(x, wp, bias, y, partials, N, Cin, Cout, L, Lo, pad, st);
     return check_launch("conv1d_mfma_fwd_kernel");
 }
 
@@ -371,19 +398,29 @@ __global__ __launch_bounds__(256, 2) void conv1d_mfma_wgrad_kernel(
         if (it + 1 < total) prefetch(it + 1);
         const float *arow = dys + (wm0 + l31) * DS + wt0 + half;
         const float *brow = xs + wt0 + half;
-#pragma unroll 8
-        for (int tp = 0; tp < TW; tp += 2) {     // straight-line: TW/2 steps of (MC+MR reads, MC*MR MFMAs)
-            float a[MC], b[MR];
+        auto ld = [&](int tp, float *a, float *b) {
 #pragma unroll
             for (int i = 0; i < MC; ++i) a[i] = arow[32 * i * DS + tp];
 #pragma unroll
             for (int j = 0; j < MR; ++j) b[j] = brow[xoff[j] + tp];
+        };
+        float a_c[MC], b_c[MR], a_n[MC], b_n[MR];
+        ld(0, a_c, b_c);
+#pragma unroll 8
+        for (int tp = 0; tp < TW; tp += 2) {     // next step's fragments are read before this step's MFMAs
+            ld((tp + 2 < TW) ? tp + 2 : 0, a_n, b_n);
+            __builtin_amdgcn_sched_barrier(0);         // keep the next-step reads ABOVE these MFMAs
 #pragma unroll
-            for (int i = 0; i < MC; ++i) bsum[i] += a[i];     // bias-grad rides on the A fragments (VALU idle anyway)
+            for (int i = 0; i < MC; ++i) bsum[i] += a_c[i];     // bias-grad rides on the A fragments (VALU idle anyway)
 #pragma unroll
             for (int i = 0; i < MC; ++i)
 #pragma unroll
-                for (int j = 0; j < MR; ++j) acc[i][j] = mfma32(a[i], b[j], acc[i][j]);
+                for (int j = 0; j < MR; ++j) acc[i][j] = mfma32(a_c[i], b_c[j], acc[i][j]);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < MC; ++i) a_c[i] = a_n[i];
+#pragma unroll
+            for (int j = 0; j < MR; ++j) b_c[j] = b_n[j];
         }
     }
 
@@ -466,7 +503,8 @@ static WgCfg wgrad_cfg(int N, int Cin, int Cout) {
     else if (Cout % 64 == 0) c = {64, 128, 0};
     else c = {32, 192, 0};
     const int tiles = cdiv(R, c.r_t) * (Cout / c.m_t);
-    int s = cdiv(512, tiles);          // ~2 workgroups per CU
+    int s = 512 / tiles;               // fill, but never exceed, the 2 x 256 resident-workgroup slots:
+                                       // one workgroup over and the launch takes two rounds
     if (s > N) s = N;
     if (s < 1) s = 1;
     c.splits = s;
