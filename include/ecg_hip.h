@@ -123,6 +123,17 @@ int ecg_bn_relu_pool_bwd(const float *y, const float *dp, const float *gamma, co
                          float *dy, float *dgamma, float *dbeta, float *ws,
                          int N, int C, int L, int train, ecg_stream_t stream);
 
+/* Last block of the backbone fused with AdaptiveAvgPool1d(1) (src/models/ecg_cnn.py:46,62):
+ * g[n,c] = mean_j max(0, max(a[2j], a[2j+1])) — the pooled tensor is never materialised.
+ * Backward takes dg [N][C] (gradient of g); same workspace as ecg_bn_relu_pool_bwd. */
+int ecg_bn_relu_pool_gap_fwd(const float *y, const float *gamma, const float *beta,
+                             const float *mean, const float *invstd, float *g,
+                             int N, int C, int L, ecg_stream_t stream);
+int ecg_bn_relu_pool_gap_bwd(const float *y, const float *dg, const float *gamma, const float *beta,
+                             const float *mean, const float *invstd,
+                             float *dy, float *dgamma, float *dbeta, float *ws,
+                             int N, int C, int L, int train, ecg_stream_t stream);
+
 /* Unfused leaves (used when a caller hooks an inner module, e.g. Grad-CAM on net[0]:
  * scripts/00_demo_inference.py:36-37). */
 int ecg_bn_apply_fwd(const float *y, const float *gamma, const float *beta, const float *mean,
@@ -166,6 +177,47 @@ int ecg_bce_logits_fwd(const float *x, const float *target, float *loss, float *
                        int numel, ecg_stream_t stream);
 /* prob = sigmoid(x) — src/training/loop.py:63 */
 int ecg_sigmoid_fwd(const float *x, float *prob, size_t n, ecg_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * Fused tail — everything after the global average pool in three launches.
+ * Dimensions: M samples; F0 = backbone width (256); F = feat_dim; D = demo_dim (5);
+ * H1 = first demographic layer (64); H = demo_hidden_dim; C = num_labels.
+ * ---------------------------------------------------------------------------------- */
+
+/* wT[c][r] = w[r][c]  (w [rows][cols]).  ecg_tail_fwd consumes Linear weights transposed. */
+int ecg_transpose(const float *w, float *wT, int rows, int cols, ecg_stream_t stream);
+
+/* z = g Wp^T + bp                                   (ECGCNN.proj / ECGBackbone.proj)
+ * xd != NULL (ECGMultimodal.forward, src/models/ecg_multimodal.py:88-99):
+ *   h1 = relu(xd W0^T + b0); h2 = relu(h1 W2^T + b2); film = h2 Wf^T + bf;
+ *   zc = (1 + tanh(film[:, :F])) * z + film[:, F:];  logits = zc Wh^T + bh
+ * xd == NULL (ECGCNN.forward, src/models/ecg_cnn.py:63-64):  logits = z Wh^T + bh
+ * WpT [F0][F] and WfT [H][2F] are TRANSPOSED weights (ecg_transpose); the small W0 [H1][D],
+ * W2 [H][H1] and Wh [C][F] are in state_dict layout.
+ * Outputs z [M][F], logits [M][C] and, on the demographic path, h1, h2, film [M][2F], zc. */
+int ecg_tail_fwd(const float *g, const float *xd, const float *WpT, const float *bp,
+                 const float *W0, const float *b0, const float *W2, const float *b2,
+                 const float *WfT, const float *bf, const float *Wh, const float *bh,
+                 float *z, float *h1, float *h2, float *film, float *zc, float *logits,
+                 int M, int F0, int F, int D, int H1, int H, int C, ecg_stream_t stream);
+
+/* Per-sample backward chain of the tail.  Weights in state_dict layout (Wp [F][F0], W0 [H1][D],
+ * W2 [H][H1], Wf [2F][H], Wh [C][F]).  dz_extra (nullable) is added to d z (gradient arriving
+ * at z from outside, e.g. return_features).  Outputs: dz [M][F], dg [M][F0]; with demo != 0
+ * also dzc [M][F], dfilm [M][2F], dh2m [M][H], dh1m [M][H1] (ReLU-masked) and dxd [M][D] (nullable). */
+int ecg_tail_bwd_chain(const float *dlogits, const float *dz_extra, const float *z,
+                       const float *h1, const float *h2, const float *film,
+                       const float *Wp, const float *W0, const float *W2, const float *Wf,
+                       const float *Wh, float *dzc, float *dz, float *dfilm, float *dh2m,
+                       float *dh1m, float *dg, float *dxd, int M, int F0, int F, int D,
+                       int H1, int H, int C, int demo, ecg_stream_t stream);
+
+/* count (<= 8) Linear weight/bias gradients in one launch:
+ * dW[q][o][i] = sum_m G[q][m][o] * X[q][m][i];  db[q][o] = sum_m G[q][m][o] (db[q] nullable).
+ * G, X, dW, db, Out, In are HOST arrays of length count. */
+int ecg_linear_wgrad_grouped(const float *const *G, const float *const *X, float *const *dW,
+                             float *const *db, const int *Out, const int *In, int count,
+                             int M, ecg_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
  * Optimizer — torch.optim.AdamW defaults over one flat fp32 buffer

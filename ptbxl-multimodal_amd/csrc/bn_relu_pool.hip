@@ -92,6 +92,27 @@ __global__ __launch_bounds__(kBlock) void bn_relu_pool_fwd_kernel(
     p[idx] = m > 0.f ? m : 0.f;
 }
 
+// Last block of the backbone: BatchNorm -> ReLU -> MaxPool(2) -> AdaptiveAvgPool1d(1) without
+// materialising the pooled tensor.  One wave per (n, c) row; g[row] = mean_j pooled[row][j].
+__global__ __launch_bounds__(kBlock) void bn_relu_pool_gap_fwd_kernel(
+    const float *__restrict__ y, const float *__restrict__ gamma, const float *__restrict__ beta,
+    const float *__restrict__ mean, const float *__restrict__ invstd, float *__restrict__ g,
+    int C, int L, int Lp, int rows) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int lane = threadIdx.x & 63, c = row % C;
+    const float sc = invstd[c] * gamma[c], mu = mean[c], be = beta[c];
+    const float *r = y + (size_t)row * L;
+    float a = 0.f;
+    for (int j = lane; j < Lp; j += 64) {
+        float a0 = bn_apply1(r[2 * j], mu, sc, be), a1 = bn_apply1(r[2 * j + 1], mu, sc, be);
+        float m = a1 > a0 ? a1 : a0;
+        a += m > 0.f ? m : 0.f;
+    }
+    a = wave_sum(a);
+    if (lane == 0) g[row] = a / (float)Lp;
+}
+
 __global__ __launch_bounds__(kBlock) void bn_apply_fwd_kernel(
     const float *__restrict__ y, const float *__restrict__ gamma, const float *__restrict__ beta,
     const float *__restrict__ mean, const float *__restrict__ invstd, float *__restrict__ out,
@@ -113,12 +134,15 @@ __device__ __forceinline__ bool pool_route(float y0, float y1, float mu, float s
 }
 
 // partials[c][s][2] = (sum da, sum da*xhat).  FUSED: da routed from dp through pool+ReLU;
-// otherwise da = dout (plain BatchNorm backward).  grid = (C, S)
+// otherwise da = dout (plain BatchNorm backward).  grid = (C, S).
+// bcast != 0 (FUSED only): dp[row][j] = g[row] * bcast for every j — the gradient of a global
+// average pool that was fused behind the max-pool (g = dG [N*C], bcast = 1/Lp).
 template <bool FUSED>
 __global__ __launch_bounds__(kBlock) void bn_bwd_reduce_kernel(
     const float *__restrict__ y, const float *__restrict__ g, const float *__restrict__ gamma,
     const float *__restrict__ beta, const float *__restrict__ mean,
-    const float *__restrict__ invstd, float *__restrict__ partials, int N, int C, int L, int S) {
+    const float *__restrict__ invstd, float *__restrict__ partials, int N, int C, int L, int S,
+    float bcast) {
     __shared__ float red[4][2];
     const int c = blockIdx.x, s = blockIdx.y, tl = threadIdx.x;
     const int n0 = (int)((long long)N * s / S), n1 = (int)((long long)N * (s + 1) / S);
@@ -129,11 +153,12 @@ __global__ __launch_bounds__(kBlock) void bn_bwd_reduce_kernel(
         const float *r = y + ((size_t)n * C + c) * L;
         if (FUSED) {
             const float *gr = g + ((size_t)n * C + c) * Lp;
+            const float gb = bcast != 0.f ? g[(size_t)n * C + c] * bcast : 0.f;
             for (int j = tl; j < Lp; j += kBlock) {
                 float y0 = r[2 * j], y1 = r[2 * j + 1];
                 int am;
                 if (pool_route(y0, y1, mu, sc, be, am)) {
-                    float d = gr[j];
+                    float d = bcast != 0.f ? gb : gr[j];
                     a += d;
                     q = __fmaf_rn(d, ((am ? y1 : y0) - mu) * is, q);
                 }
@@ -180,7 +205,7 @@ __global__ __launch_bounds__(kBlock) void bn_bwd_dx_kernel(
     const float *__restrict__ y, const float *__restrict__ g, const float *__restrict__ gamma,
     const float *__restrict__ beta, const float *__restrict__ mean,
     const float *__restrict__ invstd, const float *__restrict__ coef, float *__restrict__ dy,
-    int C, int L, int Lh, size_t total) {
+    int C, int L, int Lh, size_t total, float bcast) {
     size_t idx = (size_t)blockIdx.x * kBlock + threadIdx.x;
     if (idx >= total) return;
     size_t row = idx / Lh;
@@ -198,7 +223,7 @@ __global__ __launch_bounds__(kBlock) void bn_bwd_dx_kernel(
         if (has1) {   // an odd tail sample never reaches the pool: da = 0
             int am;
             if (pool_route(y0, y1, mu, sc, beta[c], am)) {
-                float v = g[row * (size_t)(L >> 1) + j];
+                float v = bcast != 0.f ? g[row] * bcast : g[row * (size_t)(L >> 1) + j];
                 if (am) da1 = v; else da0 = v;
             }
         }
@@ -309,6 +334,19 @@ ECG_API int ecg_bn_relu_pool_fwd(const float *y, const float *gamma, const float
     return check_launch("bn_relu_pool_fwd_kernel");
 }
 
+ECG_API int ecg_bn_relu_pool_gap_fwd(const float *y, const float *gamma, const float *beta,
+                                     const float *mean, const float *invstd, float *g, int N,
+                                     int C, int L, ecg_stream_t stream) {
+    int rc = check_ncl("bn_relu_pool_gap_fwd", N, C, L);
+    if (rc) return rc;
+    ECG_REQUIRE(y && gamma && beta && mean && invstd && g, "bn_relu_pool_gap_fwd: null pointer");
+    ECG_REQUIRE(L >= 2, "bn_relu_pool_gap_fwd: L=%d leaves an empty pooled row", L);
+    const int rows = N * C;
+    hipLaunchKernelGGL(bn_relu_pool_gap_fwd_kernel, dim3(cdiv(rows, 4)), dim3(kBlock), 0,
+                       as_stream(stream), y, gamma, beta, mean, invstd, g, C, L, L / 2, rows);
+    return check_launch("bn_relu_pool_gap_fwd_kernel");
+}
+
 ECG_API size_t ecg_bn_relu_pool_bwd_ws_floats(int N, int C, int L) {
     (void)L;
     return (size_t)C * stat_splits(N, C) * 2 + (size_t)C * 2;
@@ -318,11 +356,12 @@ ECG_API size_t ecg_bn_bwd_ws_floats(int N, int C, int L) { return ecg_bn_relu_po
 template <bool FUSED>
 static int bn_bwd_impl(const float *y, const float *g, const float *gamma, const float *beta,
                        const float *mean, const float *invstd, float *dy, float *dgamma,
-                       float *dbeta, float *ws, int N, int C, int L, int train, hipStream_t st) {
+                       float *dbeta, float *ws, int N, int C, int L, int train, hipStream_t st,
+                       float bcast = 0.f) {
     const int S = stat_splits(N, C);
     float *partials = ws, *coef = ws + (size_t)C * S * 2;
     hipLaunchKernelGGL((bn_bwd_reduce_kernel<FUSED>), dim3(C, S), dim3(kBlock), 0, st, y, g, gamma,
-                       beta, mean, invstd, partials, N, C, L, S);
+                       beta, mean, invstd, partials, N, C, L, S, bcast);
     int rc = check_launch("bn_bwd_reduce_kernel");
     if (rc) return rc;
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(64), 0, st, partials, S,
@@ -332,7 +371,7 @@ static int bn_bwd_impl(const float *y, const float *g, const float *gamma, const
     const int Lh = (L + 1) / 2;
     size_t total = (size_t)N * C * Lh;
     hipLaunchKernelGGL((bn_bwd_dx_kernel<FUSED>), dim3(cdiv(total, kBlock)), dim3(kBlock), 0, st, y,
-                       g, gamma, beta, mean, invstd, coef, dy, C, L, Lh, total);
+                       g, gamma, beta, mean, invstd, coef, dy, C, L, Lh, total, bcast);
     return check_launch("bn_bwd_dx_kernel");
 }
 
@@ -404,3 +443,17 @@ ECG_API int ecg_maxpool2_bwd(const float *x, const float *dp, float *dx, int row
                        x, dp, dx, L, Lh, total);
     return check_launch("maxpool2_bwd_kernel");
 }
+
+ECG_API int ecg_bn_relu_pool_gap_bwd(const float *y, const float *dg, const float *gamma,
+                                     const float *beta, const float *mean, const float *invstd,
+                                     float *dy, float *dgamma, float *dbeta, float *ws, int N,
+                                     int C, int L, int train, ecg_stream_t stream) {
+    int rc = check_ncl("bn_relu_pool_gap_bwd", N, C, L);
+    if (rc) return rc;
+    ECG_REQUIRE(y && dg && gamma && beta && mean && invstd && dy && ws,
+                "bn_relu_pool_gap_bwd: null pointer");
+    ECG_REQUIRE(L >= 2, "bn_relu_pool_gap_bwd: L=%d leaves an empty pooled row", L);
+    return bn_bwd_impl<true>(y, dg, gamma, beta, mean, invstd, dy, dgamma, dbeta, ws, N, C, L,
+                             train, as_stream(stream), 1.0f / (float)(L / 2));
+}
+

@@ -1,0 +1,393 @@
+// tail_fused.hip — the whole network tail in three launches instead of ~25:
+//   ecg_tail_fwd          proj Linear, demographic MLP (2 x Linear+ReLU), film_gen Linear, FiLM
+//                         fusion and the head Linear, for SB samples per workgroup;
+//   ecg_tail_bwd_chain    the per-sample backward chain (d logits -> d zc -> d z / d film ->
+//                         d h2 -> d h1 -> d x_demo, d g), emitting the masked gradient matrices;
+//   ecg_linear_wgrad_grouped   every weight / bias gradient of the tail (5 small GEMMs over the
+//                         batch dimension) as ONE grouped launch.
+// All tensors are <= [B, 512]; the arithmetic is negligible (53 MFLOP at B=256), so the design
+// target is launch count and dependent-load latency, not FLOP/s.
+//
+// Replaces the ATen addmm/relu/tanh/mul/add chain behind
+//   ECGCNN.proj/head                  reference src/models/ecg_cnn.py:47-50,63-64
+//   ECGBackbone.proj, DemoEncoder.mlp, film_gen, FiLM, head
+//                                     reference src/models/ecg_multimodal.py:35,51-59,85-98
+#include "common.h"
+
+namespace ecg {
+
+constexpr int kSB = 4;   // samples per workgroup
+constexpr int kLB = 16;  // global loads issued back-to-back before their first use
+
+// acc[s] += sum_{i<n} v_s[i][s] * w[i * stride]   (v_s in LDS as [n][kSB], w walks global memory).
+// These loops are chains of dependent-looking L2 loads; hipcc keeps each load next to its FMA and
+// waits vmcnt(0) per element unless the loads are first gathered into a register batch.
+__device__ __forceinline__ void dot_rows(float (&acc)[kSB], const float *__restrict__ v_s,
+                                         const float *__restrict__ w, size_t stride, int n) {
+    int i = 0;
+    for (; i + kLB <= n; i += kLB) {
+        float wv[kLB];
+#pragma unroll
+        for (int u = 0; u < kLB; ++u) wv[u] = w[(size_t)(i + u) * stride];
+#pragma unroll
+        for (int u = 0; u < kLB; ++u) {
+            const float4 v = *reinterpret_cast<const float4 *>(v_s + (i + u) * kSB);
+            acc[0] = __fmaf_rn(v.x, wv[u], acc[0]); acc[1] = __fmaf_rn(v.y, wv[u], acc[1]);
+            acc[2] = __fmaf_rn(v.z, wv[u], acc[2]); acc[3] = __fmaf_rn(v.w, wv[u], acc[3]);
+        }
+    }
+    for (; i < n; ++i) {
+        const float wv = w[(size_t)i * stride];
+        const float4 v = *reinterpret_cast<const float4 *>(v_s + i * kSB);
+        acc[0] = __fmaf_rn(v.x, wv, acc[0]); acc[1] = __fmaf_rn(v.y, wv, acc[1]);
+        acc[2] = __fmaf_rn(v.z, wv, acc[2]); acc[3] = __fmaf_rn(v.w, wv, acc[3]);
+    }
+}
+
+// acc += sum_{i<n} v_s[i][s] * w[i * stride]  for ONE sample column s
+__device__ __forceinline__ float dot_col(const float *__restrict__ v_s, int s,
+                                         const float *__restrict__ w, size_t stride, int n) {
+    float acc = 0.f;
+    int i = 0;
+    for (; i + kLB <= n; i += kLB) {
+        float wv[kLB];
+#pragma unroll
+        for (int u = 0; u < kLB; ++u) wv[u] = w[(size_t)(i + u) * stride];
+#pragma unroll
+        for (int u = 0; u < kLB; ++u) acc = __fmaf_rn(v_s[(i + u) * kSB + s], wv[u], acc);
+    }
+    for (; i < n; ++i) acc = __fmaf_rn(v_s[i * kSB + s], w[(size_t)i * stride], acc);
+    return acc;
+}
+
+struct TailFwdArgs {
+    const float *g, *xd;
+    const float *WpT, *bp, *W0, *b0, *W2, *b2, *WfT, *bf, *Wh, *bh;   // W0 [H1][D], W2 [H][H1]: state_dict layout
+    float *z, *h1, *h2, *film, *zc, *logits;
+    int M, F0, F, D, H1, H, C;
+};
+
+// dynamic LDS: g_s[F0][SB] | xd_s[D][SB] | h1_s[H1][SB] | h2_s[H][SB] | zc_s[F][SB]
+__global__ __launch_bounds__(256) void tail_fwd_kernel(TailFwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *g_s = smem, *xd_s = g_s + a.F0 * kSB, *h1_s = xd_s + a.D * kSB, *h2_s = h1_s + a.H1 * kSB,
+          *zc_s = h2_s + a.H * kSB;
+    const int tid = threadIdx.x, m0 = blockIdx.x * kSB;
+    const bool demo = a.xd != nullptr;
+
+    for (int e = tid; e < a.F0 * kSB; e += 256) {
+        int s = e / a.F0, i = e - s * a.F0;
+        g_s[i * kSB + s] = (m0 + s < a.M) ? a.g[(size_t)(m0 + s) * a.F0 + i] : 0.f;
+    }
+    if (demo)
+        for (int e = tid; e < a.D * kSB; e += 256) {
+            int s = e / a.D, i = e - s * a.D;
+            xd_s[i * kSB + s] = (m0 + s < a.M) ? a.xd[(size_t)(m0 + s) * a.D + i] : 0.f;
+        }
+    __syncthreads();
+
+    if (demo) {
+        // h1 = relu(xd W0^T + b0), h2 = relu(h1 W2^T + b2): thread <-> (sample, unit)
+        for (int e = tid; e < a.H1 * kSB; e += 256) {
+            int s = e / a.H1, j = e - s * a.H1;
+            float acc = a.b0[j] + dot_col(xd_s, s, a.W0 + (size_t)j * a.D, 1, a.D);
+            acc = acc > 0.f ? acc : 0.f;
+            h1_s[j * kSB + s] = acc;
+            if (m0 + s < a.M) a.h1[(size_t)(m0 + s) * a.H1 + j] = acc;
+        }
+        __syncthreads();
+        for (int e = tid; e < a.H * kSB; e += 256) {
+            int s = e / a.H, j = e - s * a.H;
+            float acc = a.b2[j] + dot_col(h1_s, s, a.W2 + (size_t)j * a.H1, 1, a.H1);
+            acc = acc > 0.f ? acc : 0.f;
+            h2_s[j * kSB + s] = acc;
+            if (m0 + s < a.M) a.h2[(size_t)(m0 + s) * a.H + j] = acc;
+        }
+        __syncthreads();
+    }
+
+    // z = g Wp^T + bp;  film = h2 Wf^T + bf;  zc = (1 + tanh(film_g)) * z + film_b: thread <-> feature o
+    for (int o = tid; o < a.F; o += 256) {
+        float zacc[kSB];
+        const float bpo = a.bp[o];
+#pragma unroll
+        for (int s = 0; s < kSB; ++s) zacc[s] = bpo;
+        dot_rows(zacc, g_s, a.WpT + o, (size_t)a.F, a.F0);
+        float zc[kSB];
+        if (demo) {
+            float fg[kSB], fb[kSB];
+            const float bg = a.bf[o], bb = a.bf[a.F + o];
+#pragma unroll
+            for (int s = 0; s < kSB; ++s) { fg[s] = bg; fb[s] = bb; }
+            dot_rows(fg, h2_s, a.WfT + o, (size_t)2 * a.F, a.H);
+            dot_rows(fb, h2_s, a.WfT + a.F + o, (size_t)2 * a.F, a.H);
+#pragma unroll
+            for (int s = 0; s < kSB; ++s) {
+                zc[s] = __fmaf_rn(1.0f + tanhf(fg[s]), zacc[s], fb[s]);
+                if (m0 + s < a.M) {
+                    a.film[(size_t)(m0 + s) * 2 * a.F + o] = fg[s];
+                    a.film[(size_t)(m0 + s) * 2 * a.F + a.F + o] = fb[s];
+                    a.zc[(size_t)(m0 + s) * a.F + o] = zc[s];
+                }
+            }
+        } else {
+#pragma unroll
+            for (int s = 0; s < kSB; ++s) zc[s] = zacc[s];
+        }
+#pragma unroll
+        for (int s = 0; s < kSB; ++s) {
+            zc_s[o * kSB + s] = zc[s];
+            if (m0 + s < a.M) a.z[(size_t)(m0 + s) * a.F + o] = zacc[s];
+        }
+    }
+    __syncthreads();
+
+    // logits = zc Wh^T + bh: one wave per (sample, label) pair
+    const int wave = tid >> 6, lane = tid & 63;
+    for (int p = wave; p < kSB * a.C; p += 4) {
+        const int s = p / a.C, c = p - s * a.C;
+        float acc = 0.f;
+        for (int o = lane; o < a.F; o += 64) acc = __fmaf_rn(zc_s[o * kSB + s], a.Wh[(size_t)c * a.F + o], acc);
+        acc = wave_sum(acc);
+        if (lane == 0 && m0 + s < a.M) a.logits[(size_t)(m0 + s) * a.C + c] = acc + a.bh[c];
+    }
+}
+
+struct TailBwdArgs {
+    const float *dlogits, *dz_extra, *z, *h1, *h2, *film;
+    const float *Wp, *W0, *W2, *Wf, *Wh;
+    float *dzc, *dz, *dfilm, *dh2m, *dh1m, *dg, *dxd;
+    int M, F0, F, D, H1, H, C, demo;
+};
+
+// dynamic LDS: dlog_s[C][SB] | dz_s[F][SB] | dfilm_s[2F][SB] | dh2_s[H][SB] | dh1_s[H1][SB]
+__global__ __launch_bounds__(256) void tail_bwd_chain_kernel(TailBwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *dlog_s = smem, *dz_s = dlog_s + a.C * kSB, *dfilm_s = dz_s + a.F * kSB,
+          *dh2_s = dfilm_s + 2 * a.F * kSB, *dh1_s = dh2_s + a.H * kSB;
+    const int tid = threadIdx.x, m0 = blockIdx.x * kSB;
+
+    for (int e = tid; e < a.C * kSB; e += 256) {
+        int s = e / a.C, c = e - s * a.C;
+        dlog_s[c * kSB + s] = (m0 + s < a.M) ? a.dlogits[(size_t)(m0 + s) * a.C + c] : 0.f;
+    }
+    __syncthreads();
+
+    // d zc = d logits Wh;  FiLM backward: d z = d zc (1+th), d film_g = d zc z (1-th^2), d film_b = d zc
+    for (int o = tid; o < a.F; o += 256) {
+        float d[kSB] = {0.f, 0.f, 0.f, 0.f};
+        for (int c = 0; c < a.C; ++c) {
+            const float w = a.Wh[(size_t)c * a.F + o];
+            const float4 dl = *reinterpret_cast<const float4 *>(dlog_s + c * kSB);
+            d[0] = __fmaf_rn(dl.x, w, d[0]); d[1] = __fmaf_rn(dl.y, w, d[1]);
+            d[2] = __fmaf_rn(dl.z, w, d[2]); d[3] = __fmaf_rn(dl.w, w, d[3]);
+        }
+#pragma unroll
+        for (int s = 0; s < kSB; ++s) {
+            const bool live = m0 + s < a.M;
+            const size_t m = live ? (size_t)(m0 + s) : 0;
+            float dzv = d[s];
+            if (a.demo) {
+                const float th = tanhf(a.film[m * 2 * a.F + o]);
+                const float zv = a.z[m * a.F + o];
+                const float dfg = d[s] * zv * (1.0f - th * th);
+                dzv = d[s] * (1.0f + th);
+                dfilm_s[o * kSB + s] = live ? dfg : 0.f;
+                dfilm_s[(a.F + o) * kSB + s] = live ? d[s] : 0.f;
+                if (live) {
+                    a.dzc[m * a.F + o] = d[s];
+                    a.dfilm[m * 2 * a.F + o] = dfg;
+                    a.dfilm[m * 2 * a.F + a.F + o] = d[s];
+                }
+            }
+            if (a.dz_extra && live) dzv += a.dz_extra[m * a.F + o];
+            dz_s[o * kSB + s] = live ? dzv : 0.f;
+            if (live) a.dz[m * a.F + o] = dzv;
+        }
+    }
+    __syncthreads();
+
+    if (a.demo) {
+        // d h2 = (d film Wf) masked by h2 > 0
+        for (int e = tid; e < a.H * kSB; e += 256) {
+            int s = e / a.H, i = e - s * a.H;
+            float acc = dot_col(dfilm_s, s, a.Wf + i, (size_t)a.H, 2 * a.F);
+            const bool live = m0 + s < a.M;
+            if (!(live && a.h2[(size_t)(m0 + s) * a.H + i] > 0.f)) acc = 0.f;
+            dh2_s[i * kSB + s] = acc;
+            if (live) a.dh2m[(size_t)(m0 + s) * a.H + i] = acc;
+        }
+        __syncthreads();
+        for (int e = tid; e < a.H1 * kSB; e += 256) {
+            int s = e / a.H1, i = e - s * a.H1;
+            float acc = dot_col(dh2_s, s, a.W2 + i, (size_t)a.H1, a.H);
+            const bool live = m0 + s < a.M;
+            if (!(live && a.h1[(size_t)(m0 + s) * a.H1 + i] > 0.f)) acc = 0.f;
+            dh1_s[i * kSB + s] = acc;
+            if (live) a.dh1m[(size_t)(m0 + s) * a.H1 + i] = acc;
+        }
+        __syncthreads();
+        if (a.dxd)
+            for (int e = tid; e < a.D * kSB; e += 256) {
+                int s = e / a.D, i = e - s * a.D;
+                float acc = dot_col(dh1_s, s, a.W0 + i, (size_t)a.D, a.H1);
+                if (m0 + s < a.M) a.dxd[(size_t)(m0 + s) * a.D + i] = acc;
+            }
+    }
+
+    // d g = d z Wp: thread <-> input feature i
+    for (int i = tid; i < a.F0; i += 256) {
+        float acc[kSB] = {0.f, 0.f, 0.f, 0.f};
+        dot_rows(acc, dz_s, a.Wp + i, (size_t)a.F0, a.F);
+#pragma unroll
+        for (int s = 0; s < kSB; ++s)
+            if (m0 + s < a.M) a.dg[(size_t)(m0 + s) * a.F0 + i] = acc[s];
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// grouped weight gradient: for each problem p, dW_p[o][i] = sum_m G_p[m][o] X_p[m][i],
+// db_p[o] = sum_m G_p[m][o].  32x32 output tile per workgroup, 2x2 outputs per thread.
+// ---------------------------------------------------------------------------------------
+constexpr int kMaxProb = 8;
+struct WgProb {
+    const float *G, *X;
+    float *dW, *db;
+    int Out, In, tile0, tiles_i;
+};
+struct WgArgs {
+    WgProb p[kMaxProb];
+    int count, M;
+};
+
+__global__ __launch_bounds__(256) void linear_wgrad_grouped_kernel(WgArgs a) {
+    __shared__ float Gs[32][33], Xs[32][33];
+    int pi = 0;
+#pragma unroll
+    for (int q = 1; q < kMaxProb; ++q)
+        if (q < a.count && (int)blockIdx.x >= a.p[q].tile0) pi = q;
+    const WgProb pr = a.p[pi];
+    const int tile = blockIdx.x - pr.tile0;
+    const int o0 = (tile / pr.tiles_i) * 32, i0 = (tile % pr.tiles_i) * 32;
+    const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;   // thread owns o = 2ty..2ty+1, i = 2tx..2tx+1
+    float acc[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
+    float bacc = 0.f;
+    for (int m0 = 0; m0 < a.M; m0 += 32) {
+        // stage G[m0:m0+32][o0:o0+32] and X[m0:m0+32][i0:i0+32]; lanes walk the contiguous axis
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int e = tid + 256 * r, mm = e >> 5, cc = e & 31;
+            const int m = m0 + mm;
+            Gs[mm][cc] = (m < a.M && o0 + cc < pr.Out) ? pr.G[(size_t)m * pr.Out + o0 + cc] : 0.f;
+            Xs[mm][cc] = (m < a.M && i0 + cc < pr.In) ? pr.X[(size_t)m * pr.In + i0 + cc] : 0.f;
+        }
+        __syncthreads();
+#pragma unroll 8
+        for (int k = 0; k < 32; ++k) {
+            const float g0 = Gs[k][2 * ty], g1 = Gs[k][2 * ty + 1];
+            const float x0 = Xs[k][2 * tx], x1 = Xs[k][2 * tx + 1];
+            acc[0][0] = __fmaf_rn(g0, x0, acc[0][0]); acc[0][1] = __fmaf_rn(g0, x1, acc[0][1]);
+            acc[1][0] = __fmaf_rn(g1, x0, acc[1][0]); acc[1][1] = __fmaf_rn(g1, x1, acc[1][1]);
+        }
+        if (i0 == 0 && tid < 32) {
+#pragma unroll 8
+            for (int k = 0; k < 32; ++k) bacc += Gs[k][tid];
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int v = 0; v < 2; ++v) {
+            const int o = o0 + 2 * ty + u, i = i0 + 2 * tx + v;
+            if (o < pr.Out && i < pr.In) pr.dW[(size_t)o * pr.In + i] = acc[u][v];
+        }
+    if (i0 == 0 && tid < 32 && pr.db && o0 + tid < pr.Out) pr.db[o0 + tid] = bacc;
+}
+
+__global__ void transpose_kernel(const float *__restrict__ w, float *__restrict__ wT, int rows,
+                                 int cols) {
+    __shared__ float t[32][33];
+    const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32, tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int r = ty; r < 32; r += 8)
+        if (r0 + r < rows && c0 + tx < cols) t[r][tx] = w[(size_t)(r0 + r) * cols + c0 + tx];
+    __syncthreads();
+    for (int c = ty; c < 32; c += 8)
+        if (c0 + c < cols && r0 + tx < rows) wT[(size_t)(c0 + c) * rows + r0 + tx] = t[tx][c];
+}
+
+}  // namespace ecg
+
+using namespace ecg;
+
+ECG_API int ecg_transpose(const float *w, float *wT, int rows, int cols, ecg_stream_t stream) {
+    ECG_REQUIRE(w && wT && rows > 0 && cols > 0, "transpose: bad argument");
+    hipLaunchKernelGGL(transpose_kernel, dim3(cdiv(cols, 32), cdiv(rows, 32)), dim3(256), 0,
+                       as_stream(stream), w, wT, rows, cols);
+    return check_launch("transpose_kernel");
+}
+
+static int check_tail_dims(const char *who, int M, int F0, int F, int D, int H1, int H, int C, int demo) {
+    ECG_REQUIRE(M > 0 && F0 > 0 && F > 0 && C > 0, "%s: M=%d F0=%d F=%d C=%d must be > 0", who, M, F0, F, C);
+    ECG_REQUIRE(!demo || (D > 0 && H1 > 0 && H > 0), "%s: demographic path needs D, H1, H > 0", who);
+    ECG_REQUIRE(F0 <= 4096 && F <= 2048 && H1 <= 1024 && H <= 1024 && D <= 256 && C <= 1024,
+                "%s: layer too wide for the fused tail (F0=%d F=%d H1=%d H=%d D=%d C=%d)", who, F0, F, H1, H, D, C);
+    return ECG_OK;
+}
+
+ECG_API int ecg_tail_fwd(const float *g, const float *xd, const float *WpT, const float *bp,
+                         const float *W0, const float *b0, const float *W2, const float *b2,
+                         const float *WfT, const float *bf, const float *Wh, const float *bh,
+                         float *z, float *h1, float *h2, float *film, float *zc, float *logits,
+                         int M, int F0, int F, int D, int H1, int H, int C, ecg_stream_t stream) {
+    const int demo = xd != nullptr;
+    int rc = check_tail_dims("tail_fwd", M, F0, F, D, H1, H, C, demo);
+    if (rc) return rc;
+    ECG_REQUIRE(g && WpT && bp && Wh && bh && z && logits, "tail_fwd: null pointer");
+    ECG_REQUIRE(!demo || (W0 && b0 && W2 && b2 && WfT && bf && h1 && h2 && film && zc),
+                "tail_fwd: null pointer on the demographic path");
+    TailFwdArgs a{g, xd, WpT, bp, W0, b0, W2, b2, WfT, bf, Wh, bh, z, h1, h2, film, zc, logits,
+                  M, F0, F, demo ? D : 0, demo ? H1 : 0, demo ? H : 0, C};
+    size_t lds = sizeof(float) * kSB * (size_t)(F0 + a.D + a.H1 + a.H + F);
+    ECG_REQUIRE(lds <= 64 * 1024, "tail_fwd: %zu bytes of LDS needed", lds);
+    hipLaunchKernelGGL(tail_fwd_kernel, dim3(cdiv(M, kSB)), dim3(256), lds, as_stream(stream), a);
+    return check_launch("tail_fwd_kernel");
+}
+
+ECG_API int ecg_tail_bwd_chain(const float *dlogits, const float *dz_extra, const float *z,
+                               const float *h1, const float *h2, const float *film,
+                               const float *Wp, const float *W0, const float *W2, const float *Wf,
+                               const float *Wh, float *dzc, float *dz, float *dfilm, float *dh2m,
+                               float *dh1m, float *dg, float *dxd, int M, int F0, int F, int D,
+                               int H1, int H, int C, int demo, ecg_stream_t stream) {
+    int rc = check_tail_dims("tail_bwd_chain", M, F0, F, D, H1, H, C, demo);
+    if (rc) return rc;
+    ECG_REQUIRE(dlogits && Wp && Wh && dz && dg, "tail_bwd_chain: null pointer");
+    ECG_REQUIRE(!demo || (z && h1 && h2 && film && W0 && W2 && Wf && dzc && dfilm && dh2m && dh1m),
+                "tail_bwd_chain: null pointer on the demographic path");
+    TailBwdArgs a{dlogits, dz_extra, z, h1, h2, film, Wp, W0, W2, Wf, Wh, dzc, dz, dfilm, dh2m,
+                  dh1m, dg, dxd, M, F0, F, demo ? D : 0, demo ? H1 : 0, demo ? H : 0, C, demo};
+    size_t lds = sizeof(float) * kSB * (size_t)(C + F + 2 * F + a.H + a.H1);
+    ECG_REQUIRE(lds <= 64 * 1024, "tail_bwd_chain: %zu bytes of LDS needed", lds);
+    hipLaunchKernelGGL(tail_bwd_chain_kernel, dim3(cdiv(M, kSB)), dim3(256), lds, as_stream(stream), a);
+    return check_launch("tail_bwd_chain_kernel");
+}
+
+ECG_API int ecg_linear_wgrad_grouped(const float *const *G, const float *const *X, float *const *dW,
+                                     float *const *db, const int *Out, const int *In, int count,
+                                     int M, ecg_stream_t stream) {
+    ECG_REQUIRE(G && X && dW && db && Out && In, "linear_wgrad_grouped: null table");
+    ECG_REQUIRE(count >= 1 && count <= kMaxProb, "linear_wgrad_grouped: count=%d outside [1,%d]", count, kMaxProb);
+    ECG_REQUIRE(M > 0, "linear_wgrad_grouped: M=%d", M);
+    WgArgs a;
+    a.count = count; a.M = M;
+    int tiles = 0;
+    for (int q = 0; q < count; ++q) {
+        ECG_REQUIRE(G[q] && X[q] && dW[q] && Out[q] > 0 && In[q] > 0, "linear_wgrad_grouped: problem %d is malformed", q);
+        a.p[q] = WgProb{G[q], X[q], dW[q], db[q], Out[q], In[q], tiles, cdiv(In[q], 32)};
+        tiles += cdiv(Out[q], 32) * cdiv(In[q], 32);
+    }
+    for (int q = count; q < kMaxProb; ++q) a.p[q] = WgProb{nullptr, nullptr, nullptr, nullptr, 0, 0, 1 << 30, 1};
+    hipLaunchKernelGGL(linear_wgrad_grouped_kernel, dim3(tiles), dim3(256), 0, as_stream(stream), a);
+    return check_launch("linear_wgrad_grouped_kernel");
+}

@@ -33,6 +33,8 @@ SIGNATURES = {
     "ecg_bn_relu_pool_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "ecg_bn_relu_pool_bwd_ws_floats": (_sz, [_i, _i, _i]),
     "ecg_bn_relu_pool_bwd": (_i, [_vp] * 10 + [_i, _i, _i, _i, _vp]),
+    "ecg_bn_relu_pool_gap_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
+    "ecg_bn_relu_pool_gap_bwd": (_i, [_vp] * 10 + [_i, _i, _i, _i, _vp]),
     "ecg_bn_apply_fwd": (_i, [_vp] * 6 + [_i, _i, _i, _vp]),
     "ecg_bn_bwd_ws_floats": (_sz, [_i, _i, _i]),
     "ecg_bn_bwd": (_i, [_vp] * 9 + [_i, _i, _i, _i, _vp]),
@@ -49,6 +51,10 @@ SIGNATURES = {
     "ecg_film_bwd": (_i, [_vp] * 5 + [_i, _i, _vp]),
     "ecg_bce_logits_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _vp]),
     "ecg_sigmoid_fwd": (_i, [_vp, _vp, _sz, _vp]),
+    "ecg_transpose": (_i, [_vp, _vp, _i, _i, _vp]),
+    "ecg_tail_fwd": (_i, [_vp] * 18 + [_i] * 7 + [_vp]),
+    "ecg_tail_bwd_chain": (_i, [_vp] * 18 + [_i] * 8 + [_vp]),
+    "ecg_linear_wgrad_grouped": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp]),
     "ecg_adamw_step": (_i, [_vp, _vp, _vp, _vp, _sz, _i, _f, _f, _f, _f, _f, _f, _vp]),
     "ecg_zscore_rows": (_i, [_vp, _vp, _i, _i, _vp]),
 }
@@ -143,6 +149,16 @@ class kernel_timing:
         for name, sig, e0, e1 in ev:
             self.result.setdefault((name, sig), []).append(e0.elapsed_time(e1))
         return False
+
+
+def ptr_table(tensors):
+    """Host array of device pointers (NULL for None) for the grouped entry points."""
+    arr = (ctypes.c_void_p * len(tensors))(*[f32(t) for t in tensors])
+    return arr
+
+
+def int_table(values):
+    return (ctypes.c_int * len(values))(*[int(v) for v in values])
 
 
 def query(name, *args):

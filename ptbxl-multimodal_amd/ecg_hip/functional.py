@@ -97,7 +97,7 @@ class ConvBlockFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, w, b, gamma, beta, running_mean, running_var, nbt, training, momentum,
-                eps, pad):
+                eps, pad, gap=False):
         x, w = _contig(x), _contig(w)
         Co, _, K = w.shape
         use_batch = training or running_mean is None
@@ -110,11 +110,16 @@ class ConvBlockFn(torch.autograd.Function):
         else:
             mean, invstd = bn_eval_stats(running_mean, running_var, eps)
         N, _, Lo = y.shape
-        p = _empty(x, N, Co, Lo // 2)
-        _call("ecg_bn_relu_pool_fwd", _f32(y), _f32(gamma), _f32(beta), _f32(mean), _f32(invstd),
-              _f32(p), N, Co, Lo, _st())
+        if gap:      # last block: AdaptiveAvgPool1d(1) folded in, the pooled tensor never exists
+            p = _empty(x, N, Co)
+            _call("ecg_bn_relu_pool_gap_fwd", _f32(y), _f32(gamma), _f32(beta), _f32(mean),
+                  _f32(invstd), _f32(p), N, Co, Lo, _st())
+        else:
+            p = _empty(x, N, Co, Lo // 2)
+            _call("ecg_bn_relu_pool_fwd", _f32(y), _f32(gamma), _f32(beta), _f32(mean), _f32(invstd),
+                  _f32(p), N, Co, Lo, _st())
         ctx.save_for_backward(x, w, y, gamma, beta, mean, invstd)
-        ctx.w_bwd, ctx.pad, ctx.batch_stats = w_bwd, pad, use_batch
+        ctx.w_bwd, ctx.pad, ctx.batch_stats, ctx.gap = w_bwd, pad, use_batch, gap
         return p
 
     @staticmethod
@@ -125,11 +130,11 @@ class ConvBlockFn(torch.autograd.Function):
         dy = torch.empty_like(y)
         dgamma, dbeta = _empty(y, Co), _empty(y, Co)
         ws = _empty(y, _query("ecg_bn_relu_pool_bwd_ws_floats", N, Co, Lo))
-        _call("ecg_bn_relu_pool_bwd", _f32(y), _f32(dp), _f32(gamma), _f32(beta), _f32(mean),
-              _f32(invstd), _f32(dy), _f32(dgamma), _f32(dbeta), _f32(ws), N, Co, Lo,
-              1 if ctx.batch_stats else 0, _st())
+        _call("ecg_bn_relu_pool_gap_bwd" if ctx.gap else "ecg_bn_relu_pool_bwd", _f32(y), _f32(dp),
+              _f32(gamma), _f32(beta), _f32(mean), _f32(invstd), _f32(dy), _f32(dgamma), _f32(dbeta),
+              _f32(ws), N, Co, Lo, 1 if ctx.batch_stats else 0, _st())
         dx, dw, db = conv1d_backward_raw(x, dy, w.shape, ctx.w_bwd, ctx.pad, ctx.needs_input_grad[0])
-        return dx, dw, db, dgamma, dbeta, None, None, None, None, None, None, None
+        return dx, dw, db, dgamma, dbeta, None, None, None, None, None, None, None, None
 
 
 # --------------------------------------------------------------------------------------
@@ -320,10 +325,82 @@ class BceWithLogitsFn(torch.autograd.Function):
 # --------------------------------------------------------------------------------------
 # functional entry points
 # --------------------------------------------------------------------------------------
-def conv_block(x, conv, bn):
+def conv_block(x, conv, bn, gap=False):
+    """Fused Conv1d -> BatchNorm1d -> ReLU -> MaxPool1d(2) [-> AdaptiveAvgPool1d(1).squeeze(-1)]."""
     return ConvBlockFn.apply(x, conv.weight, conv.bias, bn.weight, bn.bias, bn.running_mean,
                              bn.running_var, bn.num_batches_tracked, bn.training, bn.momentum,
-                             bn.eps, conv.padding[0])
+                             bn.eps, conv.padding[0], gap)
+
+
+class TailFn(torch.autograd.Function):
+    """Everything after the global average pool as one forward launch (+2 weight transposes) and
+    two backward launches: proj [-> demographic MLP -> film_gen -> FiLM] -> head.
+    reference src/models/ecg_cnn.py:63-64 and src/models/ecg_multimodal.py:88-99."""
+
+    @staticmethod
+    def forward(ctx, g, xd, Wp, bp, W0, b0, W2, b2, Wf, bf, Wh, bh):
+        g = _contig(g)
+        M, F0 = g.shape
+        F, C = Wp.shape[0], Wh.shape[0]
+        demo = xd is not None
+        WpT = _empty(g, F0, F)
+        _call("ecg_transpose", _f32(_contig(Wp)), _f32(WpT), F, F0, _st())
+        z, logits = _empty(g, M, F), _empty(g, M, C)
+        D = H1 = H = 0
+        xdc = WfT = h1 = h2 = film = zc = None
+        if demo:
+            xdc = _contig(xd)
+            D, H1, H = xdc.shape[1], W0.shape[0], W2.shape[0]
+            WfT = _empty(g, H, 2 * F)
+            _call("ecg_transpose", _f32(_contig(Wf)), _f32(WfT), 2 * F, H, _st())
+            h1, h2, film, zc = _empty(g, M, H1), _empty(g, M, H), _empty(g, M, 2 * F), _empty(g, M, F)
+        _call("ecg_tail_fwd", _f32(g), _f32(xdc), _f32(WpT), _f32(bp), _f32(W0), _f32(b0), _f32(W2),
+              _f32(b2), _f32(WfT), _f32(bf), _f32(_contig(Wh)), _f32(bh), _f32(z), _f32(h1), _f32(h2),
+              _f32(film), _f32(zc), _f32(logits), M, F0, F, D, H1, H, C, _st())
+        ctx.save_for_backward(g, xdc, Wp, W0, W2, Wf, Wh, z, h1, h2, film, zc)
+        ctx.dims = (M, F0, F, D, H1, H, C, demo)
+        return logits, z
+
+    @staticmethod
+    def backward(ctx, dlogits, dz_extra):
+        g, xd, Wp, W0, W2, Wf, Wh, z, h1, h2, film, zc = ctx.saved_tensors
+        M, F0, F, D, H1, H, C, demo = ctx.dims
+        dlogits = _contig(dlogits)
+        dz, dg = _empty(g, M, F), _empty(g, M, F0)
+        dzc = dfilm = dh2m = dh1m = dxd = None
+        if demo:
+            dzc, dfilm = _empty(g, M, F), _empty(g, M, 2 * F)
+            dh2m, dh1m = _empty(g, M, H), _empty(g, M, H1)
+            if ctx.needs_input_grad[1]:
+                dxd = _empty(g, M, D)
+        dze = None if dz_extra is None else _contig(dz_extra)
+        _call("ecg_tail_bwd_chain", _f32(dlogits), _f32(dze), _f32(z), _f32(h1), _f32(h2), _f32(film),
+              _f32(Wp), _f32(W0), _f32(W2), _f32(Wf), _f32(Wh), _f32(dzc), _f32(dz), _f32(dfilm),
+              _f32(dh2m), _f32(dh1m), _f32(dg), _f32(dxd), M, F0, F, D, H1, H, C, int(demo), _st())
+        dWp, dbp = torch.empty_like(Wp), _empty(g, F)
+        dWh, dbh = torch.empty_like(Wh), _empty(g, C)
+        if demo:
+            dW0, db0 = torch.empty_like(W0), _empty(g, H1)
+            dW2, db2 = torch.empty_like(W2), _empty(g, H)
+            dWf, dbf = torch.empty_like(Wf), _empty(g, 2 * F)
+            Gs, Xs = [dz, dfilm, dh2m, dh1m, dlogits], [g, h2, h1, xd, zc]
+            dWs, dbs = [dWp, dWf, dW2, dW0, dWh], [dbp, dbf, db2, db0, dbh]
+        else:
+            dW0 = db0 = dW2 = db2 = dWf = dbf = None
+            Gs, Xs, dWs, dbs = [dz, dlogits], [g, z], [dWp, dWh], [dbp, dbh]
+        _call("ecg_linear_wgrad_grouped", L.ptr_table(Gs), L.ptr_table(Xs), L.ptr_table(dWs),
+              L.ptr_table(dbs), L.int_table([w.shape[0] for w in dWs]),
+              L.int_table([w.shape[1] for w in dWs]), len(Gs), M, _st())
+        return dg, dxd, dWp, dbp, dW0, db0, dW2, db2, dWf, dbf, dWh, dbh
+
+
+def tail(g, x_demo, proj, head, mlp0=None, mlp2=None, film_gen=None):
+    """(logits, z) of the fused tail; x_demo/mlp0/mlp2/film_gen are None for ECGCNN."""
+    if x_demo is None:
+        return TailFn.apply(g, None, proj.weight, proj.bias, None, None, None, None, None, None,
+                            head.weight, head.bias)
+    return TailFn.apply(g, x_demo, proj.weight, proj.bias, mlp0.weight, mlp0.bias, mlp2.weight,
+                        mlp2.bias, film_gen.weight, film_gen.bias, head.weight, head.bias)
 
 
 def binary_cross_entropy_with_logits(logits, target):

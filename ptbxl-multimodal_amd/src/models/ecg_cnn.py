@@ -44,6 +44,20 @@ def make_backbone(in_leads: int) -> nn.Sequential:
     return nn.Sequential(*(ConvBlock(a, b) for a, b in zip(widths, widths[1:])))
 
 
+def backbone_features(backbone: nn.Sequential, gap: nn.Module, x: torch.Tensor) -> torch.Tensor:
+    """`gap(backbone(x)).squeeze(-1)` -> [B, C].  When nobody hooks the containers, the last
+    ConvBlock runs with the global average pool folded into its BN+ReLU+pool kernel, so the
+    last pooled activation is never written to HBM."""
+    blocks = list(backbone)
+    last = blocks[-1]
+    if (isinstance(last, ConvBlock) and last._fusable and x.dim() == 3
+            and not hipnn.has_hooks(backbone, gap, *blocks, last.net, *last.net)):
+        for blk in blocks[:-1]:
+            x = blk(x)
+        return hipF.conv_block(x, last.net[0], last.net[1], gap=True)
+    return gap(backbone(x)).squeeze(-1)
+
+
 class ECGCNN(nn.Module):
     """12-lead ECG classifier: 4 ConvBlocks -> global average pool -> proj -> head.
 
@@ -59,7 +73,10 @@ class ECGCNN(nn.Module):
 
     def forward(self, x: torch.Tensor, return_features: bool = False):
         """x: [B, in_leads, T] -> logits [B, num_labels] (or (logits, z) if return_features)."""
-        pooled = self.gap(self.backbone(x)).squeeze(-1)
-        z = self.proj(pooled)
-        logits = self.head(z)
+        pooled = backbone_features(self.backbone, self.gap, x)
+        if not hipnn.has_hooks(self.proj, self.head):
+            logits, z = hipF.tail(pooled, None, self.proj, self.head)       # one fused launch
+        else:
+            z = self.proj(pooled)
+            logits = self.head(z)
         return (logits, z) if return_features else logits

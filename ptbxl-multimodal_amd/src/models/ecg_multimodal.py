@@ -10,7 +10,7 @@ import torch.nn as nn
 
 from ecg_hip import functional as hipF
 from ecg_hip import nn as hipnn
-from src.models.ecg_cnn import BACKBONE_WIDTHS, ConvBlock, make_backbone  # noqa: F401  (ConvBlock re-exported)
+from src.models.ecg_cnn import BACKBONE_WIDTHS, ConvBlock, backbone_features, make_backbone  # noqa: F401  (ConvBlock re-exported)
 
 
 class ECGBackbone(nn.Module):
@@ -22,8 +22,12 @@ class ECGBackbone(nn.Module):
         self.gap = hipnn.HipAdaptiveAvgPool1d(1)
         self.proj = hipnn.HipLinear(BACKBONE_WIDTHS[-1], feat_dim)
 
+    def features(self, x: torch.Tensor) -> torch.Tensor:
+        """Globally pooled backbone activation [B, 256] (the input of `proj`)."""
+        return backbone_features(self.backbone, self.gap, x)
+
     def forward(self, x: torch.Tensor) -> torch.Tensor:
-        return self.proj(self.gap(self.backbone(x)).squeeze(-1))
+        return self.proj(self.features(x))
 
 
 class DemoEncoder(nn.Module):
@@ -53,6 +57,12 @@ class ECGMultimodal(nn.Module):
         self.head = hipnn.HipLinear(feat_dim, num_labels)
 
     def forward(self, x_ecg: torch.Tensor, x_demo: torch.Tensor) -> torch.Tensor:
-        z = self.ecg_backbone(x_ecg)
-        film = self.film_gen(self.demo_encoder(x_demo))      # [B, 2F]: gamma-raw | beta
+        enc, bb = self.demo_encoder, self.ecg_backbone
+        if not hipnn.has_hooks(bb, bb.proj, enc, enc.mlp, *enc.mlp, self.film_gen, self.head):
+            # proj + demographic MLP + film_gen + FiLM + head: one fused launch
+            logits, _ = hipF.tail(bb.features(x_ecg), x_demo, bb.proj, self.head, enc.mlp[0], enc.mlp[2],
+                                  self.film_gen)
+            return logits
+        z = bb(x_ecg)
+        film = self.film_gen(enc(x_demo))      # [B, 2F]: gamma-raw | beta
         return self.head(hipF.FilmFn.apply(z, film))

@@ -262,3 +262,81 @@ def test_conv_full_size_vs_torch_restatement(hip, shape):
     # linearity: conv(2x, w, 0) == 2*(conv(x, w, b) - b)
     y2, _, _, _ = conv_all(hip, (2 * x).numpy(), w.numpy(), np.zeros(Co, np.float32), dy.numpy())
     np.testing.assert_allclose(y2, 2 * (y - b.numpy()[None, :, None]), atol=2e-5)
+
+
+@pytest.mark.parametrize("M", [256, 7, 1])
+@pytest.mark.parametrize("demo", [True, False])
+def test_fused_tail_vs_oracle(hip, oracle, M, demo):
+    """ecg_tail_fwd / ecg_tail_bwd_chain / ecg_linear_wgrad_grouped against the per-layer oracle
+    composition (ragged M exercises the partial last sample group)."""
+    rng = np.random.default_rng(M * 2 + demo)
+    F0, F, D, H1, H, C = 256, 256, 5, 64, 64, 5
+    def W(o, i): return (rng.standard_normal((o, i)) / np.sqrt(i)).astype(np.float32)
+    def B(o): return (0.1 * rng.standard_normal(o)).astype(np.float32)
+    g = rng.standard_normal((M, F0)).astype(np.float32)
+    xd = rng.random((M, D)).astype(np.float32)
+    Wp, bp, W0, b0, W2, b2, Wf, bf, Wh, bh = W(F, F0), B(F), W(H1, D), B(H1), W(H, H1), B(H), W(2 * F, H), B(2 * F), W(C, F), B(C)
+    dlog = rng.standard_normal((M, C)).astype(np.float32)
+    dze = rng.standard_normal((M, F)).astype(np.float32) * 0.1
+    names = ["g", "xd", "Wp", "bp", "W0", "b0", "W2", "b2", "Wf", "bf", "Wh", "bh"]
+    vals = [g, xd, Wp, bp, W0, b0, W2, b2, Wf, bf, Wh, bh]
+    t = {k: dev(v).requires_grad_(True) for k, v in zip(names, vals)}
+    if demo:
+        logits, z = hip.TailFn.apply(*[t[k] for k in names])
+    else:
+        logits, z = hip.TailFn.apply(t["g"], None, t["Wp"], t["bp"], None, None, None, None, None, None, t["Wh"], t["bh"])
+    torch.autograd.backward([logits, z], [dev(dlog), dev(dze)])
+    # oracle
+    rz = oracle.linear_fwd(g, Wp, bp)
+    if demo:
+        rh1 = oracle.linear_fwd(xd, W0, b0, relu=True)
+        rh2 = oracle.linear_fwd(rh1, W2, b2, relu=True)
+        rfilm = oracle.linear_fwd(rh2, Wf, bf)
+        rzc = oracle.film_fwd(rz, rfilm)
+    else:
+        rzc = rz
+    rlog = oracle.linear_fwd(rzc, Wh, bh)
+    np.testing.assert_allclose(host(z), rz, atol=1e-5)
+    np.testing.assert_allclose(host(logits), rlog, atol=2e-5)
+    dzc, dWh, dbh = oracle.linear_bwd(rzc, Wh, rlog, dlog)
+    ref = {"Wh": dWh, "bh": dbh}
+    if demo:
+        dz, dfilm = oracle.film_bwd(rz, rfilm, dzc)
+        dh2, ref["Wf"], ref["bf"] = oracle.linear_bwd(rh2, Wf, rfilm, dfilm)
+        dh1, ref["W2"], ref["b2"] = oracle.linear_bwd(rh1, W2, rh2, dh2, relu=True)
+        ref["xd"], ref["W0"], ref["b0"] = oracle.linear_bwd(xd, W0, rh1, dh1, relu=True)
+    else:
+        dz = dzc
+    dz = dz + dze
+    ref["g"], ref["Wp"], ref["bp"] = oracle.linear_bwd(g, Wp, rz, dz)
+    for k, r in ref.items():
+        np.testing.assert_allclose(host(t[k].grad), r, atol=5e-5 * max(1.0, np.sqrt(M) / 4), err_msg=k)
+    if not demo:
+        assert t["xd"].grad is None and t["Wf"].grad is None
+
+
+def test_conv_block_with_fused_gap(hip, oracle):
+    """Last-block fusion: conv + BN(train) + ReLU + pool + global average pool, fwd and bwd."""
+    rng = np.random.default_rng(11)
+    N, Ci, Co, Lin = 5, 128, 256, 125
+    x = rng.standard_normal((N, Ci, Lin)).astype(np.float32)
+    w = (rng.standard_normal((Co, Ci, 15)) / np.sqrt(Ci * 15)).astype(np.float32)
+    b = rng.standard_normal(Co).astype(np.float32)
+    gamma = (1 + 0.1 * rng.standard_normal(Co)).astype(np.float32)
+    beta = (0.1 * rng.standard_normal(Co)).astype(np.float32)
+    dg = rng.standard_normal((N, Co)).astype(np.float32)
+    xs, ws, bs, gs, bes = (dev(a).requires_grad_(True) for a in (x, w, b, gamma, beta))
+    rm, rv, nbt = torch.zeros(Co).cuda(), torch.ones(Co).cuda(), torch.zeros((), dtype=torch.int64).cuda()
+    g = hip.ConvBlockFn.apply(xs, ws, bs, gs, bes, rm, rv, nbt, True, 0.1, 1e-5, 7, True)
+    g.backward(dev(dg))
+    y = oracle.conv1d_fwd(x, w, b, 7)
+    mean, invstd = oracle.bn_stats(y)
+    p = oracle.bn_relu_pool_fwd(y, gamma, beta, mean, invstd)
+    np.testing.assert_allclose(host(g), oracle.gap_fwd(p), atol=2e-5)
+    dy, dgam, dbet = oracle.bn_relu_pool_bwd(y, oracle.gap_bwd(dg, p.shape[2]), gamma, beta, mean, invstd, True)
+    np.testing.assert_allclose(host(gs.grad), dgam, atol=1e-4)
+    np.testing.assert_allclose(host(bes.grad), dbet, atol=1e-4)
+    dw, db = oracle.conv1d_bwd_weight(dy, x, 15, 7)
+    np.testing.assert_allclose(host(ws.grad), dw, atol=1e-4)
+    np.testing.assert_allclose(host(xs.grad), oracle.conv1d_bwd_data(dy, w, Lin, 7), atol=1e-4)
+    assert int(nbt.item()) == 1
