@@ -40,37 +40,41 @@ __device__ __forceinline__ int acc_row(int r, int half) { return (r & 3) + 8 * (
 // grid = (ceil(Lo/T_T), Cout/CO_T, N), 256 threads = 4 waves laid out WCO x WT over the tile.
 //
 // Pipeline (per chunk of CI_C = 4 input channels = 30 reduction steps = 120 MFMAs per wave):
-//   LDS holds TWO chunk images.  While the MFMAs of chunk c run out of image c&1,
-//     steps  0..14: the registers holding chunk c+1 are written into image (c+1)&1,
-//     steps 15..29: the global loads of chunk c+2 are issued into those registers,
-//   one ds_write / global_load at a time between MFMA groups, and ONE barrier closes the chunk.
-//   So the matrix pipe never waits for a staging phase, and global latency has half a chunk
-//   (~4k cycles) plus the next commit window to land.
-// Staging loads are UNCONDITIONAL (clamped addresses; zero padding applied at commit time by
-// AND-ing with a bit mask): a load that is only used under a condition gets sunk into a branch
-// by hipcc and followed by s_waitcnt vmcnt(0) — one serialised L2 round trip per element.
+//   LDS holds TWO chunk images {weights [K][4][CO_T] | x tile [4][T_T+16]}.  While the MFMAs of
+//   chunk c run out of image c&1,
+//     * the weight slice of chunk c+1 streams global -> LDS directly (global_load_lds_dwordx4:
+//       no VGPRs, no ds_write; one 1 KB wave-instruction every few steps),
+//     * the x tile of chunk c+1 (3 floats per thread, loaded one chunk earlier) is written with
+//       its zero padding applied by an AND mask, and the x tile of chunk c+2 is loaded,
+//   and ONE barrier (with the vmcnt(0) the compiler attaches to it) closes the chunk.
+//   Every global offset is loop-invariant per thread and precomputed; a chunk only advances a
+//   uniform base pointer.
+// Loads are UNCONDITIONAL (clamped addresses, zeroing by mask): a load that is only used under
+// a condition gets sunk into a branch by hipcc and followed by s_waitcnt vmcnt(0).
 template <int CO_T, int T_T, int WCO, int WT, bool STATS>
 __global__ __launch_bounds__(256, 2) void conv1d_mfma_fwd_kernel(
     const float *__restrict__ x, const float *__restrict__ wp, const float *__restrict__ bias,
     float *__restrict__ y, float *__restrict__ partials, int Cin, int Cout, int L, int Lo, int pad,
     int P) {
     static_assert(WCO * WT == 4, "4 waves per workgroup");
-    constexpr int KK = kKM, CI_C = 4, NST = KK * CI_C / 2, HALF = NST / 2;
+    constexpr int KK = kKM, CI_C = 4, NST = KK * CI_C / 2;
     constexpr int MC = CO_T / WCO / 32, MT = T_T / WT / 32;
     static_assert(MC >= 1 && MT >= 1, "wave tile must hold at least one 32x32 accumulator");
     constexpr int XS = T_T + 16;                 // x-tile row stride (span T_T + 14)
-    constexpr int C4 = CO_T / 4;
-    constexpr int WF4 = KK * CI_C * C4;          // 16-byte pieces of one weight chunk [K][CI_C][CO_T]
-    constexpr int WLOADS = (WF4 + 255) / 256;
+    constexpr int WSZ = KK * CI_C * CO_T;        // floats of one weight chunk [K][CI_C][CO_T]
+    constexpr int NDMA = (WSZ + 255) / 256;      // 1 KB wave-instructions per chunk
+    constexpr int WPAD = NDMA * 256;             // weight region padded to whole DMA pieces
+    constexpr int DPW = (NDMA + 3) / 4;          // DMA instructions per wave per chunk
     constexpr int XEL = CI_C * XS;
     constexpr int XLOADS = (XEL + 255) / 256;
-    constexpr int NOPS = WLOADS + XLOADS;        // staging operations per chunk (per thread)
-    constexpr int WSZ = KK * CI_C * CO_T, IMG = WSZ + XEL;
-    static_assert(256 % C4 == 0, "weight rows per pass");
-    static_assert(XLOADS <= 32, "x mask bits");
+    constexpr int IMG = WPAD + XEL;
+    constexpr int REDF = STATS ? 4 * (CO_T / WCO) * 2 : 0;
+    static_assert(REDF <= IMG, "stat scratch aliases image 0");
+    static_assert(NST >= 2 + DPW + XLOADS, "not enough steps to spread the staging over");
 
-    __shared__ __attribute__((aligned(16))) float lds[2 * IMG];
-    __shared__ float red[STATS ? 4 * (CO_T / WCO) * 2 : 1];
+    // ONE shared array: a second __shared__ object beside an LDS-DMA target makes hipcc wait
+    // vmcnt(0) in front of every LDS read.
+    __shared__ __attribute__((aligned(1024))) float lds[2 * IMG];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int half = lane >> 5, l31 = lane & 31;
@@ -86,60 +90,60 @@ __global__ __launch_bounds__(256, 2) void conv1d_mfma_fwd_kernel(
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
-    f32x4 wreg[WLOADS];
-    float xreg[XLOADS];
+    // ---- loop-invariant per-thread staging offsets -------------------------------------------
+    int woff[DPW];          // weight piece j of this wave: element offset inside wp (chunk 0)
+#pragma unroll
+    for (int j = 0; j < DPW; ++j) {
+        const int e = min(((j * 4 + wave) * 64 + lane) * 4, WSZ - 4);   // float index in the image
+        const int row = e / CO_T, col = e - row * CO_T;                  // row = k*CI_C + ci
+        const int k = row / CI_C, ci = row - k * CI_C;
+        woff[j] = (k * Cin + ci) * Cout + col;
+    }
+    int xoff[XLOADS];
     unsigned xmask = 0;
-    constexpr int RPP = 256 / C4;                 // weight rows fetched per pass of 256 threads
-    const int wrow0 = tid / C4, wc4 = (tid % C4) * 4;
+#pragma unroll
+    for (int j = 0; j < XLOADS; ++j) {
+        const int e = min(tid + 256 * j, XEL - 1);
+        const int ci = e / XS, pos = e - ci * XS;
+        const int s = t0 - pad + pos;
+        xoff[j] = ci * L + min(max(s, 0), L - 1);
+        xmask |= ((s >= 0) && (s < L)) ? (1u << j) : 0u;
+    }
+    float xreg[XLOADS];
 
-    // ---- one staging op = one global load (issue) or one LDS write (commit) ----------------
-    auto load_op = [&](int o, int ci0) {
-        const int nci = min(CI_C, Cin - ci0);
-        if (o < WLOADS) {
-            const int row = min(wrow0 + o * RPP, KK * CI_C - 1);
-            const int k = row / CI_C, ci = row - k * CI_C;
-            wreg[o] = *reinterpret_cast<const f32x4 *>(
-                wp + ((size_t)k * Cin + ci0 + min(ci, nci - 1)) * Cout + co0 + wc4);
-        } else {
-            const int j = o - WLOADS;
-            const int e = tid + 256 * j;
-            const int ci = e / XS, pos = e - ci * XS;
-            const int s = t0 - pad + pos;
-            xreg[j] = xn[(size_t)(ci0 + min(ci, nci - 1)) * L + min(max(s, 0), L - 1)];
-            const unsigned bit = ((ci < nci) && (s >= 0) && (s < L)) ? (1u << j) : 0u;
-            xmask = (j == 0) ? bit : (xmask | bit);
-        }
+    auto dma_w = [&](int j, int ci0, float *img) {       // one 1 KB piece of the weight slice
+        if ((j * 4 + wave) < NDMA)
+            __builtin_amdgcn_global_load_lds(
+                (const __attribute__((address_space(1))) void *)(wp + (size_t)ci0 * Cout + co0 + woff[j]),
+                (__attribute__((address_space(3))) void *)(img + (j * 4 + wave) * 256), 16, 0, 0);
     };
-    auto commit_op = [&](int o, float *img) {
-        if (o < WLOADS) {
-            const int f = tid + 256 * o;
-            if (256 * (o + 1) <= WF4 || f < WF4) *reinterpret_cast<f32x4 *>(img + 4 * f) = wreg[o];
-        } else {
-            const int j = o - WLOADS;
-            const int e = tid + 256 * j;
-            const unsigned keep = 0u - ((xmask >> j) & 1u);
-            if (256 * (j + 1) <= XEL || e < XEL)
-                img[WSZ + e] = __uint_as_float(__float_as_uint(xreg[j]) & keep);
-        }
+    auto load_x = [&](int j, int ci0) { xreg[j] = xn[(size_t)ci0 * L + xoff[j]]; };
+    auto commit_x = [&](int j, float *img) {
+        const int e = tid + 256 * j;
+        const unsigned keep = 0u - ((xmask >> j) & 1u);
+        if (256 * (j + 1) <= XEL || e < XEL)
+            img[WPAD + e] = __uint_as_float(__float_as_uint(xreg[j]) & keep);
     };
 
-    const int nchunks = (Cin + CI_C - 1) / CI_C;
-    // prologue: chunk 0 -> image 0, chunk 1 -> registers
+    const int nchunks = Cin / CI_C;
+    // prologue: chunk 0 -> image 0; x tile of chunk 1 -> registers
 #pragma unroll
-    for (int o = 0; o < NOPS; ++o) load_op(o, 0);
+    for (int j = 0; j < DPW; ++j) dma_w(j, 0, lds);
 #pragma unroll
-    for (int o = 0; o < NOPS; ++o) commit_op(o, lds);
+    for (int j = 0; j < XLOADS; ++j) load_x(j, 0);
+#pragma unroll
+    for (int j = 0; j < XLOADS; ++j) commit_x(j, lds);
     if (nchunks > 1) {
 #pragma unroll
-        for (int o = 0; o < NOPS; ++o) load_op(o, CI_C);
+        for (int j = 0; j < XLOADS; ++j) load_x(j, CI_C);
     }
     __syncthreads();
 
     for (int c = 0; c < nchunks; ++c) {
-        const float *ws = lds + (c & 1) * IMG, *xs = ws + WSZ;
+        const float *ws = lds + (c & 1) * IMG, *xs = ws + WPAD;
         float *nxt = lds + ((c + 1) & 1) * IMG;
-        const bool do_commit = c + 1 < nchunks, do_load = c + 2 < nchunks;
-        const int ci_next2 = (c + 2) * CI_C;
+        const bool do_next = c + 1 < nchunks, do_next2 = c + 2 < nchunks;
+        const int ci_next = (c + 1) * CI_C, ci_next2 = (c + 2) * CI_C;
 
         // One reduction step = one (tap, ci-pair): MC + MT LDS reads feed MC*MT MFMAs; the
         // fragments of step s+1 are read BEFORE the MFMAs of step s are issued.
@@ -157,18 +161,13 @@ __global__ __launch_bounds__(256, 2) void conv1d_mfma_fwd_kernel(
 #pragma unroll
         for (int st = 0; st < NST; ++st) {
             ld(st + 1 < NST ? st + 1 : 0, a_n, b_n);
-            // staging ops of this step: commits in the first half, load issues in the second
-            if (st < HALF) {
-                if (do_commit) {
-#pragma unroll
-                    for (int o = st * NOPS / HALF; o < (st + 1) * NOPS / HALF; ++o) commit_op(o, nxt);
-                }
-            } else {
-                if (do_load) {
-#pragma unroll
-                    for (int o = (st - HALF) * NOPS / (NST - HALF); o < (st - HALF + 1) * NOPS / (NST - HALF); ++o)
-                        load_op(o, ci_next2);
-                }
+            // staging, one operation per step: x commits, then weight DMA pieces, then x loads
+            if (st < XLOADS) {
+                if (do_next) commit_x(st, nxt);
+            } else if (st < XLOADS + DPW) {
+                if (do_next) dma_w(st - XLOADS, ci_next, nxt);
+            } else if (st < 2 * XLOADS + DPW) {
+                if (do_next2) load_x(st - XLOADS - DPW, ci_next2);
             }
             __builtin_amdgcn_sched_barrier(0);     // keep reads + staging ABOVE this step's MFMAs
 #pragma unroll
@@ -181,8 +180,9 @@ __global__ __launch_bounds__(256, 2) void conv1d_mfma_fwd_kernel(
 #pragma unroll
             for (int i = 0; i < MT; ++i) b_c[i] = b_n[i];
         }
-        __syncthreads();      // image c&1 free for chunk c+2's commit; image (c+1)&1 complete
+        __syncthreads();      // image c&1 free again; image (c+1)&1 complete (vmcnt(0) + barrier)
     }
+    float *red = lds;         // all images are dead: reuse image 0 for the statistics scratch
 
     // ---- epilogue: bias, store, per-channel (sum, sum^2) partials --------------------------
 #pragma unroll
@@ -245,7 +245,7 @@ static FwdCfg fwd_cfg(int N, int Cout, int Lo) {
 
 bool mfma_fwd_supported(int Cin, int Cout, int K, int pad) {
     (void)pad;
-    return K == kKM && Cin % 2 == 0 && Cout % 32 == 0;   // other kernel sizes take the direct path
+    return K == kKM && Cin % 4 == 0 && Cout % 32 == 0;   // other shapes take the direct path
 }
 
 int mfma_fwd_stat_partials(int N, int Cin, int Cout, int Lo) {
