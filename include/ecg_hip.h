@@ -172,9 +172,11 @@ int ecg_film_bwd(const float *z, const float *film, const float *dzc, float *dz,
                  int M, int F, ecg_stream_t stream);
 
 /* loss[0] = mean(max(x,0) - x*t + log1p(exp(-|x|)))  — src/training/loop.py:32, loop_demo.py:10,33
- * dx (nullable) = (sigmoid(x) - t) / numel  (the gradient for d loss = 1). */
+ * dx (nullable) = (sigmoid(x) - t) / numel  (the gradient for d loss = 1).
+ * running_sum (nullable, device double): running_sum[0] += loss * weight — the epoch-loss
+ * bookkeeping of the loops (loop.py:36 weight = batch size, loop_demo.py:38 weight = 1). */
 int ecg_bce_logits_fwd(const float *x, const float *target, float *loss, float *dx,
-                       int numel, ecg_stream_t stream);
+                       int numel, double *running_sum, double weight, ecg_stream_t stream);
 /* prob = sigmoid(x) — src/training/loop.py:63 */
 int ecg_sigmoid_fwd(const float *x, float *prob, size_t n, ecg_stream_t stream);
 

@@ -28,9 +28,11 @@ __global__ __launch_bounds__(kBlock) void bn_stat_partials_kernel(
     const int c = blockIdx.x, s = blockIdx.y, tl = threadIdx.x;
     const int n0 = (int)((long long)N * s / S), n1 = (int)((long long)N * (s + 1) / S);
     float a = 0.f, q = 0.f;
-    for (int n = n0; n < n1; ++n) {
-        const float *r = y + ((size_t)n * C + c) * L;
-        for (int t = tl; t < L; t += kBlock) { float v = r[t]; a += v; q = __fmaf_rn(v, v, q); }
+    const int total = (n1 - n0) * L;
+    for (int idx = tl; idx < total; idx += kBlock) {
+        const int nl = idx / L, t = idx - nl * L;
+        const float v = y[((size_t)(n0 + nl) * C + c) * L + t];
+        a += v; q = __fmaf_rn(v, v, q);
     }
     a = wave_sum(a); q = wave_sum(q);
     if ((tl & 63) == 0) { red[tl >> 6][0] = a; red[tl >> 6][1] = q; }
@@ -149,27 +151,26 @@ __global__ __launch_bounds__(kBlock) void bn_bwd_reduce_kernel(
     const float mu = mean[c], is = invstd[c], sc = is * gamma[c], be = FUSED ? beta[c] : 0.f;
     const int Lp = L >> 1;
     float a = 0.f, q = 0.f;
-    for (int n = n0; n < n1; ++n) {
-        const float *r = y + ((size_t)n * C + c) * L;
+    // flat walk over (n, position) of this block's n-range: all 256 lanes stay busy even when a
+    // row is shorter than the workgroup (Lp = 62 for the last block)
+    const int per = FUSED ? Lp : L;
+    const int total = (n1 - n0) * per;
+    for (int idx = tl; idx < total; idx += kBlock) {
+        const int nl = idx / per, j = idx - nl * per;
+        const size_t row = (size_t)(n0 + nl) * C + c;
+        const float *r = y + row * L;
         if (FUSED) {
-            const float *gr = g + ((size_t)n * C + c) * Lp;
-            const float gb = bcast != 0.f ? g[(size_t)n * C + c] * bcast : 0.f;
-            for (int j = tl; j < Lp; j += kBlock) {
-                float y0 = r[2 * j], y1 = r[2 * j + 1];
-                int am;
-                if (pool_route(y0, y1, mu, sc, be, am)) {
-                    float d = bcast != 0.f ? gb : gr[j];
-                    a += d;
-                    q = __fmaf_rn(d, ((am ? y1 : y0) - mu) * is, q);
-                }
+            const float y0 = r[2 * j], y1 = r[2 * j + 1];
+            int am;
+            if (pool_route(y0, y1, mu, sc, be, am)) {
+                const float d = bcast != 0.f ? g[row] * bcast : g[row * Lp + j];
+                a += d;
+                q = __fmaf_rn(d, ((am ? y1 : y0) - mu) * is, q);
             }
         } else {
-            const float *gr = g + ((size_t)n * C + c) * L;
-            for (int t = tl; t < L; t += kBlock) {
-                float d = gr[t];
-                a += d;
-                q = __fmaf_rn(d, (r[t] - mu) * is, q);
-            }
+            const float d = g[row * L + j];
+            a += d;
+            q = __fmaf_rn(d, (r[j] - mu) * is, q);
         }
     }
     a = wave_sum(a); q = wave_sum(q);

@@ -114,7 +114,8 @@ __global__ void film_bwd_kernel(const float *__restrict__ z, const float *__rest
 __global__ __launch_bounds__(256) void bce_kernel(const float *__restrict__ x,
                                                   const float *__restrict__ t,
                                                   float *__restrict__ loss, float *__restrict__ dx,
-                                                  int numel) {
+                                                  int numel, double *__restrict__ running,
+                                                  double weight) {
     __shared__ double red[4];
     double a = 0.0;
     const float inv = 1.0f / (float)numel;
@@ -127,7 +128,11 @@ __global__ __launch_bounds__(256) void bce_kernel(const float *__restrict__ x,
     a = wave_sum(a);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = a;
     __syncthreads();
-    if (threadIdx.x == 0) loss[0] = (float)((red[0] + red[1] + red[2] + red[3]) / (double)numel);
+    if (threadIdx.x == 0) {
+        const float l = (float)((red[0] + red[1] + red[2] + red[3]) / (double)numel);
+        loss[0] = l;
+        if (running) running[0] += (double)l * weight;    // epoch bookkeeping without extra launches
+    }
 }
 
 __global__ void sigmoid_kernel(const float *__restrict__ x, float *__restrict__ p, size_t n) {
@@ -211,10 +216,11 @@ ECG_API int ecg_film_bwd(const float *z, const float *film, const float *dzc, fl
 }
 
 ECG_API int ecg_bce_logits_fwd(const float *x, const float *target, float *loss, float *dx,
-                               int numel, ecg_stream_t stream) {
+                               int numel, double *running_sum, double weight,
+                               ecg_stream_t stream) {
     ECG_REQUIRE(x && target && loss && numel > 0, "bce_logits_fwd: bad argument");
     hipLaunchKernelGGL(bce_kernel, dim3(1), dim3(256), 0, as_stream(stream), x, target, loss, dx,
-                       numel);
+                       numel, running_sum, weight);
     return check_launch("bce_kernel");
 }
 

@@ -49,7 +49,7 @@ SIGNATURES = {
     "ecg_linear_bwd": (_i, [_vp] * 8 + [_i, _i, _i, _i, _vp]),
     "ecg_film_fwd": (_i, [_vp, _vp, _vp, _i, _i, _vp]),
     "ecg_film_bwd": (_i, [_vp] * 5 + [_i, _i, _vp]),
-    "ecg_bce_logits_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _vp]),
+    "ecg_bce_logits_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _vp, ctypes.c_double, _vp]),
     "ecg_sigmoid_fwd": (_i, [_vp, _vp, _sz, _vp]),
     "ecg_transpose": (_i, [_vp, _vp, _i, _i, _vp]),
     "ecg_tail_fwd": (_i, [_vp] * 18 + [_i] * 7 + [_vp]),

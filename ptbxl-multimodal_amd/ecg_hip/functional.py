@@ -306,20 +306,23 @@ class BceWithLogitsFn(torch.autograd.Function):
     """mean BCE-with-logits; the gradient is produced by the same launch as the loss."""
 
     @staticmethod
-    def forward(ctx, logits, target):
+    def forward(ctx, logits, target, running, weight):
         logits, target = _contig(logits), _contig(target)
         if logits.shape != target.shape:
             raise ValueError(f"Target size ({tuple(target.shape)}) must be the same as input size ({tuple(logits.shape)})")
+        if running is not None and (running.dtype != torch.float64 or running.numel() != 1):
+            raise L.EcgHipError("running loss accumulator must be a float64 scalar tensor")
         loss = _empty(logits, 1)
         dx = torch.empty_like(logits) if ctx.needs_input_grad[0] else None
-        _call("ecg_bce_logits_fwd", _f32(logits), _f32(target), _f32(loss), _f32(dx), logits.numel(), _st())
+        _call("ecg_bce_logits_fwd", _f32(logits), _f32(target), _f32(loss), _f32(dx), logits.numel(),
+              L.ptr(running), float(weight), _st())
         ctx.save_for_backward(dx)
         return loss.view(())
 
     @staticmethod
     def backward(ctx, dloss):
         (dx,) = ctx.saved_tensors
-        return dx * dloss, None
+        return dx * dloss, None, None, None
 
 
 # --------------------------------------------------------------------------------------
@@ -359,12 +362,15 @@ class TailFn(torch.autograd.Function):
               _f32(film), _f32(zc), _f32(logits), M, F0, F, D, H1, H, C, _st())
         ctx.save_for_backward(g, xdc, Wp, W0, W2, Wf, Wh, z, h1, h2, film, zc)
         ctx.dims = (M, F0, F, D, H1, H, C, demo)
+        ctx.set_materialize_grads(False)       # an unused `z` output must not cost a zero-fill
         return logits, z
 
     @staticmethod
     def backward(ctx, dlogits, dz_extra):
         g, xd, Wp, W0, W2, Wf, Wh, z, h1, h2, film, zc = ctx.saved_tensors
         M, F0, F, D, H1, H, C, demo = ctx.dims
+        if dlogits is None:
+            dlogits = torch.zeros(M, C, dtype=torch.float32, device=g.device)
         dlogits = _contig(dlogits)
         dz, dg = _empty(g, M, F), _empty(g, M, F0)
         dzc = dfilm = dh2m = dh1m = dxd = None
@@ -403,9 +409,11 @@ def tail(g, x_demo, proj, head, mlp0=None, mlp2=None, film_gen=None):
                         mlp2.bias, film_gen.weight, film_gen.bias, head.weight, head.bias)
 
 
-def binary_cross_entropy_with_logits(logits, target):
-    """Drop-in for F.binary_cross_entropy_with_logits(logits, y) (mean reduction only)."""
-    return BceWithLogitsFn.apply(logits, target)
+def binary_cross_entropy_with_logits(logits, target, running=None, weight=1.0):
+    """Drop-in for F.binary_cross_entropy_with_logits(logits, y) (mean reduction only).
+    `running` (optional float64 scalar on the device) receives `+= loss * weight` inside the same
+    launch: the loops' epoch-loss bookkeeping without a host sync or extra kernels."""
+    return BceWithLogitsFn.apply(logits, target, running, weight)
 
 
 def sigmoid(x):

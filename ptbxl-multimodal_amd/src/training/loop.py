@@ -32,12 +32,13 @@ def train_one_epoch(model, loader: DataLoader, optimizer, device) -> float:
     weighted = None
     for x, y in tqdm(loader, desc="Train", leave=False):
         x, y = x.to(device), y.to(device)
+        if weighted is None:
+            weighted = torch.zeros((), dtype=torch.float64, device=x.device)
         optimizer.zero_grad()
-        loss = hipF.binary_cross_entropy_with_logits(_logits(model(x)), y)
+        # the BCE launch also does `weighted += loss * batch_size` (double, on the device)
+        loss = hipF.binary_cross_entropy_with_logits(_logits(model(x)), y, weighted, x.size(0))
         loss.backward()
         optimizer.step()
-        term = loss.detach().double() * x.size(0)
-        weighted = term if weighted is None else weighted + term
     return (0.0 if weighted is None else weighted.item()) / len(loader.dataset)
 
 
@@ -48,8 +49,9 @@ def eval_one_epoch(model, loader: DataLoader, device) -> Dict[str, float]:
         for x, y in tqdm(loader, desc="Eval", leave=False):
             x, y = x.to(device), y.to(device)
             logits = _logits(model(x))
-            term = hipF.binary_cross_entropy_with_logits(logits, y).double() * x.size(0)
-            weighted = term if weighted is None else weighted + term
+            if weighted is None:
+                weighted = torch.zeros((), dtype=torch.float64, device=x.device)
+            hipF.binary_cross_entropy_with_logits(logits, y, weighted, x.size(0))
             probs.append(hipF.sigmoid(logits))
             targets.append(y)
     y_true = torch.cat(targets).cpu().numpy()

@@ -21,8 +21,8 @@ except ImportError:
 class _HipBCEWithLogits(torch.nn.Module):
     """BCEWithLogitsLoss() (mean) on the HIP path."""
 
-    def forward(self, logits, target):
-        return hipF.binary_cross_entropy_with_logits(logits, target)
+    def forward(self, logits, target, running=None, weight=1.0):
+        return hipF.binary_cross_entropy_with_logits(logits, target, running, weight)
 
 
 bce_loss_fn = _HipBCEWithLogits()
@@ -33,12 +33,13 @@ def train_one_epoch_demo(model, loader, optimizer, device):
     running, batches = None, 0
     for x_ecg, x_demo, y in tqdm(loader, desc="Train-ECG+Demo", leave=False):
         x_ecg, x_demo, y = x_ecg.to(device), x_demo.to(device), y.to(device)
+        if running is None:
+            running = torch.zeros((), dtype=torch.float64, device=x_ecg.device)
         optimizer.zero_grad()
-        loss = bce_loss_fn(model(x_ecg, x_demo), y)
+        loss = bce_loss_fn(model(x_ecg, x_demo), y, running, 1.0)    # running += loss inside the launch
         loss.backward()
         optimizer.step()
-        term = loss.detach().double()
-        running, batches = (term if running is None else running + term), batches + 1
+        batches += 1
     return (0.0 if running is None else running.item()) / max(1, batches)
 
 
@@ -49,8 +50,10 @@ def eval_one_epoch_demo(model, loader, device):
         for x_ecg, x_demo, y in tqdm(loader, desc="Val-ECG+Demo", leave=False):
             x_ecg, x_demo, y = x_ecg.to(device), x_demo.to(device), y.to(device)
             logits = model(x_ecg, x_demo)
-            term = bce_loss_fn(logits, y).double()
-            running, batches = (term if running is None else running + term), batches + 1
+            if running is None:
+                running = torch.zeros((), dtype=torch.float64, device=x_ecg.device)
+            bce_loss_fn(logits, y, running, 1.0)
+            batches += 1
             probs.append(hipF.sigmoid(logits))
             targets.append(y)
     out = compute_metrics(torch.cat(targets).cpu().numpy(), torch.cat(probs).cpu().numpy())
