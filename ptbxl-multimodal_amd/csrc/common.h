@@ -30,10 +30,30 @@ inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
     do { if (!(cond)) return ::ecg::fail(ECG_EINVAL, __VA_ARGS__); } while (0)
 
 // ---- device helpers ----------------------------------------------------------------
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+// Lane reductions: the first four butterfly levels are DPP row operations (fused into
+// v_add_f32_dpp, ~1 issue slot each); only the 16- and 32-lane levels need the LDS crossbar
+// (ds_bpermute, ~100 cycles of latency each).
+template <int CTRL>
+__device__ __forceinline__ float dpp_move(float v) {
+    return __builtin_bit_cast(
+        float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+// every lane ends with the sum over its 16-lane row
+__device__ __forceinline__ float row16_sum(float v) {
+    v += dpp_move<0xB1>(v);     // quad_perm [1,0,3,2]
+    v += dpp_move<0x4E>(v);     // quad_perm [2,3,0,1]
+    v += dpp_move<0x141>(v);    // row_half_mirror
+    v += dpp_move<0x140>(v);    // row_mirror
     return v;
+}
+// sum over each 32-lane half of the wave (the column axis of a 32x32 MFMA accumulator)
+__device__ __forceinline__ float half32_sum(float v) {
+    v = row16_sum(v);
+    return v + __shfl_xor(v, 16, 64);
+}
+__device__ __forceinline__ float wave_sum(float v) {
+    v = half32_sum(v);
+    return v + __shfl_xor(v, 32, 64);
 }
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll

@@ -202,11 +202,8 @@ __global__ __launch_bounds__(256, 2) void conv1d_mfma_fwd_kernel(
                 }
             }
             if (STATS) {
-#pragma unroll
-                for (int off = 16; off > 0; off >>= 1) {     // stays inside the 32-lane half
-                    s += __shfl_xor(s, off, 64);
-                    q += __shfl_xor(q, off, 64);
-                }
+                s = half32_sum(s);       // 4 DPP adds + 1 bpermute, stays inside the 32-lane half
+                q = half32_sum(q);
                 if (l31 == 0) {
                     const int lc = 32 * i + acc_row(r, half);   // channel inside the wave tile
                     red[(wave * (CO_T / WCO) + lc) * 2] = s;
@@ -288,6 +285,12 @@ int mfma_fwd(const float *x, const float *wp, const float *bias, float *y, float
 // grid = (ceil(R/R_T), Cout/M_T, S), R = Cin*K.  4 waves laid out WM x WR x WK: WK > 1 splits the
 // staged t range between waves (their accumulators are summed through LDS at the end).
 // slab[s][co][r] (+ bias slab [s][co] behind the S weight slabs), summed by wgrad_reduce_kernel.
+//
+// Pipeline: a stage is one (n, t-tile).  LDS holds TWO stage images {dY tile | x tile}.  While the
+// MFMAs of stage i run out of image i&1, the registers holding stage i+1 are written into image
+// (i+1)&1 (first half of the steps) and the loads of stage i+2 are issued (second half), one
+// staging operation per MFMA group; ONE barrier closes the stage.  Per-thread global offsets are
+// loop-invariant; a stage only moves uniform base pointers.
 template <int M_T, int R_T, int WM, int WR, int WK, int T_T, int KK>
 __global__ __launch_bounds__(256, 2) void conv1d_mfma_wgrad_kernel(
     const float *__restrict__ dy, const float *__restrict__ x, float *__restrict__ slab, int N,
@@ -295,20 +298,23 @@ __global__ __launch_bounds__(256, 2) void conv1d_mfma_wgrad_kernel(
     static_assert(WM * WR * WK == 4, "4 waves per workgroup");
     constexpr int MC = M_T / WM / 32, MR = R_T / WR / 32;
     constexpr int TW = T_T / WK;                        // t range of one wave per staged tile
+    constexpr int NST = TW / 2;                         // reduction steps per stage
     constexpr int DS = T_T + 1;                         // dY tile row stride: odd -> conflict-free A reads
     constexpr int XSPAN = T_T + KK - 1;
     constexpr int XS = ((XSPAN - KK + 31) / 32) * 32 + KK;   // >= XSPAN and == KK (mod 32)
     constexpr int NCI = (R_T + KK - 2) / KK + 1;        // input channels a column tile can touch
     constexpr int DEL = M_T * T_T, DLOADS = DEL / 256;
-    static_assert(DEL % 256 == 0, "dY tile must be a whole number of 256-thread passes");
     constexpr int XEL = NCI * XS, XLOADS = (XEL + 255) / 256;
+    constexpr int NOPS = DLOADS + XLOADS;               // staging operations per stage (per thread)
+    constexpr int IMG = M_T * DS + XEL;
     constexpr int ACCF = MC * MR * 16 * 64;             // floats of one wave's accumulators
-    constexpr int STAGEF = M_T * DS + NCI * XS;
-    constexpr int LDSF = (WK > 1 && ACCF > STAGEF) ? ACCF : STAGEF;
+    constexpr int LDSF = (WK > 1 && ACCF > 2 * IMG) ? ACCF : 2 * IMG;
     static_assert(XS >= XSPAN, "x row stride too small");
+    static_assert(DEL % 256 == 0, "dY tile must be a whole number of 256-thread passes");
+    static_assert(256 % T_T == 0 || T_T % 256 == 0, "dY tile rows per pass");
+    static_assert(XLOADS <= 32 && DLOADS <= 64, "mask bits");
 
     __shared__ float lds[LDSF + (WK > 1 ? 4 * 32 : 0)];
-    float *dys = lds, *xs = lds + M_T * DS;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int half = lane >> 5, l31 = lane & 31;
@@ -320,13 +326,13 @@ __global__ __launch_bounds__(256, 2) void conv1d_mfma_wgrad_kernel(
     const int n_begin = (int)((long long)N * s / S), n_end = (int)((long long)N * (s + 1) / S);
 
     // per-lane LDS offset of column r = r0 + wr0 + 32*j + l31 inside the x tile: ci_local*XS + k
-    int xoff[MR];
+    int xcol[MR];
 #pragma unroll
     for (int j = 0; j < MR; ++j) {
         int r = r0 + wr0 + 32 * j + l31;
         if (r >= R) r = R - 1;                 // clamped columns compute garbage that is never stored
         const int ci = r / KK;
-        xoff[j] = (ci - ci_base) * XS + (r - ci * KK);
+        xcol[j] = (ci - ci_base) * XS + (r - ci * KK);
     }
 
     f32x16 acc[MC][MR];
@@ -341,77 +347,117 @@ __global__ __launch_bounds__(256, 2) void conv1d_mfma_wgrad_kernel(
     for (int a = 0; a < MC; ++a) bsum[a] = 0.f;
     const bool want_bias = (blockIdx.x == 0) && (wr == 0);
 
-    float dreg[DLOADS], xreg[XLOADS];
-    const int ntt = (Lo + T_T - 1) / T_T;
-    const int total = (n_end - n_begin) * ntt;
-
-    // unconditional staging loads, zero padding applied at commit (see the forward kernel)
-    static_assert(256 % T_T == 0 || T_T % 256 == 0, "dY tile rows per pass");
+    // ---- staging: loop-invariant per-thread pieces ------------------------------------------
     constexpr int RPP = (T_T >= 256) ? 1 : 256 / T_T;       // dY rows fetched per pass
     constexpr int PPR = (T_T >= 256) ? T_T / 256 : 1;       // passes per dY row
     const int drow0 = (T_T >= 256) ? 0 : tid / T_T, dtt = (T_T >= 256) ? tid : tid % T_T;
+    int xci[XLOADS], xpos[XLOADS];
+#pragma unroll
+    for (int j = 0; j < XLOADS; ++j) {
+        const int e = min(tid + 256 * j, XEL - 1);
+        xci[j] = min(ci_base + e / XS, Cin - 1) * L;          // row offset (clamped into the tensor)
+        xpos[j] = e % XS - pad;
+    }
+    float dreg[DLOADS], xreg[XLOADS];
     unsigned xmask = 0, dmask = 0;
+    const int ntt = (Lo + T_T - 1) / T_T;
+    const int total = (n_end - n_begin) * ntt;
 
-    auto prefetch = [&](int it) {
-        const int n = n_begin + it / ntt, t0 = (it % ntt) * T_T;
-        const float *dyn = dy + ((size_t)n * Cout + co0) * Lo;
-        const float *xn = x + (size_t)n * Cin * L;
+    // stage geometry -> uniform bases + the few per-stage per-thread values
+    const float *dyn = dy, *xn = x;
+    int dvoff = 0, t0 = 0;
+    auto stage_setup = [&](int it) {
+        const int n = n_begin + it / ntt;
+        t0 = (it % ntt) * T_T;
+        dyn = dy + ((size_t)n * Cout + co0) * Lo + t0;
+        xn = x + (size_t)n * Cin * L;
+        dvoff = drow0 * Lo + min(dtt, Lo - 1 - t0);           // same VGPR offset for every dY load
         dmask = 0;
 #pragma unroll
-        for (int j = 0; j < DLOADS; ++j) {
-            const int row = drow0 + (j / PPR) * RPP, tt = dtt + (j % PPR) * 256;
-            const int t = t0 + tt;
-            dreg[j] = dyn[(size_t)row * Lo + min(t, Lo - 1)];
-            dmask |= (t < Lo) ? (1u << (j % PPR)) : 0u;
-        }
-        xmask = 0;
-#pragma unroll
-        for (int j = 0; j < XLOADS; ++j) {
-            const int e = tid + 256 * j;
-            const int ci = e / XS, pos = e - ci * XS;
-            const int sidx = t0 - pad + pos;
-            const int cic = min(ci_base + ci, Cin - 1), sc = min(max(sidx, 0), L - 1);
-            xreg[j] = xn[(size_t)cic * L + sc];
-            xmask |= ((sidx >= 0) && (sidx < L)) ? (1u << j) : 0u;
+        for (int q = 0; q < PPR; ++q) dmask |= (t0 + dtt + 256 * q < Lo) ? (1u << q) : 0u;
+    };
+    auto load_op = [&](int o) {
+        if (o < DLOADS) {
+            // row = drow0 + (o/PPR)*RPP, tt = dtt + (o%PPR)*256: the (o-dependent) part is uniform
+            const int extra = (o % PPR) * 256;
+            const float *pj = dyn + (size_t)(o / PPR) * RPP * Lo;
+            dreg[o] = pj[PPR == 1 ? dvoff : drow0 * Lo + min(dtt + extra, Lo - 1 - t0)];
+        } else {
+            const int j = o - DLOADS;
+            const int sidx = t0 + xpos[j];
+            xreg[j] = xn[xci[j] + min(max(sidx, 0), L - 1)];
+            const unsigned bit = ((sidx >= 0) && (sidx < L)) ? (1u << j) : 0u;
+            xmask = (j == 0) ? bit : (xmask | bit);
         }
     };
-    auto commit = [&]() {
-#pragma unroll
-        for (int j = 0; j < DLOADS; ++j) {
-            const int row = drow0 + (j / PPR) * RPP, tt = dtt + (j % PPR) * 256;
-            const unsigned keep = 0u - ((dmask >> (j % PPR)) & 1u);
-            dys[row * DS + tt] = __uint_as_float(__float_as_uint(dreg[j]) & keep);
-        }
-#pragma unroll
-        for (int j = 0; j < XLOADS; ++j) {
+    // the masks of the stage being committed must survive the loads of the following stage
+    unsigned cxmask = 0, cdmask = 0;
+    auto commit_op = [&](int o, float *img) {
+        if (o < DLOADS) {
+            const int row = drow0 + (o / PPR) * RPP, tt = dtt + (o % PPR) * 256;
+            const unsigned keep = 0u - ((cdmask >> (o % PPR)) & 1u);
+            img[row * DS + tt] = __uint_as_float(__float_as_uint(dreg[o]) & keep);
+        } else {
+            const int j = o - DLOADS;
             const int e = tid + 256 * j;
-            const unsigned keep = 0u - ((xmask >> j) & 1u);
-            if (256 * (j + 1) <= XEL || e < XEL) xs[e] = __uint_as_float(__float_as_uint(xreg[j]) & keep);
+            const unsigned keep = 0u - ((cxmask >> j) & 1u);
+            if (256 * (j + 1) <= XEL || e < XEL)
+                img[M_T * DS + e] = __uint_as_float(__float_as_uint(xreg[j]) & keep);
         }
     };
 
-    if (total > 0) prefetch(0);
+    // prologue: stage 0 -> image 0, stage 1 -> registers
+    if (total > 0) {
+        stage_setup(0);
+#pragma unroll
+        for (int o = 0; o < NOPS; ++o) load_op(o);
+        cxmask = xmask; cdmask = dmask;
+#pragma unroll
+        for (int o = 0; o < NOPS; ++o) commit_op(o, lds);
+        if (total > 1) {
+            stage_setup(1);
+#pragma unroll
+            for (int o = 0; o < NOPS; ++o) load_op(o);
+        }
+    }
+    __syncthreads();
+
     for (int it = 0; it < total; ++it) {
-        __syncthreads();
-        commit();
-        __syncthreads();
-        if (it + 1 < total) prefetch(it + 1);
+        const float *dys = lds + (it & 1) * IMG, *xs = dys + M_T * DS;
+        float *nxt = lds + ((it + 1) & 1) * IMG;
+        const bool do_commit = it + 1 < total, do_load = it + 2 < total;
+        cxmask = xmask; cdmask = dmask;                    // masks of stage it+1 (now in registers)
+        if (do_load) stage_setup(it + 2);                  // bases/masks for the loads issued below
+
         const float *arow = dys + (wm0 + l31) * DS + wt0 + half;
         const float *brow = xs + wt0 + half;
         auto ld = [&](int tp, float *a, float *b) {
 #pragma unroll
             for (int i = 0; i < MC; ++i) a[i] = arow[32 * i * DS + tp];
 #pragma unroll
-            for (int j = 0; j < MR; ++j) b[j] = brow[xoff[j] + tp];
+            for (int j = 0; j < MR; ++j) b[j] = brow[xcol[j] + tp];
         };
         float a_c[MC], b_c[MR], a_n[MC], b_n[MR];
         ld(0, a_c, b_c);
-#pragma unroll 8
-        for (int tp = 0; tp < TW; tp += 2) {     // next step's fragments are read before this step's MFMAs
-            ld((tp + 2 < TW) ? tp + 2 : 0, a_n, b_n);
-            __builtin_amdgcn_sched_barrier(0);         // keep the next-step reads ABOVE these MFMAs
+        constexpr int H1 = NST / 2;
 #pragma unroll
-            for (int i = 0; i < MC; ++i) bsum[i] += a_c[i];     // bias-grad rides on the A fragments (VALU idle anyway)
+        for (int st = 0; st < NST; ++st) {      // next step's fragments are read before this step's MFMAs
+            ld(st + 1 < NST ? 2 * (st + 1) : 0, a_n, b_n);
+            if (st < H1) {
+                if (do_commit) {
+#pragma unroll
+                    for (int o = st * NOPS / H1; o < (st + 1) * NOPS / H1; ++o) commit_op(o, nxt);
+                }
+            } else {
+                if (do_load) {
+#pragma unroll
+                    for (int o = (st - H1) * NOPS / (NST - H1); o < (st - H1 + 1) * NOPS / (NST - H1); ++o)
+                        load_op(o);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);         // keep reads + staging ABOVE these MFMAs
+#pragma unroll
+            for (int i = 0; i < MC; ++i) bsum[i] += a_c[i];     // bias-grad rides on the A fragments
 #pragma unroll
             for (int i = 0; i < MC; ++i)
 #pragma unroll
@@ -422,6 +468,7 @@ __global__ __launch_bounds__(256, 2) void conv1d_mfma_wgrad_kernel(
 #pragma unroll
             for (int j = 0; j < MR; ++j) b_c[j] = b_n[j];
         }
+        __syncthreads();      // image it&1 free again; image (it+1)&1 complete
     }
 
     // ---- combine the WK t-split waves through LDS (fixed order), then write the slab ---------
