@@ -229,14 +229,12 @@ __global__ __launch_bounds__(256, 2) void conv1d_mfma_fwd_kernel(
 
 struct FwdCfg { int co_t, t_t; };
 
-// Tile choice: the largest channel tile that still gives >= 2 workgroups per CU (512), so two
-// workgroups can overlap each other's staging on every CU.
+// Tile choice.  Measured on MI355X (B=256): 64x128 tiles at 4 resident workgroups per CU beat
+// 128x128 at 2 per CU by 6-8 % (more independent waves per SIMD to cover each other's prologue,
+// epilogue and staging waits), so the 64-channel tile is used whenever C_out allows it.
 static FwdCfg fwd_cfg(int N, int Cout, int Lo) {
-    if (Cout % 128 == 0 && (long long)(Cout / 128) * cdiv(Lo, 128) * N >= 512) return {128, 128};
-    if (Cout % 64 == 0) {
-        if (Lo > 128 && (long long)(Cout / 64) * cdiv(Lo, 256) * N >= 512) return {64, 256};
-        return {64, 128};
-    }
+    (void)N; (void)Lo;
+    if (Cout % 64 == 0) return {64, 128};
     return {32, 256};
 }
 
@@ -268,11 +266,7 @@ int mfma_fwd(const float *x, const float *wp, const float *bias, float *y, float
              int Cin, int Cout, int L, int K, int pad, hipStream_t st) {
     const int Lo = L + 2 * pad - K + 1;
     const FwdCfg c = fwd_cfg(N, Cout, Lo);
-    if (c.co_t == 128)
-        launch_fwd<128, 128, 2, 2>(x, wp, bias, y, partials, N, Cin, Cout, L, Lo, pad, st);
-    else if (c.co_t == 64 && c.t_t == 256)
-        launch_fwd<64, 256, 1, 4>(x, wp, bias, y, partials, N, Cin, Cout, L, Lo, pad, st);
-    else if (c.co_t == 64)
+    if (c.co_t == 64)
         launch_fwd<64, 128, 2, 2>(x, wp, bias, y, partials, N, Cin, Cout, L, Lo, pad, st);
     else
         launch_fwd<32, 256, 1, 4>(x, wp, bias, y, partials, N, Cin, Cout, L, Lo, pad, st);
@@ -551,7 +545,8 @@ static WgCfg wgrad_cfg(int N, int Cin, int Cout) {
     else c = {32, 192, 0};
     const int tiles = cdiv(R, c.r_t) * (Cout / c.m_t);
     int s = 512 / tiles;               // fill, but never exceed, the 2 x 256 resident-workgroup slots:
-                                       // one workgroup over and the launch takes two rounds
+                                       // one workgroup over and the launch takes two rounds.
+                                       // (64-channel tiles at 4 workgroups per CU measured no better here.)
     if (s > N) s = N;
     if (s < 1) s = 1;
     c.splits = s;
