@@ -62,6 +62,13 @@ int ecg_check_device(void);
 int ecg_conv1d_pack_weights(const float *w, float *w_fwd, float *w_bwd,
                             int C_out, int C_in, int K, ecg_stream_t stream);
 
+/* count (<= 16) packs in ONE launch; problem q == ecg_conv1d_pack_weights(w[q], w_fwd[q], w_bwd[q],
+ * C_out[q], C_in[q], K[q]).  A Linear weight transpose is the K = 1 case (w_fwd[ci][co] = w[co][ci]).
+ * All six arguments are HOST arrays of length count; w_fwd[q] or w_bwd[q] may be NULL. */
+int ecg_pack_weights_grouped(const float *const *w, float *const *w_fwd, float *const *w_bwd,
+                             const int *C_out, const int *C_in, const int *K, int count,
+                             ecg_stream_t stream);
+
 /* Number P of per-channel (sum, sum-of-squares) partials ecg_conv1d_fwd writes per output
  * channel for this shape; stat_partials must hold C_out*P*2 floats. */
 int ecg_conv1d_fwd_stat_partials(int N, int C_in, int C_out, int L, int K, int pad);

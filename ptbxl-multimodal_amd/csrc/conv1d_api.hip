@@ -12,6 +12,8 @@ int direct_wgrad(const float *dy, const float *x, float *dw, float *db, float *w
                  int Cout, int L, int K, int pad, hipStream_t st);
 int pack_weights(const float *w, float *w_fwd, float *w_bwd, int Co, int Ci, int K,
                  hipStream_t st);
+int pack_weights_grouped(const float *const *w, float *const *w_fwd, float *const *w_bwd,
+                         const int *Co, const int *Ci, const int *K, int count, hipStream_t st);
 // conv1d_mfma.hip
 bool mfma_fwd_supported(int Cin, int Cout, int K, int pad);
 int mfma_fwd_stat_partials(int N, int Cin, int Cout, int Lo);
@@ -40,6 +42,19 @@ ECG_API int ecg_conv1d_pack_weights(const float *w, float *w_fwd, float *w_bwd, 
     ECG_REQUIRE(w && (w_fwd || w_bwd), "pack_weights: null pointer");
     ECG_REQUIRE(C_out > 0 && C_in > 0 && K >= 1 && K <= 31, "pack_weights: bad shape");
     return pack_weights(w, w_fwd, w_bwd, C_out, C_in, K, as_stream(stream));
+}
+
+ECG_API int ecg_pack_weights_grouped(const float *const *w, float *const *w_fwd,
+                                     float *const *w_bwd, const int *C_out, const int *C_in,
+                                     const int *K, int count, ecg_stream_t stream) {
+    ECG_REQUIRE(w && w_fwd && w_bwd && C_out && C_in && K, "pack_weights_grouped: null table");
+    ECG_REQUIRE(count >= 1 && count <= 16, "pack_weights_grouped: count=%d outside [1,16]", count);
+    for (int q = 0; q < count; ++q) {
+        ECG_REQUIRE(w[q] && (w_fwd[q] || w_bwd[q]), "pack_weights_grouped: problem %d has null pointers", q);
+        ECG_REQUIRE(C_out[q] > 0 && C_in[q] > 0 && K[q] >= 1 && K[q] <= 31,
+                    "pack_weights_grouped: problem %d has a bad shape", q);
+    }
+    return pack_weights_grouped(w, w_fwd, w_bwd, C_out, C_in, K, count, as_stream(stream));
 }
 
 ECG_API int ecg_conv1d_fwd_stat_partials(int N, int C_in, int C_out, int L, int K, int pad) {

@@ -313,6 +313,40 @@ int direct_wgrad(const float *dy, const float *x, float *dw, float *db, float *w
     return wgrad_reduce(ws, dw, db, wslab, Cout, S, st);
 }
 
+// All weight packs of a model in ONE launch (a Linear transpose is the K = 1 case).
+constexpr int kMaxPack = 16;
+struct PackProb { const float *w; float *w_fwd, *w_bwd; int Co, Ci, K, block0; };
+struct PackArgs { PackProb p[kMaxPack]; int count; };
+
+__global__ __launch_bounds__(256) void pack_weights_grouped_kernel(PackArgs a) {
+    int pi = 0;
+#pragma unroll
+    for (int q = 1; q < kMaxPack; ++q)
+        if (q < a.count && (int)blockIdx.x >= a.p[q].block0) pi = q;
+    const PackProb pr = a.p[pi];
+    const int idx = ((int)blockIdx.x - pr.block0) * 256 + threadIdx.x;
+    const int total = pr.Co * pr.Ci * pr.K;
+    if (idx >= total) return;
+    const int k = idx % pr.K, ci = (idx / pr.K) % pr.Ci, co = idx / (pr.K * pr.Ci);
+    const float v = pr.w[idx];
+    if (pr.w_fwd) pr.w_fwd[((size_t)k * pr.Ci + ci) * pr.Co + co] = v;
+    if (pr.w_bwd) pr.w_bwd[((size_t)(pr.K - 1 - k) * pr.Co + co) * pr.Ci + ci] = v;
+}
+
+int pack_weights_grouped(const float *const *w, float *const *w_fwd, float *const *w_bwd,
+                         const int *Co, const int *Ci, const int *K, int count, hipStream_t st) {
+    PackArgs a;
+    a.count = count;
+    int blocks = 0;
+    for (int q = 0; q < count; ++q) {
+        a.p[q] = PackProb{w[q], w_fwd[q], w_bwd[q], Co[q], Ci[q], K[q], blocks};
+        blocks += cdiv((long long)Co[q] * Ci[q] * K[q], 256);
+    }
+    for (int q = count; q < kMaxPack; ++q) a.p[q] = PackProb{nullptr, nullptr, nullptr, 0, 0, 1, 1 << 30};
+    hipLaunchKernelGGL(pack_weights_grouped_kernel, dim3(blocks), dim3(256), 0, st, a);
+    return check_launch("pack_weights_grouped_kernel");
+}
+
 int pack_weights(const float *w, float *w_fwd, float *w_bwd, int Co, int Ci, int K,
                  hipStream_t st) {
     int total = Co * Ci * K;

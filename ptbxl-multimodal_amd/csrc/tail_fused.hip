@@ -17,7 +17,7 @@
 namespace ecg {
 
 constexpr int kSB = 4;   // samples per workgroup
-constexpr int kLB = 16;  // global loads issued back-to-back before their first use
+constexpr int kLB = 32;  // global loads issued back-to-back before their first use
 
 // acc[s] += sum_{i<n} v_s[i][s] * w[i * stride]   (v_s in LDS as [n][kSB], w walks global memory).
 // These loops are chains of dependent-looking L2 loads; hipcc keeps each load next to its FMA and
@@ -272,16 +272,29 @@ __global__ __launch_bounds__(256) void linear_wgrad_grouped_kernel(WgArgs a) {
     const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;   // thread owns o = 2ty..2ty+1, i = 2tx..2tx+1
     float acc[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
     float bacc = 0.f;
-    for (int m0 = 0; m0 < a.M; m0 += 32) {
-        // stage G[m0:m0+32][o0:o0+32] and X[m0:m0+32][i0:i0+32]; lanes walk the contiguous axis
+    // the next 32-sample chunk is loaded into registers while the current one is consumed
+    float gr[4], xr[4];
+    auto fetch = [&](int m0) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int e = tid + 256 * r, mm = e >> 5, cc = e & 31;
-            const int m = m0 + mm;
-            Gs[mm][cc] = (m < a.M && o0 + cc < pr.Out) ? pr.G[(size_t)m * pr.Out + o0 + cc] : 0.f;
-            Xs[mm][cc] = (m < a.M && i0 + cc < pr.In) ? pr.X[(size_t)m * pr.In + i0 + cc] : 0.f;
+            const int m = min(m0 + mm, a.M - 1);
+            const float gv = pr.G[(size_t)m * pr.Out + min(o0 + cc, pr.Out - 1)];
+            const float xv = pr.X[(size_t)m * pr.In + min(i0 + cc, pr.In - 1)];
+            gr[r] = (m0 + mm < a.M && o0 + cc < pr.Out) ? gv : 0.f;
+            xr[r] = (m0 + mm < a.M && i0 + cc < pr.In) ? xv : 0.f;
+        }
+    };
+    fetch(0);
+    for (int m0 = 0; m0 < a.M; m0 += 32) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int e = tid + 256 * r, mm = e >> 5, cc = e & 31;
+            Gs[mm][cc] = gr[r];
+            Xs[mm][cc] = xr[r];
         }
         __syncthreads();
+        if (m0 + 32 < a.M) fetch(m0 + 32);
 #pragma unroll 8
         for (int k = 0; k < 32; ++k) {
             const float g0 = Gs[k][2 * ty], g1 = Gs[k][2 * ty + 1];

@@ -67,6 +67,48 @@ def conv1d_pack(w, need_bwd=True):
     return w_fwd, w_bwd
 
 
+class WeightPacker:
+    """All per-forward weight repacking of a model in one launch: conv weights -> (w_fwd, w_bwd)
+    and the Linear weights the fused tail reads transposed.  Destination buffers and the
+    host-side pointer tables are cached while the parameter storage stays put."""
+
+    def __init__(self):
+        self._key = None
+
+    # the cache holds raw device pointers: never copy or pickle it along with the model
+    def __deepcopy__(self, memo):
+        return WeightPacker()
+
+    def __getstate__(self):
+        return {}
+
+    def __setstate__(self, state):
+        self._key = None
+
+    def pack(self, convs, linears, need_bwd):
+        srcs = [c.weight for c in convs] + [l.weight for l in linears]
+        key = (need_bwd,) + tuple((w.data_ptr(), tuple(w.shape)) for w in srcs)
+        if key != self._key:
+            self._key = key
+            self.conv_packs, self.linear_T, fw, bw, co, ci, kk = [], [], [], [], [], [], []
+            for i, c in enumerate(convs):
+                w = _contig(c.weight)
+                Co, Ci, K = w.shape
+                wf = torch.empty_like(w).view(K, Ci, Co)
+                wb = torch.empty_like(w).view(K, Co, Ci) if (need_bwd and i > 0) else None   # block 0 has no input-grad
+                self.conv_packs.append((wf, wb))
+                fw.append(wf); bw.append(wb); co.append(Co); ci.append(Ci); kk.append(K)
+            for l in linears:
+                w = _contig(l.weight)
+                wt = torch.empty(w.shape[1], w.shape[0], dtype=w.dtype, device=w.device)
+                self.linear_T.append(wt)
+                fw.append(wt); bw.append(None); co.append(w.shape[0]); ci.append(w.shape[1]); kk.append(1)
+            self._tables = (L.ptr_table([_contig(w) for w in srcs]), L.ptr_table(fw), L.ptr_table(bw),
+                            L.int_table(co), L.int_table(ci), L.int_table(kk), len(srcs))
+        _call("ecg_pack_weights_grouped", *self._tables, _st())
+        return self.conv_packs, self.linear_T
+
+
 def conv1d_forward_raw(x, w_fwd, bias, Co, K, pad, want_stats):
     N, Ci, Lin = x.shape
     Lo = Lin + 2 * pad - K + 1
@@ -153,12 +195,15 @@ class ConvBlockFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, w, b, gamma, beta, running_mean, running_var, nbt, training, momentum,
-                eps, pad, gap=False):
+                eps, pad, gap=False, packed=None):
         x, w = _contig(x), _contig(w)
         Co, _, K = w.shape
         use_batch = training or running_mean is None
         need_grad = any(ctx.needs_input_grad)
-        w_fwd, w_bwd = conv1d_pack(w, need_bwd=need_grad and ctx.needs_input_grad[0])
+        if packed is not None and (packed[1] is not None or not ctx.needs_input_grad[0]):
+            w_fwd, w_bwd = packed                        # packed by WeightPacker for the whole model
+        else:
+            w_fwd, w_bwd = conv1d_pack(w, need_bwd=need_grad and ctx.needs_input_grad[0])
         y, partials, P = conv1d_forward_raw(x, w_fwd, b, Co, K, pad, want_stats=use_batch)
         if use_batch:
             rm, rv, cnt = (running_mean, running_var, nbt) if training else (None, None, None)
@@ -191,7 +236,7 @@ class ConvBlockFn(torch.autograd.Function):
               _f32(ws), N, Co, Lo, 1 if ctx.batch_stats else 0, _st())
         dx, dw, db = conv1d_backward_raw(x, dy, w.shape, ctx.w_bwd, ctx.pad, ctx.needs_input_grad[0],
                                          overlap=True)
-        return dx, dw, db, dgamma, dbeta, None, None, None, None, None, None, None, None
+        return dx, dw, db, dgamma, dbeta, None, None, None, None, None, None, None, None, None
 
 
 # --------------------------------------------------------------------------------------
@@ -385,11 +430,11 @@ class BceWithLogitsFn(torch.autograd.Function):
 # --------------------------------------------------------------------------------------
 # functional entry points
 # --------------------------------------------------------------------------------------
-def conv_block(x, conv, bn, gap=False):
+def conv_block(x, conv, bn, gap=False, packed=None):
     """Fused Conv1d -> BatchNorm1d -> ReLU -> MaxPool1d(2) [-> AdaptiveAvgPool1d(1).squeeze(-1)]."""
     return ConvBlockFn.apply(x, conv.weight, conv.bias, bn.weight, bn.bias, bn.running_mean,
                              bn.running_var, bn.num_batches_tracked, bn.training, bn.momentum,
-                             bn.eps, conv.padding[0], gap)
+                             bn.eps, conv.padding[0], gap, packed)
 
 
 class TailFn(torch.autograd.Function):
@@ -398,21 +443,23 @@ class TailFn(torch.autograd.Function):
     reference src/models/ecg_cnn.py:63-64 and src/models/ecg_multimodal.py:88-99."""
 
     @staticmethod
-    def forward(ctx, g, xd, Wp, bp, W0, b0, W2, b2, Wf, bf, Wh, bh):
+    def forward(ctx, g, xd, Wp, bp, W0, b0, W2, b2, Wf, bf, Wh, bh, WpT=None, WfT=None):
         g = _contig(g)
         M, F0 = g.shape
         F, C = Wp.shape[0], Wh.shape[0]
         demo = xd is not None
-        WpT = _empty(g, F0, F)
-        _call("ecg_transpose", _f32(_contig(Wp)), _f32(WpT), F, F0, _st())
+        if WpT is None:
+            WpT = _empty(g, F0, F)
+            _call("ecg_transpose", _f32(_contig(Wp)), _f32(WpT), F, F0, _st())
         z, logits = _empty(g, M, F), _empty(g, M, C)
         D = H1 = H = 0
         xdc = WfT = h1 = h2 = film = zc = None
         if demo:
             xdc = _contig(xd)
             D, H1, H = xdc.shape[1], W0.shape[0], W2.shape[0]
-            WfT = _empty(g, H, 2 * F)
-            _call("ecg_transpose", _f32(_contig(Wf)), _f32(WfT), 2 * F, H, _st())
+            if WfT is None:
+                WfT = _empty(g, H, 2 * F)
+                _call("ecg_transpose", _f32(_contig(Wf)), _f32(WfT), 2 * F, H, _st())
             h1, h2, film, zc = _empty(g, M, H1), _empty(g, M, H), _empty(g, M, 2 * F), _empty(g, M, F)
         _call("ecg_tail_fwd", _f32(g), _f32(xdc), _f32(WpT), _f32(bp), _f32(W0), _f32(b0), _f32(W2),
               _f32(b2), _f32(WfT), _f32(bf), _f32(_contig(Wh)), _f32(bh), _f32(z), _f32(h1), _f32(h2),
@@ -454,16 +501,19 @@ class TailFn(torch.autograd.Function):
         _call("ecg_linear_wgrad_grouped", L.ptr_table(Gs), L.ptr_table(Xs), L.ptr_table(dWs),
               L.ptr_table(dbs), L.int_table([w.shape[0] for w in dWs]),
               L.int_table([w.shape[1] for w in dWs]), len(Gs), M, _st())
-        return dg, dxd, dWp, dbp, dW0, db0, dW2, db2, dWf, dbf, dWh, dbh
+        return dg, dxd, dWp, dbp, dW0, db0, dW2, db2, dWf, dbf, dWh, dbh, None, None
 
 
-def tail(g, x_demo, proj, head, mlp0=None, mlp2=None, film_gen=None):
-    """(logits, z) of the fused tail; x_demo/mlp0/mlp2/film_gen are None for ECGCNN."""
+def tail(g, x_demo, proj, head, mlp0=None, mlp2=None, film_gen=None, transposed=None):
+    """(logits, z) of the fused tail; x_demo/mlp0/mlp2/film_gen are None for ECGCNN.
+    `transposed` = [proj.weight^T (, film_gen.weight^T)] when a WeightPacker already made them."""
+    WpT = transposed[0] if transposed else None
     if x_demo is None:
         return TailFn.apply(g, None, proj.weight, proj.bias, None, None, None, None, None, None,
-                            head.weight, head.bias)
+                            head.weight, head.bias, WpT, None)
+    WfT = transposed[1] if transposed else None
     return TailFn.apply(g, x_demo, proj.weight, proj.bias, mlp0.weight, mlp0.bias, mlp2.weight,
-                        mlp2.bias, film_gen.weight, film_gen.bias, head.weight, head.bias)
+                        mlp2.bias, film_gen.weight, film_gen.bias, head.weight, head.bias, WpT, WfT)
 
 
 def binary_cross_entropy_with_logits(logits, target, running=None, weight=1.0):

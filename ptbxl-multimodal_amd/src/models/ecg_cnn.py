@@ -44,6 +44,29 @@ def make_backbone(in_leads: int) -> nn.Sequential:
     return nn.Sequential(*(ConvBlock(a, b) for a, b in zip(widths, widths[1:])))
 
 
+def fully_fusable(backbone: nn.Sequential, gap: nn.Module, *tail_modules) -> bool:
+    """True when nobody hooks any module of the path and every block is a stock ConvBlock: the whole
+    forward then runs as fused launches with ONE weight-repack launch up front."""
+    blocks = list(backbone)
+    mods = [backbone, gap, *tail_modules]
+    for blk in blocks:
+        if not (isinstance(blk, ConvBlock) and blk._fusable):
+            return False
+        mods += [blk, blk.net, *blk.net]
+    return not hipnn.has_hooks(*mods)
+
+
+def fused_forward(packer, backbone, gap, x, x_demo, proj, head, mlp0=None, mlp2=None, film_gen=None):
+    """(logits, z): 4 fused ConvBlocks (the last one with the global average pool folded in) and
+    the fused tail, with all weight repacking done by one grouped launch."""
+    blocks = list(backbone)
+    linears = [proj] if x_demo is None else [proj, film_gen]
+    packs, transposed = packer.pack([b.net[0] for b in blocks], linears, torch.is_grad_enabled())
+    for i, blk in enumerate(blocks):
+        x = hipF.conv_block(x, blk.net[0], blk.net[1], gap=(i == len(blocks) - 1), packed=packs[i])
+    return hipF.tail(x, x_demo, proj, head, mlp0, mlp2, film_gen, transposed=transposed)
+
+
 def backbone_features(backbone: nn.Sequential, gap: nn.Module, x: torch.Tensor) -> torch.Tensor:
     """`gap(backbone(x)).squeeze(-1)` -> [B, C].  When nobody hooks the containers, the last
     ConvBlock runs with the global average pool folded into its BN+ReLU+pool kernel, so the
@@ -70,9 +93,13 @@ class ECGCNN(nn.Module):
         self.gap = hipnn.HipAdaptiveAvgPool1d(1)
         self.proj = hipnn.HipLinear(BACKBONE_WIDTHS[-1], feat_dim)
         self.head = hipnn.HipLinear(feat_dim, num_labels)
+        self._packer = hipF.WeightPacker()
 
     def forward(self, x: torch.Tensor, return_features: bool = False):
         """x: [B, in_leads, T] -> logits [B, num_labels] (or (logits, z) if return_features)."""
+        if x.dim() == 3 and fully_fusable(self.backbone, self.gap, self.proj, self.head):
+            logits, z = fused_forward(self._packer, self.backbone, self.gap, x, None, self.proj, self.head)
+            return (logits, z) if return_features else logits
         pooled = backbone_features(self.backbone, self.gap, x)
         if not hipnn.has_hooks(self.proj, self.head):
             logits, z = hipF.tail(pooled, None, self.proj, self.head)       # one fused launch

@@ -10,7 +10,8 @@ import torch.nn as nn
 
 from ecg_hip import functional as hipF
 from ecg_hip import nn as hipnn
-from src.models.ecg_cnn import BACKBONE_WIDTHS, ConvBlock, backbone_features, make_backbone  # noqa: F401  (ConvBlock re-exported)
+from src.models.ecg_cnn import (BACKBONE_WIDTHS, ConvBlock, backbone_features, fully_fusable,  # noqa: F401
+                                fused_forward, make_backbone)
 
 
 class ECGBackbone(nn.Module):
@@ -55,9 +56,16 @@ class ECGMultimodal(nn.Module):
         self.demo_encoder = DemoEncoder(demo_dim=demo_dim, hidden_dim=demo_hidden_dim)
         self.film_gen = hipnn.HipLinear(demo_hidden_dim, 2 * feat_dim)
         self.head = hipnn.HipLinear(feat_dim, num_labels)
+        self._packer = hipF.WeightPacker()
 
     def forward(self, x_ecg: torch.Tensor, x_demo: torch.Tensor) -> torch.Tensor:
         enc, bb = self.demo_encoder, self.ecg_backbone
+        if x_ecg.dim() == 3 and fully_fusable(bb.backbone, bb.gap, bb, bb.proj, enc, enc.mlp, *enc.mlp,
+                                              self.film_gen, self.head):
+            # 4 fused blocks + fused tail, one weight-repack launch for the whole model
+            logits, _ = fused_forward(self._packer, bb.backbone, bb.gap, x_ecg, x_demo, bb.proj, self.head,
+                                      enc.mlp[0], enc.mlp[2], self.film_gen)
+            return logits
         if not hipnn.has_hooks(bb, bb.proj, enc, enc.mlp, *enc.mlp, self.film_gen, self.head):
             # proj + demographic MLP + film_gen + FiLM + head: one fused launch
             logits, _ = hipF.tail(bb.features(x_ecg), x_demo, bb.proj, self.head, enc.mlp[0], enc.mlp[2],

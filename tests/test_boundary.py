@@ -90,3 +90,20 @@ def test_metrics_and_seed_helpers():
     set_seed(7); a = torch.rand(3)
     set_seed(7); b = torch.rand(3)
     assert torch.equal(a, b) and torch.backends.cudnn.deterministic and not torch.backends.cudnn.benchmark
+
+
+def test_models_survive_deepcopy_and_pickle_with_pack_cache():
+    """The per-model weight-pack cache holds raw device pointers; copying or pickling a model
+    must drop it instead of failing or aliasing (torch.save(model) / copy.deepcopy(model))."""
+    import copy
+    import pickle
+    from ecg_hip.functional import WeightPacker
+    from src.models.ecg_multimodal import ECGMultimodal
+    m = ECGMultimodal()
+    m._packer._key = ("stale",)
+    m._packer._tables = object()          # stands in for the ctypes pointer tables
+    m2 = copy.deepcopy(m)
+    assert isinstance(m2._packer, WeightPacker) and m2._packer._key is None
+    m3 = pickle.loads(pickle.dumps(m))
+    assert m3._packer._key is None
+    assert list(m3.state_dict()) == list(m.state_dict())

@@ -340,3 +340,43 @@ def test_conv_block_with_fused_gap(hip, oracle):
     np.testing.assert_allclose(host(ws.grad), dw, atol=1e-4)
     np.testing.assert_allclose(host(xs.grad), oracle.conv1d_bwd_data(dy, w, Lin, 7), atol=1e-4)
     assert int(nbt.item()) == 1
+
+
+def test_grouped_pack_matches_single_packs(hip):
+    """ecg_pack_weights_grouped == per-layer ecg_conv1d_pack_weights + ecg_transpose, bit for bit."""
+    from ecg_hip import _lib as L
+    torch.manual_seed(3)
+    convs = [torch.nn.Conv1d(12, 32, 15), torch.nn.Conv1d(32, 64, 15), torch.nn.Conv1d(7, 5, 3)]
+    lins = [torch.nn.Linear(256, 256), torch.nn.Linear(64, 512)]
+    for m in convs + lins:
+        m.cuda()
+    packs, trans = hip.WeightPacker().pack(convs, lins, need_bwd=True)
+    for i, c in enumerate(convs):
+        wf, wb = hip.conv1d_pack(c.weight.detach())
+        assert torch.equal(packs[i][0], wf)
+        if i == 0:
+            assert packs[i][1] is None          # block 0 never needs the input-grad operand
+        else:
+            assert torch.equal(packs[i][1], wb)
+    for l, t in zip(lins, trans):
+        assert torch.equal(t, l.weight.detach().t().contiguous())
+
+
+def test_return_features_and_feature_gradient(hip, oracle):
+    """ECGCNN(return_features=True): z is a differentiable output of the fused tail."""
+    from src.models.ecg_cnn import ECGCNN
+    from src.utils.seed import set_seed
+    from oracle import ref_models as R
+    set_seed(5)
+    m = ECGCNN(num_labels=5).cuda().train()
+    R.seed_all(5)
+    ref = R.RefECGCNN(num_labels=5).train()
+    x = torch.randn(3, 12, 200)
+    logits, z = m(x.cuda(), return_features=True)
+    rl, rz = ref(x, return_features=True)
+    np.testing.assert_allclose(host(z), rz.detach().numpy(), atol=1e-4)
+    (logits.sum() + (z * z).sum()).backward()
+    (rl.sum() + (rz * rz).sum()).backward()
+    for (k, a), (_, b) in zip(m.named_parameters(), ref.named_parameters()):
+        tol = 1e-5 if ".net.0.bias" in k else 2e-4 * max(1.0, float(b.grad.abs().max()))
+        np.testing.assert_allclose(host(a.grad), b.grad.numpy(), atol=tol, err_msg=k)
