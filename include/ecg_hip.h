@@ -130,6 +130,17 @@ int ecg_bn_relu_pool_bwd(const float *y, const float *dp, const float *gamma, co
                          float *dy, float *dgamma, float *dbeta, float *ws,
                          int N, int C, int L, int train, ecg_stream_t stream);
 
+/* Inference: a whole ConvBlock in ONE launch — Conv1d, eval-mode BatchNorm1d (running statistics)
+ * folded into the epilogue, ReLU and MaxPool1d(2); only the pooled activation p [N][C_out][Lo/2]
+ * is written (reference test path scripts/06_ecg_baseline_test.py:69-106).  Covered shapes:
+ * ecg_conv1d_bn_relu_pool_eval_supported() != 0 (K = 15, C_in % 4 == 0, C_out % 32 == 0). */
+int ecg_conv1d_bn_relu_pool_eval_supported(int C_in, int C_out, int K, int pad);
+int ecg_conv1d_bn_relu_pool_eval_fwd(const float *x, const float *w_fwd, const float *bias,
+                                     const float *gamma, const float *beta,
+                                     const float *running_mean, const float *running_var,
+                                     float eps, float *p, int N, int C_in, int C_out, int L,
+                                     int K, int pad, ecg_stream_t stream);
+
 /* Last block of the backbone fused with AdaptiveAvgPool1d(1) (src/models/ecg_cnn.py:46,62):
  * g[n,c] = mean_j max(0, max(a[2j], a[2j+1])) — the pooled tensor is never materialised.
  * Backward takes dg [N][C] (gradient of g); same workspace as ecg_bn_relu_pool_bwd. */

@@ -19,6 +19,9 @@ bool mfma_fwd_supported(int Cin, int Cout, int K, int pad);
 int mfma_fwd_stat_partials(int N, int Cin, int Cout, int Lo);
 int mfma_fwd(const float *x, const float *wp, const float *bias, float *y, float *partials, int N,
              int Cin, int Cout, int L, int K, int pad, hipStream_t st);
+int mfma_fwd_eval_pool(const float *x, const float *wp, const float *bias, const float *gamma,
+                       const float *beta, const float *mean, const float *var, float eps, float *p,
+                       int N, int Cin, int Cout, int L, int K, int pad, hipStream_t st);
 bool mfma_wgrad_supported(int Cin, int Cout, int K, int pad);
 size_t mfma_wgrad_ws_floats(int N, int Cin, int Cout, int L, int K);
 int mfma_wgrad(const float *dy, const float *x, float *dw, float *db, float *ws, int N, int Cin,
@@ -101,4 +104,27 @@ ECG_API int ecg_conv1d_bwd_weight_bias(const float *dy, const float *x, float *d
     if (mfma_wgrad_supported(C_in, C_out, K, pad))
         return mfma_wgrad(dy, x, dw, db, ws, N, C_in, C_out, L, K, pad, as_stream(stream));
     return direct_wgrad(dy, x, dw, db, ws, N, C_in, C_out, L, K, pad, as_stream(stream));
+}
+
+ECG_API int ecg_conv1d_bn_relu_pool_eval_supported(int C_in, int C_out, int K, int pad) {
+    return mfma_fwd_supported(C_in, C_out, K, pad) ? 1 : 0;
+}
+
+ECG_API int ecg_conv1d_bn_relu_pool_eval_fwd(const float *x, const float *w_fwd, const float *bias,
+                                             const float *gamma, const float *beta,
+                                             const float *running_mean, const float *running_var,
+                                             float eps, float *p, int N, int C_in, int C_out, int L,
+                                             int K, int pad, ecg_stream_t stream) {
+    int rc = check_conv_shape(N, C_in, C_out, L, K, pad);
+    if (rc) return rc;
+    ECG_REQUIRE(x && w_fwd && gamma && beta && running_mean && running_var,
+                "conv1d_bn_relu_pool_eval_fwd: null pointer");
+    ECG_REQUIRE(mfma_fwd_supported(C_in, C_out, K, pad),
+                "conv1d_bn_relu_pool_eval_fwd: shape not covered by the fused kernel "
+                "(query ecg_conv1d_bn_relu_pool_eval_supported and use the unfused sequence)");
+    const int Lo = L + 2 * pad - K + 1;
+    if (Lo / 2 == 0) return ECG_OK;
+    ECG_REQUIRE(p, "conv1d_bn_relu_pool_eval_fwd: null output");
+    return mfma_fwd_eval_pool(x, w_fwd, bias, gamma, beta, running_mean, running_var, eps, p, N,
+                              C_in, C_out, L, K, pad, as_stream(stream));
 }

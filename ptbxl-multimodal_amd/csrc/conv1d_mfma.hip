@@ -51,11 +51,18 @@ __device__ __forceinline__ int acc_row(int r, int half) { return (r & 3) + 8 * (
 //   uniform base pointer.
 // Loads are UNCONDITIONAL (clamped addresses, zeroing by mask): a load that is only used under
 // a condition gets sunk into a branch by hipcc and followed by s_waitcnt vmcnt(0).
-template <int CO_T, int T_T, int WCO, int WT, bool STATS>
+// Epilogue modes: EPI_PLAIN stores y; EPI_STATS also emits the train-mode BN (sum, sum^2)
+// partials; EPI_EVAL folds the eval-mode BatchNorm affine, ReLU and MaxPool1d(2) into the store —
+// the inference path writes only the pooled activation (one launch per ConvBlock).
+enum { EPI_PLAIN = 0, EPI_STATS = 1, EPI_EVAL = 2 };
+struct EvalEpi { const float *gamma, *beta, *mean, *var; float eps; };
+
+template <int CO_T, int T_T, int WCO, int WT, int EPI>
 __global__ __launch_bounds__(256, 2) void conv1d_mfma_fwd_kernel(
     const float *__restrict__ x, const float *__restrict__ wp, const float *__restrict__ bias,
     float *__restrict__ y, float *__restrict__ partials, int Cin, int Cout, int L, int Lo, int pad,
-    int P) {
+    int P, EvalEpi ev) {
+    constexpr bool STATS = (EPI == EPI_STATS);
     static_assert(WCO * WT == 4, "4 waves per workgroup");
     constexpr int KK = kKM, CI_C = 4, NST = KK * CI_C / 2;
     constexpr int MC = CO_T / WCO / 32, MT = T_T / WT / 32;
@@ -192,13 +199,30 @@ __global__ __launch_bounds__(256, 2) void conv1d_mfma_fwd_kernel(
             const int col = wco + 32 * i + acc_row(r, half);    // channel inside the CO_T tile
             const float bv = bias ? bias[co0 + col] : 0.f;
             float s = 0.f, q = 0.f;
+            if (EPI == EPI_EVAL) {
+                // p[j] = max(0, max(a[2j], a[2j+1])), a = (v - mean) * (invstd * gamma) + beta.  The two
+                // samples of a pooling pair sit on adjacent lanes: one DPP quad_perm fetches the partner.
+                const int ch = co0 + col;
+                const float is = (float)(1.0 / sqrt((double)ev.var[ch] + (double)ev.eps));
+                const float sc = is * ev.gamma[ch], mu = ev.mean[ch], be = ev.beta[ch];
+                const int Lp = Lo >> 1;
 #pragma unroll
-            for (int j = 0; j < MT; ++j) {
-                const int t = t0 + wt + 32 * j + l31;
-                const float v = acc[i][j][r] + bv;
-                if (t < Lo) {
-                    y[((size_t)n * Cout + co0 + col) * Lo + t] = v;
-                    if (STATS) { s += v; q = __fmaf_rn(v, v, q); }
+                for (int j = 0; j < MT; ++j) {
+                    const int t = t0 + wt + 32 * j + l31;
+                    const float a = bn_apply1(acc[i][j][r] + bv, mu, sc, be);
+                    const float o = dpp_move<0xB1>(a);                 // lane ^ 1
+                    const float m = fmaxf(fmaxf(a, o), 0.f);
+                    if (!(l31 & 1) && (t >> 1) < Lp) y[((size_t)n * Cout + ch) * Lp + (t >> 1)] = m;
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < MT; ++j) {
+                    const int t = t0 + wt + 32 * j + l31;
+                    const float v = acc[i][j][r] + bv;
+                    if (t < Lo) {
+                        y[((size_t)n * Cout + co0 + col) * Lo + t] = v;
+                        if (STATS) { s += v; q = __fmaf_rn(v, v, q); }
+                    }
                 }
             }
             if (STATS) {
@@ -250,27 +274,43 @@ int mfma_fwd_stat_partials(int N, int Cin, int Cout, int Lo) {
 
 template <int CO_T, int T_T, int WCO, int WT>
 static void launch_fwd(const float *x, const float *wp, const float *bias, float *y,
-                       float *partials, int N, int Cin, int Cout, int L, int Lo, int pad,
-                       hipStream_t st) {
+                       float *partials, const EvalEpi *ev, int N, int Cin, int Cout, int L, int Lo,
+                       int pad, hipStream_t st) {
     dim3 grid(cdiv(Lo, T_T), Cout / CO_T, N), block(256);
     const int P = N * (int)grid.x;
-    if (partials)
-        hipLaunchKernelGGL((conv1d_mfma_fwd_kernel<CO_T, T_T, WCO, WT, true>), grid, block, 0, st, x,
-                           wp, bias, y, partials, Cin, Cout, L, Lo, pad, P);
+    const EvalEpi none{nullptr, nullptr, nullptr, nullptr, 0.f};
+#define ECG_FWD(MODE, EV) \
+    hipLaunchKernelGGL((conv1d_mfma_fwd_kernel<CO_T, T_T, WCO, WT, MODE>), grid, block, 0, st, x, wp, \
+                       bias, y, partials, Cin, Cout, L, Lo, pad, P, EV)
+    if (ev) ECG_FWD(EPI_EVAL, *ev);
+    else if (partials) ECG_FWD(EPI_STATS, none);
+    else ECG_FWD(EPI_PLAIN, none);
+#undef ECG_FWD
+}
+
+static int mfma_fwd_any(const float *x, const float *wp, const float *bias, float *y,
+                        float *partials, const EvalEpi *ev, int N, int Cin, int Cout, int L, int K,
+                        int pad, hipStream_t st) {
+    const int Lo = L + 2 * pad - K + 1;
+    const FwdCfg c = fwd_cfg(N, Cout, Lo);
+    if (c.co_t == 64)
+        launch_fwd<64, 128, 2, 2>(x, wp, bias, y, partials, ev, N, Cin, Cout, L, Lo, pad, st);
     else
-        hipLaunchKernelGGL((conv1d_mfma_fwd_kernel<CO_T, T_T, WCO, WT, false>), grid, block, 0, st, x,
-                           wp, bias, y, partials, Cin, Cout, L, Lo, pad, P);
+        launch_fwd<32, 256, 1, 4>(x, wp, bias, y, partials, ev, N, Cin, Cout, L, Lo, pad, st);
+    return check_launch("conv1d_mfma_fwd_kernel");
 }
 
 int mfma_fwd(const float *x, const float *wp, const float *bias, float *y, float *partials, int N,
              int Cin, int Cout, int L, int K, int pad, hipStream_t st) {
-    const int Lo = L + 2 * pad - K + 1;
-    const FwdCfg c = fwd_cfg(N, Cout, Lo);
-    if (c.co_t == 64)
-        launch_fwd<64, 128, 2, 2>(x, wp, bias, y, partials, N, Cin, Cout, L, Lo, pad, st);
-    else
-        launch_fwd<32, 256, 1, 4>(x, wp, bias, y, partials, N, Cin, Cout, L, Lo, pad, st);
-    return check_launch("conv1d_mfma_fwd_kernel");
+    return mfma_fwd_any(x, wp, bias, y, partials, nullptr, N, Cin, Cout, L, K, pad, st);
+}
+
+// eval-mode ConvBlock in one launch: p = MaxPool2(ReLU(BN_running(conv(x))))
+int mfma_fwd_eval_pool(const float *x, const float *wp, const float *bias, const float *gamma,
+                       const float *beta, const float *mean, const float *var, float eps, float *p,
+                       int N, int Cin, int Cout, int L, int K, int pad, hipStream_t st) {
+    const EvalEpi ev{gamma, beta, mean, var, eps};
+    return mfma_fwd_any(x, wp, bias, p, nullptr, &ev, N, Cin, Cout, L, K, pad, st);
 }
 
 // =======================================================================================

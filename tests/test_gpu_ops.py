@@ -380,3 +380,28 @@ def test_return_features_and_feature_gradient(hip, oracle):
     for (k, a), (_, b) in zip(m.named_parameters(), ref.named_parameters()):
         tol = 1e-5 if ".net.0.bias" in k else 2e-4 * max(1.0, float(b.grad.abs().max()))
         np.testing.assert_allclose(host(a.grad), b.grad.numpy(), atol=tol, err_msg=k)
+
+
+@pytest.mark.parametrize("shape", [(3, 12, 32, 300), (2, 32, 64, 257), (2, 64, 128, 125), (1, 128, 256, 33)])
+def test_eval_fused_conv_bn_relu_pool(hip, oracle, shape):
+    """Inference ConvBlock in one launch (BN folded into the conv epilogue) vs the oracle sequence."""
+    from ecg_hip import _lib as L
+    N, Ci, Co, Lin = shape
+    rng = np.random.default_rng(Ci + Lin)
+    x = rng.standard_normal((N, Ci, Lin)).astype(np.float32)
+    w = (rng.standard_normal((Co, Ci, 15)) / np.sqrt(Ci * 15)).astype(np.float32)
+    b = rng.standard_normal(Co).astype(np.float32)
+    gamma = (1 + 0.2 * rng.standard_normal(Co)).astype(np.float32)
+    beta = (0.2 * rng.standard_normal(Co)).astype(np.float32)
+    rmean = (0.3 * rng.standard_normal(Co)).astype(np.float32)
+    rvar = rng.uniform(0.5, 2.0, Co).astype(np.float32)
+    assert L.query("ecg_conv1d_bn_relu_pool_eval_supported", Ci, Co, 15, 7) == 1
+    w_fwd, _ = hip.conv1d_pack(dev(w), need_bwd=False)
+    p = torch.empty(N, Co, Lin // 2, device="cuda")
+    L.call("ecg_conv1d_bn_relu_pool_eval_fwd", *map(L.f32, (dev(x), w_fwd, dev(b), dev(gamma), dev(beta), dev(rmean), dev(rvar))),
+           1e-5, L.f32(p), N, Ci, Co, Lin, 15, 7, L.stream())
+    y = oracle.conv1d_fwd(x, w, b, 7)
+    invstd = (1.0 / np.sqrt(rvar.astype(np.float64) + 1e-5)).astype(np.float32)
+    rp = oracle.bn_relu_pool_fwd(y, gamma, beta, rmean, invstd)
+    np.testing.assert_allclose(host(p), rp, atol=3e-5)
+    assert L.query("ecg_conv1d_bn_relu_pool_eval_supported", 7, 5, 3, 1) == 0
