@@ -107,3 +107,14 @@ def test_models_survive_deepcopy_and_pickle_with_pack_cache():
     m3 = pickle.loads(pickle.dumps(m))
     assert m3._packer._key is None
     assert list(m3.state_dict()) == list(m.state_dict())
+
+
+def test_legacy_concat_model_matches_committed_checkpoint_layout():
+    """§8(f)-4: ECGDemoConcat reproduces key names / shapes / dtypes of outputs/ecg_demo/ckpts/
+    ecg_demo_best.pth (captured in g7_concat_ckpt_shapes.npz), i.e. it would load strict=True."""
+    from src.models.ecg_demo_concat import ECGDemoConcat
+    g = golden("g7_concat_ckpt_shapes")
+    sd = ECGDemoConcat().state_dict()
+    assert list(sd) == [str(k) for k in g["keys"]]
+    for (k, v), shp, dt in zip(sd.items(), g["shapes"], g["dtypes"]):
+        assert str(tuple(v.shape)) == str(shp) and str(v.dtype) == str(dt), k
