@@ -5,8 +5,14 @@ launch over one flat fp32 buffer (ecg_adamw_step), instead of 20-28 per-tensor u
 On construction the parameters are re-pointed as views into a single contiguous buffer
 (values unchanged, so state_dicts and checkpoints are unaffected).  `step()` gathers the
 per-parameter gradients into a flat gradient with one concatenation, optionally all-reduces
-it over a process group (the data-parallel exchange of SURVEY §8e: one RCCL collective per
-step on 3 MB) and applies the update; averaging by 1/world is folded into the kernel.
+it over a process group (the data-parallel exchange of SURVEY §8e: RCCL all-reduce of 3 MB per
+step) and applies the update; averaging by 1/world is folded into the kernel.
+
+With a process group the exchange is split in two buckets so that it hides under backward:
+parameters are in forward order, gradients arrive in reverse, so as soon as every gradient of the
+"late" bucket (everything after the first `early_params` tensors — blocks 2-3 and the tail, 95 %
+of the bytes) has been accumulated, it is gathered and all-reduced asynchronously while the
+backward pass of blocks 1 and 0 is still running; step() only exposes the small early bucket.
 """
 import torch
 
@@ -34,7 +40,7 @@ def flatten_tensors_(tensors):
 
 class FlatAdamW(torch.optim.Optimizer):
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2,
-                 process_group=None, world_size=None):
+                 process_group=None, world_size=None, overlap=True, early_params=8):
         defaults = dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)
         super().__init__(params, defaults)
         if len(self.param_groups) != 1:
@@ -56,19 +62,51 @@ class FlatAdamW(torch.optim.Optimizer):
                                              and torch.distributed.is_initialized()):
                 world_size = torch.distributed.get_world_size(process_group)
         self.world_size = world_size
+        # ---- bucketed, backward-overlapped exchange (world > 1 only) -------------------------
+        self._n_early = min(max(int(early_params), 0), len(self._params))
+        self._split = sum(p.numel() for p in self._params[:self._n_early])      # flat offset of the late bucket
+        self._late_pending = 0
+        self._late_work = None
+        self._overlap = bool(overlap) and world_size > 1 and 0 < self._n_early < len(self._params)
+        if self._overlap:
+            self._late_total = len(self._params) - self._n_early
+            for p in self._params[self._n_early:]:
+                p.register_post_accumulate_grad_hook(self._on_late_grad)
 
-    def _gather_grads(self):
-        parts = []
-        for p in self._params:
-            g = p.grad
-            parts.append(torch.zeros_like(p).view(-1) if g is None else g.reshape(-1))
-        return torch.cat(parts)
+    @staticmethod
+    def _flat(p):
+        g = p.grad
+        return torch.zeros_like(p).view(-1) if g is None else g.reshape(-1)
+
+    def _on_late_grad(self, _param):
+        """Autograd hook: when the last gradient of the late bucket lands, gather that bucket into
+        the flat gradient and start its all-reduce; backward of the early blocks keeps running."""
+        self._late_pending += 1
+        if self._late_pending < self._late_total:
+            return
+        self._late_pending = 0
+        with torch.no_grad():
+            if self.flat_grad is None or self.flat_grad.numel() != self.flat_param.numel():
+                self.flat_grad = torch.empty_like(self.flat_param)
+            late = self.flat_grad[self._split:]
+            torch.cat([self._flat(p) for p in self._params[self._n_early:]], out=late)
+            self._late_work = torch.distributed.all_reduce(late, group=self.process_group, async_op=True)
 
     @torch.no_grad()
     def reduce_gradients(self):
-        """Flat gradient of this step, summed over ranks by ONE all-reduce; returns (flat, scale)
-        where scale = 1/world is applied inside the AdamW kernel."""
-        self.flat_grad = g = self._gather_grads()
+        """Flat gradient of this step, summed over ranks; returns (flat, scale) where
+        scale = 1/world is applied inside the AdamW kernel.  One all-reduce, or two buckets when the
+        late bucket was already launched from the backward hooks."""
+        if self._late_work is not None:                       # late bucket is in flight / done
+            g = self.flat_grad
+            early = g[:self._split]
+            torch.cat([self._flat(p) for p in self._params[:self._n_early]], out=early)
+            torch.distributed.all_reduce(early, group=self.process_group)
+            self._late_work.wait()
+            self._late_work = None
+            return g, 1.0 / self.world_size
+        self._late_pending = 0
+        self.flat_grad = g = torch.cat([self._flat(p) for p in self._params])
         if self.world_size > 1:
             torch.distributed.all_reduce(g, group=self.process_group)
             return g, 1.0 / self.world_size

@@ -98,7 +98,7 @@ def _worker_flat(rank, world, port, out_dir):
     torch.manual_seed(0)
     lin = torch.nn.Sequential(torch.nn.Linear(7, 5), torch.nn.Linear(5, 3))
     before = [p.detach().clone() for p in lin.parameters()]
-    opt = FlatAdamW(lin.parameters(), lr=1e-3, weight_decay=1e-4)      # single-bucket flat storage
+    opt = FlatAdamW(lin.parameters(), lr=1e-3, weight_decay=1e-4, overlap=False)   # single bucket
     assert opt.world_size == 2 and opt.flat_param.numel() == sum(p.numel() for p in lin.parameters())
     for p, b in zip(lin.parameters(), before):
         assert torch.equal(p, b) and p.data_ptr() >= opt.flat_param.data_ptr()   # values kept, storage shared
@@ -119,6 +119,40 @@ def _worker_flat(rank, world, port, out_dir):
     assert a.flatten().tolist() == list(range(rank * 4, rank * 4 + 4))
     dist.barrier()
     dist.destroy_process_group()
+
+
+def _worker_overlap(rank, world, port, out_dir):
+    """Bucketed exchange launched from backward hooks == single flat all-reduce (world 2)."""
+    _setup(rank, world, port)
+    from ecg_hip.optim import FlatAdamW
+    from oracle import ref_models as R
+    R.seed_all(42)
+    model = R.RefECGMultimodal().train()
+    opt = FlatAdamW(model.parameters(), lr=1e-4, weight_decay=1e-4)            # overlap on, early bucket = 8 tensors
+    assert opt._overlap and opt._n_early == 8
+    assert opt._split == sum(p.numel() for p in list(model.parameters())[:8])
+    batch = R.synthetic_batch(8, 256, 5, gen_seed=100 + rank, demo=True)
+    for it in range(2):                                                        # two steps: state resets correctly
+        opt.zero_grad()
+        loss = torch.nn.functional.binary_cross_entropy_with_logits(model(*batch[:-1]), batch[-1])
+        loss.backward()
+        assert opt._late_work is not None                                      # launched during backward
+        local = torch.cat([p.grad.reshape(-1) for p in model.parameters()]).clone()
+        flat, scale = opt.reduce_gradients()
+        assert scale == 0.5 and opt._late_work is None
+        both = [torch.empty_like(local) for _ in range(world)]
+        dist.all_gather(both, local)
+        assert torch.allclose(flat, both[0] + both[1], rtol=0, atol=0)
+    # overlap=False gives the same flat gradient through one collective
+    opt2 = FlatAdamW(model.parameters(), lr=1e-4, overlap=False)
+    assert not opt2._overlap
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_bucketed_overlap_exchange_world2(tmp_path):
+    world, port = 2, _free_port()
+    mp.spawn(_worker_overlap, args=(world, port, str(tmp_path)), nprocs=world, join=True)
 
 
 def test_flat_optimizer_exchange_world2(tmp_path):
