@@ -95,6 +95,24 @@ int ecg_conv1d_bwd_weight_bias(const float *dy, const float *x, float *dw, float
                                int N, int C_in, int C_out, int L, int K, int pad,
                                ecg_stream_t stream);
 
+/* ---- mixed precision (opt-in; BASELINE.json config 5: AF binary 12x5000, bf16) ----------------
+ * Forward and input-grad with bf16 operands on the matrix cores (fp32 accumulate, fp32
+ * activations in HBM); the weight gradient stays on ecg_conv1d_bwd_weight_bias (fp32).
+ * Packed weights are bf16: wb_fwd [ceil(C_in/16)][K][C_out][16], wb_bwd [ceil(C_out/16)][K][C_in][16]
+ * (tap-flipped), ecg_conv1d_bf16_packed_elems(C_reduce, C_result, K) 2-byte elements each.
+ * K must be 15; forward needs C_in % 4 == 0 and C_out % 32 == 0, the input-grad the same with the
+ * roles swapped.  ecg_conv1d_bf16_supported returns a bit mask: 1 = forward, 2 = input-grad. */
+int ecg_conv1d_bf16_supported(int C_in, int C_out, int K, int pad);
+size_t ecg_conv1d_bf16_packed_elems(int C_reduce, int C_result, int K);
+int ecg_conv1d_pack_weights_bf16(const float *w, void *wb_fwd, void *wb_bwd, int C_out, int C_in,
+                                 int K, ecg_stream_t stream);
+int ecg_conv1d_fwd_bf16_stat_partials(int N, int C_in, int C_out, int L, int K, int pad);
+int ecg_conv1d_fwd_bf16(const float *x, const void *wb_fwd, const float *bias, float *y,
+                        float *stat_partials, int N, int C_in, int C_out, int L, int K, int pad,
+                        ecg_stream_t stream);
+int ecg_conv1d_bwd_data_bf16(const float *dy, const void *wb_bwd, float *dx, int N, int C_in,
+                             int C_out, int L, int K, int pad, ecg_stream_t stream);
+
 /* ------------------------------------------------------------------------------------
  * BatchNorm1d / ReLU / MaxPool1d(2) — ConvBlock.net[1..3]: src/models/ecg_cnn.py:14-16.
  * ---------------------------------------------------------------------------------- */

@@ -1,0 +1,335 @@
+// conv1d_mfma_bf16.hip — mixed-precision Conv1d forward / input-grad: bf16 operands on the
+// gfx950 matrix cores (v_mfma_f32_32x32x16_bf16, fp32 accumulate), fp32 activations in HBM.
+// This is the opt-in path of BASELINE.json config 5 ("AF binary, 12x5000, bf16 mixed precision");
+// the fp32 MFMA kernels of conv1d_mfma.hip remain the default and the parity path.  The weight
+// gradient stays on the fp32 kernels (weight gradients are kept in full precision).
+//
+// Same im2col-free structure as the fp32 kernel, with a 16-channel reduction block per MFMA:
+//   D[co][t] += sum_{ci in chunk of 16} W[tap][co][ci] * X[t + tap][ci]       (one MFMA per tap)
+//   MFMA A = weight fragment: lane (co = l&31, h = l>>5) holds ci 8h..8h+7  -> LDS [tap][co][16]
+//   MFMA B = x fragment:      lane (t  = l&31, h)       holds ci 8h..8h+7  -> LDS [pos][16]
+// so both fragments are single 16-byte LDS reads.  Weights are pre-packed to bf16 in that order
+// ([chunk][tap][C_out][16]) and stream global -> LDS by DMA; the x tile is converted fp32 -> bf16
+// (round to nearest even) while it is staged, with its zero padding applied by AND masks.
+//
+// Replaces the ATen work behind ConvBlock.net[0] (reference src/models/ecg_cnn.py:13); the
+// reference itself has no mixed precision (`amp: true` in its YAML is a dead key).
+#include "common.h"
+
+namespace ecg {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned short u16;
+
+constexpr int kKB = 15;      // kernel size staged by this path
+constexpr int kCB = 16;      // input channels per MFMA (its K dimension)
+
+__device__ __forceinline__ int acc_row_b(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }
+
+__device__ __forceinline__ unsigned pack2_bf16(float lo, float hi) {
+    const u16 a = __builtin_bit_cast(u16, (__bf16)lo), b = __builtin_bit_cast(u16, (__bf16)hi);
+    return (unsigned)a | ((unsigned)b << 16);
+}
+
+// w [Co][Ci][K] fp32 -> wb_fwd [ceil(Ci/16)][K][Co][16] and wb_bwd [ceil(Co/16)][K][Ci][16]
+// (tap-flipped, roles of the channel axes swapped), zero-filled past the channel count.
+__global__ void pack_weights_bf16_kernel(const float *__restrict__ w, u16 *__restrict__ wb_fwd,
+                                         u16 *__restrict__ wb_bwd, int Co, int Ci, int K) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    const int nf = ((Ci + kCB - 1) / kCB) * K * Co * kCB;
+    const int nb = ((Co + kCB - 1) / kCB) * K * Ci * kCB;
+    if (wb_fwd && idx < nf) {
+        const int j = idx % kCB, co = (idx / kCB) % Co, k = (idx / (kCB * Co)) % K, c = idx / (kCB * Co * K);
+        const int ci = c * kCB + j;
+        const float v = ci < Ci ? w[((size_t)co * Ci + ci) * K + k] : 0.f;
+        wb_fwd[idx] = __builtin_bit_cast(u16, (__bf16)v);
+    }
+    if (wb_bwd && idx < nb) {
+        const int j = idx % kCB, ci = (idx / kCB) % Ci, k = (idx / (kCB * Ci)) % K, c = idx / (kCB * Ci * K);
+        const int co = c * kCB + j;
+        const float v = co < Co ? w[((size_t)co * Ci + ci) * K + (K - 1 - k)] : 0.f;
+        wb_bwd[idx] = __builtin_bit_cast(u16, (__bf16)v);
+    }
+}
+
+// grid = (ceil(Lo/T_T), Cout/CO_T, N); 256 threads = 4 waves laid out WCO x WT.
+template <int CO_T, int T_T, int WCO, int WT, bool STATS>
+__global__ __launch_bounds__(256, 2) void conv1d_mfma_bf16_fwd_kernel(
+    const float *__restrict__ x, const u16 *__restrict__ wb, const float *__restrict__ bias,
+    float *__restrict__ y, float *__restrict__ partials, int Cin, int Cout, int L, int Lo, int pad,
+    int P) {
+    static_assert(WCO * WT == 4, "4 waves per workgroup");
+    constexpr int KK = kKB;
+    constexpr int MC = CO_T / WCO / 32, MT = T_T / WT / 32;
+    static_assert(MC >= 1 && MT >= 1, "wave tile must hold at least one 32x32 accumulator");
+    constexpr int SPAN = T_T + KK - 1;                   // x-tile positions
+    constexpr int WBYTES = KK * CO_T * kCB * 2;          // bytes of one weight chunk [K][CO_T][16] bf16
+    constexpr int NDMA = (WBYTES + 1023) / 1024;         // 1 KB wave-instructions per chunk
+    constexpr int WPADB = NDMA * 1024;
+    constexpr int DPW = (NDMA + 3) / 4;
+    constexpr int XBYTES = SPAN * kCB * 2;
+    constexpr int IMGB = WPADB + ((XBYTES + 15) / 16) * 16;
+    constexpr int XITEMS = SPAN * 4;                     // (pos, quarter of 4 channels)
+    constexpr int XL = (XITEMS + 255) / 256;
+    constexpr int NOPS = XL + DPW + XL;                  // commits, DMA pieces, loads
+    static_assert(NOPS <= KK, "not enough steps to spread the staging over");
+    constexpr int REDB = STATS ? 4 * (CO_T / WCO) * 2 * 4 : 0;
+    static_assert(REDB <= IMGB, "stat scratch aliases image 0");
+
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[2 * IMGB];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int half = lane >> 5, l31 = lane & 31;
+    const int t0 = blockIdx.x * T_T, co0 = blockIdx.y * CO_T, n = blockIdx.z;
+    const int wco = (wave / WT) * (CO_T / WCO), wt = (wave % WT) * (T_T / WT);
+    const float *xn = x + (size_t)n * Cin * L;
+    const int nchunks = (Cin + kCB - 1) / kCB;
+
+    f32x16 acc[MC][MT];
+#pragma unroll
+    for (int a = 0; a < MC; ++a)
+#pragma unroll
+        for (int b = 0; b < MT; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    // ---- loop-invariant staging geometry ---------------------------------------------------
+    // weight piece j of this wave: byte offset inside a chunk [K][Cout][16] bf16 -> (k, co, lane part)
+    size_t woff[DPW];
+#pragma unroll
+    for (int j = 0; j < DPW; ++j) {
+        const int e = min(((j * 4 + wave) * 64 + lane) * 16, WBYTES - 16);   // byte in the LDS image
+        const int k = e / (CO_T * kCB * 2), rem = e - k * (CO_T * kCB * 2);  // rem = co_local*32 + part
+        woff[j] = ((size_t)k * Cout + co0) * kCB * 2 + rem;                   // byte offset in the global chunk
+    }
+    int xpos[XL], xq[XL], xsrc[XL];
+    unsigned xin = 0;                 // bit j: position inside the sequence
+#pragma unroll
+    for (int j = 0; j < XL; ++j) {
+        const int it = min(tid + 256 * j, XITEMS - 1);
+        xq[j] = it / SPAN;
+        xpos[j] = it - xq[j] * SPAN;
+        const int s = t0 - pad + xpos[j];
+        xsrc[j] = min(max(s, 0), L - 1);
+        xin |= ((s >= 0) && (s < L)) ? (1u << j) : 0u;
+    }
+    float xreg[XL][4];
+    unsigned xok = 0;                 // bit j: item j of the chunk in registers is real data
+
+    const unsigned char *wbase = reinterpret_cast<const unsigned char *>(wb);
+    const size_t chunk_bytes = (size_t)KK * Cout * kCB * 2;
+    auto dma_w = [&](int j, int c, unsigned char *img) {
+        if ((j * 4 + wave) < NDMA)
+            __builtin_amdgcn_global_load_lds(
+                (const __attribute__((address_space(1))) void *)(wbase + (size_t)c * chunk_bytes + woff[j]),
+                (__attribute__((address_space(3))) void *)(img + (j * 4 + wave) * 1024), 16, 0, 0);
+    };
+    auto load_x = [&](int j, int c) {
+        const int ci = c * kCB + 4 * xq[j];
+        unsigned ok = (xin >> j) & 1u;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) xreg[j][u] = xn[(size_t)min(ci + u, Cin - 1) * L + xsrc[j]];
+        ok &= (ci < Cin) ? 1u : 0u;                      // Cin % 4 == 0: a quarter is all valid or all padding
+        xok = (xok & ~(1u << j)) | (ok << j);
+    };
+    auto commit_x = [&](int j, unsigned char *img) {
+        const unsigned keep = 0u - ((xok >> j) & 1u);
+        const unsigned lo = pack2_bf16(xreg[j][0], xreg[j][1]) & keep;
+        const unsigned hi = pack2_bf16(xreg[j][2], xreg[j][3]) & keep;
+        if (256 * (j + 1) <= XITEMS || tid + 256 * j < XITEMS)
+            *reinterpret_cast<uint2 *>(img + WPADB + (xpos[j] * kCB + 4 * xq[j]) * 2) = make_uint2(lo, hi);
+    };
+
+    // prologue: chunk 0 -> image 0; x of chunk 1 -> registers
+#pragma unroll
+    for (int j = 0; j < DPW; ++j) dma_w(j, 0, lds);
+#pragma unroll
+    for (int j = 0; j < XL; ++j) load_x(j, 0);
+#pragma unroll
+    for (int j = 0; j < XL; ++j) commit_x(j, lds);
+    if (nchunks > 1) {
+#pragma unroll
+        for (int j = 0; j < XL; ++j) load_x(j, 1);
+    }
+    __syncthreads();
+
+    for (int c = 0; c < nchunks; ++c) {
+        const unsigned char *ws = lds + (c & 1) * IMGB, *xs = ws + WPADB;
+        unsigned char *nxt = lds + ((c + 1) & 1) * IMGB;
+        const bool do_next = c + 1 < nchunks, do_next2 = c + 2 < nchunks;
+
+        auto ld = [&](int k, bf16x8 *a, bf16x8 *b) {
+#pragma unroll
+            for (int i = 0; i < MC; ++i)
+                a[i] = *reinterpret_cast<const bf16x8 *>(ws + ((k * CO_T + wco + 32 * i + l31) * kCB + 8 * half) * 2);
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+                b[i] = *reinterpret_cast<const bf16x8 *>(xs + ((wt + 32 * i + l31 + k) * kCB + 8 * half) * 2);
+        };
+        bf16x8 a_c[MC], b_c[MT], a_n[MC], b_n[MT];
+        ld(0, a_c, b_c);
+#pragma unroll
+        for (int k = 0; k < KK; ++k) {
+            ld(k + 1 < KK ? k + 1 : 0, a_n, b_n);
+            if (k < XL) {
+                if (do_next) commit_x(k, nxt);
+            } else if (k < XL + DPW) {
+                if (do_next) dma_w(k - XL, c + 1, nxt);
+            } else if (k < 2 * XL + DPW) {
+                if (do_next2) load_x(k - XL - DPW, c + 2);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < MC; ++i)
+#pragma unroll
+                for (int j = 0; j < MT; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_c[i], b_c[j], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < MC; ++i) a_c[i] = a_n[i];
+#pragma unroll
+            for (int i = 0; i < MT; ++i) b_c[i] = b_n[i];
+        }
+        __syncthreads();
+    }
+    float *red = reinterpret_cast<float *>(lds);
+
+    // ---- epilogue (identical to the fp32 kernel: the accumulator layout is dtype-independent) ---
+#pragma unroll
+    for (int i = 0; i < MC; ++i) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int col = wco + 32 * i + acc_row_b(r, half);
+            const float bv = bias ? bias[co0 + col] : 0.f;
+            float s = 0.f, q = 0.f;
+#pragma unroll
+            for (int j = 0; j < MT; ++j) {
+                const int t = t0 + wt + 32 * j + l31;
+                const float v = acc[i][j][r] + bv;
+                if (t < Lo) {
+                    y[((size_t)n * Cout + co0 + col) * Lo + t] = v;
+                    if (STATS) { s += v; q = __fmaf_rn(v, v, q); }
+                }
+            }
+            if (STATS) {
+                s = half32_sum(s);
+                q = half32_sum(q);
+                if (l31 == 0) {
+                    const int lc = 32 * i + acc_row_b(r, half);
+                    red[(wave * (CO_T / WCO) + lc) * 2] = s;
+                    red[(wave * (CO_T / WCO) + lc) * 2 + 1] = q;
+                }
+            }
+        }
+    }
+    if (STATS) {
+        __syncthreads();
+        for (int e = tid; e < CO_T * 2; e += 256) {
+            const int col = e >> 1, w = e & 1;
+            const int wrow = col / (CO_T / WCO), lc = col - wrow * (CO_T / WCO);
+            float s = 0.f;
+#pragma unroll
+            for (int j = 0; j < WT; ++j) s += red[((wrow * WT + j) * (CO_T / WCO) + lc) * 2 + w];
+            const int pidx = n * gridDim.x + blockIdx.x;
+            partials[((size_t)(co0 + col) * P + pidx) * 2 + w] = s;
+        }
+    }
+}
+
+bool bf16_fwd_supported(int Cin, int Cout, int K, int pad) {
+    (void)pad;
+    return K == kKB && Cin % 4 == 0 && Cout % 32 == 0;
+}
+
+static int bf16_tile_t(int Cout) { return Cout % 64 == 0 ? 128 : 256; }
+
+int bf16_fwd_stat_partials(int N, int Cout, int Lo) { return N * cdiv(Lo, bf16_tile_t(Cout)); }
+
+size_t bf16_packed_elems(int Cred, int Cout, int K) {       // reduction channels padded to 16
+    return (size_t)((Cred + kCB - 1) / kCB) * K * Cout * kCB;
+}
+
+template <int CO_T, int T_T, int WCO, int WT>
+static void launch_bf16(const float *x, const u16 *wb, const float *bias, float *y, float *partials,
+                        int N, int Cin, int Cout, int L, int Lo, int pad, hipStream_t st) {
+    dim3 grid(cdiv(Lo, T_T), Cout / CO_T, N), block(256);
+    const int P = N * (int)grid.x;
+    if (partials)
+        hipLaunchKernelGGL((conv1d_mfma_bf16_fwd_kernel<CO_T, T_T, WCO, WT, true>), grid, block, 0, st,
+                           x, wb, bias, y, partials, Cin, Cout, L, Lo, pad, P);
+    else
+        hipLaunchKernelGGL((conv1d_mfma_bf16_fwd_kernel<CO_T, T_T, WCO, WT, false>), grid, block, 0, st,
+                           x, wb, bias, y, partials, Cin, Cout, L, Lo, pad, P);
+}
+
+int bf16_fwd(const float *x, const void *wb, const float *bias, float *y, float *partials, int N,
+             int Cin, int Cout, int L, int K, int pad, hipStream_t st) {
+    const int Lo = L + 2 * pad - K + 1;
+    const u16 *w = static_cast<const u16 *>(wb);
+    if (Cout % 64 == 0)
+        launch_bf16<64, 128, 2, 2>(x, w, bias, y, partials, N, Cin, Cout, L, Lo, pad, st);
+    else
+        launch_bf16<32, 256, 1, 4>(x, w, bias, y, partials, N, Cin, Cout, L, Lo, pad, st);
+    return check_launch("conv1d_mfma_bf16_fwd_kernel");
+}
+
+int bf16_pack(const float *w, void *wb_fwd, void *wb_bwd, int Co, int Ci, int K, hipStream_t st) {
+    const size_t n = bf16_packed_elems(Ci, Co, K), m = bf16_packed_elems(Co, Ci, K);
+    const size_t total = n > m ? n : m;
+    hipLaunchKernelGGL(pack_weights_bf16_kernel, dim3(cdiv((long long)total, 256)), dim3(256), 0, st, w,
+                       static_cast<u16 *>(wb_fwd), static_cast<u16 *>(wb_bwd), Co, Ci, K);
+    return check_launch("pack_weights_bf16_kernel");
+}
+
+}  // namespace ecg
+
+using namespace ecg;
+
+static int check_bf16_shape(const char *who, int N, int Cin, int Cout, int L, int K, int pad) {
+    ECG_REQUIRE(N > 0 && N <= 65535 && Cin > 0 && Cout > 0 && L > 0, "%s: bad shape", who);
+    ECG_REQUIRE(K == kKB && pad >= 0 && pad < K && L + 2 * pad - K + 1 > 0, "%s: kernel size must be 15", who);
+    return ECG_OK;
+}
+
+ECG_API int ecg_conv1d_bf16_supported(int C_in, int C_out, int K, int pad) {
+    // bit 0: forward (C_in % 4 == 0, C_out % 32 == 0); bit 1: input-grad (roles swapped)
+    return (bf16_fwd_supported(C_in, C_out, K, pad) ? 1 : 0) |
+           (bf16_fwd_supported(C_out, C_in, K, K - 1 - pad) ? 2 : 0);
+}
+
+ECG_API size_t ecg_conv1d_bf16_packed_elems(int C_reduce, int C_result, int K) {
+    return bf16_packed_elems(C_reduce, C_result, K);
+}
+
+ECG_API int ecg_conv1d_pack_weights_bf16(const float *w, void *wb_fwd, void *wb_bwd, int C_out,
+                                         int C_in, int K, ecg_stream_t stream) {
+    ECG_REQUIRE(w && (wb_fwd || wb_bwd) && C_out > 0 && C_in > 0 && K >= 1 && K <= 31,
+                "pack_weights_bf16: bad argument");
+    return bf16_pack(w, wb_fwd, wb_bwd, C_out, C_in, K, as_stream(stream));
+}
+
+ECG_API int ecg_conv1d_fwd_bf16_stat_partials(int N, int C_in, int C_out, int L, int K, int pad) {
+    (void)C_in;
+    return bf16_fwd_stat_partials(N, C_out, L + 2 * pad - K + 1);
+}
+
+ECG_API int ecg_conv1d_fwd_bf16(const float *x, const void *wb_fwd, const float *bias, float *y,
+                                float *stat_partials, int N, int C_in, int C_out, int L, int K,
+                                int pad, ecg_stream_t stream) {
+    int rc = check_bf16_shape("conv1d_fwd_bf16", N, C_in, C_out, L, K, pad);
+    if (rc) return rc;
+    ECG_REQUIRE(x && wb_fwd && y, "conv1d_fwd_bf16: null pointer");
+    ECG_REQUIRE(bf16_fwd_supported(C_in, C_out, K, pad), "conv1d_fwd_bf16: needs C_in %% 4 == 0, C_out %% 32 == 0");
+    return bf16_fwd(x, wb_fwd, bias, y, stat_partials, N, C_in, C_out, L, K, pad, as_stream(stream));
+}
+
+ECG_API int ecg_conv1d_bwd_data_bf16(const float *dy, const void *wb_bwd, float *dx, int N, int C_in,
+                                     int C_out, int L, int K, int pad, ecg_stream_t stream) {
+    int rc = check_bf16_shape("conv1d_bwd_data_bf16", N, C_in, C_out, L, K, pad);
+    if (rc) return rc;
+    ECG_REQUIRE(dy && wb_bwd && dx, "conv1d_bwd_data_bf16: null pointer");
+    const int Lo = L + 2 * pad - K + 1, padb = K - 1 - pad;
+    ECG_REQUIRE(bf16_fwd_supported(C_out, C_in, K, padb), "conv1d_bwd_data_bf16: needs C_out %% 4 == 0, C_in %% 32 == 0");
+    return bf16_fwd(dy, wb_bwd, nullptr, dx, nullptr, N, C_out, C_in, Lo, K, padb, as_stream(stream));
+}

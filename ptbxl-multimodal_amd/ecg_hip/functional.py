@@ -67,6 +67,64 @@ def conv1d_pack(w, need_bwd=True):
     return w_fwd, w_bwd
 
 
+# --------------------------------------------------------------------------------------
+# Conv precision: "fp32" (default, the parity path: exact-fp32 MFMA) or "bf16" (opt-in mixed
+# precision, BASELINE.json config 5: bf16 operands / fp32 accumulate in forward and input-grad,
+# fp32 weight-grad, fp32 everything else).  ECG_HIP_CONV_PRECISION sets the process default.
+# --------------------------------------------------------------------------------------
+_conv_precision = _os.environ.get("ECG_HIP_CONV_PRECISION", "fp32")
+
+
+def set_conv_precision(mode):
+    global _conv_precision
+    if mode not in ("fp32", "bf16"):
+        raise ValueError("conv precision must be 'fp32' or 'bf16'")
+    _conv_precision = mode
+
+
+def get_conv_precision():
+    return _conv_precision
+
+
+class conv_precision:
+    """Context manager: `with conv_precision("bf16"): model(x)`."""
+
+    def __init__(self, mode):
+        self.mode = mode
+
+    def __enter__(self):
+        self.prev = get_conv_precision()
+        set_conv_precision(self.mode)
+
+    def __exit__(self, *exc):
+        set_conv_precision(self.prev)
+        return False
+
+
+def conv1d_pack_bf16(w, need_bwd=True):
+    Co, Ci, K = w.shape
+    nf = _query("ecg_conv1d_bf16_packed_elems", Ci, Co, K)
+    wb_fwd = torch.empty(nf, dtype=torch.bfloat16, device=w.device)
+    wb_bwd = None
+    if need_bwd:
+        wb_bwd = torch.empty(_query("ecg_conv1d_bf16_packed_elems", Co, Ci, K), dtype=torch.bfloat16, device=w.device)
+    _call("ecg_conv1d_pack_weights_bf16", _f32(w), L.ptr(wb_fwd), L.ptr(wb_bwd), Co, Ci, K, _st())
+    return wb_fwd, wb_bwd
+
+
+def conv1d_forward_bf16_raw(x, wb_fwd, bias, Co, K, pad, want_stats):
+    N, Ci, Lin = x.shape
+    Lo = Lin + 2 * pad - K + 1
+    y = _empty(x, N, Co, Lo)
+    partials, P = None, 0
+    if want_stats:
+        P = _query("ecg_conv1d_fwd_bf16_stat_partials", N, Ci, Co, Lin, K, pad)
+        partials = _empty(x, Co * P * 2)
+    _call("ecg_conv1d_fwd_bf16", _f32(x), L.ptr(wb_fwd), _f32(bias), _f32(y), _f32(partials),
+          N, Ci, Co, Lin, K, pad, _st())
+    return y, partials, P
+
+
 class WeightPacker:
     """All per-forward weight repacking of a model in one launch: conv weights -> (w_fwd, w_bwd)
     and the Linear weights the fused tail reads transposed.  Destination buffers and the
@@ -124,7 +182,7 @@ def conv1d_forward_raw(x, w_fwd, bias, Co, K, pad, want_stats):
     return y, partials, P
 
 
-def conv1d_backward_raw(x, dy, w_shape, w_bwd, pad, need_dx, need_db=True, overlap=False):
+def conv1d_backward_raw(x, dy, w_shape, w_bwd, pad, need_dx, need_db=True, overlap=False, bf16=False):
     N, Ci, Lin = x.shape
     Co, _, K = w_shape
     main = torch.cuda.current_stream()
@@ -154,7 +212,10 @@ def conv1d_backward_raw(x, dy, w_shape, w_bwd, pad, need_dx, need_db=True, overl
     dx = None
     if need_dx:
         dx = torch.empty_like(x)
-        _call("ecg_conv1d_bwd_data", _f32(dy), _f32(w_bwd), _f32(dx), N, Ci, Co, Lin, K, pad, _st())
+        if bf16:
+            _call("ecg_conv1d_bwd_data_bf16", _f32(dy), L.ptr(w_bwd), _f32(dx), N, Ci, Co, Lin, K, pad, _st())
+        else:
+            _call("ecg_conv1d_bwd_data", _f32(dy), _f32(w_bwd), _f32(dx), N, Ci, Co, Lin, K, pad, _st())
     return dx, dw, db
 
 
@@ -200,11 +261,17 @@ class ConvBlockFn(torch.autograd.Function):
         Co, _, K = w.shape
         use_batch = training or running_mean is None
         need_grad = any(ctx.needs_input_grad)
-        if packed is not None and (packed[1] is not None or not ctx.needs_input_grad[0]):
+        sup = _query("ecg_conv1d_bf16_supported", x.shape[1], Co, K, pad) if _conv_precision == "bf16" else 0
+        need_dx = need_grad and ctx.needs_input_grad[0]
+        bf16 = bool(sup & 1) and (not need_dx or bool(sup & 2))     # block 0 (no input-grad) only needs the forward
+        ctx.bf16 = bf16
+        if bf16:
+            w_fwd, w_bwd = conv1d_pack_bf16(w, need_bwd=need_grad and ctx.needs_input_grad[0])
+        elif packed is not None and (packed[1] is not None or not ctx.needs_input_grad[0]):
             w_fwd, w_bwd = packed                        # packed by WeightPacker for the whole model
         else:
             w_fwd, w_bwd = conv1d_pack(w, need_bwd=need_grad and ctx.needs_input_grad[0])
-        if (not use_batch and not gap and not need_grad
+        if (not use_batch and not gap and not need_grad and not bf16
                 and _query("ecg_conv1d_bn_relu_pool_eval_supported", x.shape[1], Co, K, pad)):
             # pure inference: conv + folded BN + ReLU + pool in one launch, y is never written
             N, Ci, Lin = x.shape
@@ -214,7 +281,10 @@ class ConvBlockFn(torch.autograd.Function):
                   _f32(beta), _f32(running_mean), _f32(running_var), float(eps), _f32(p),
                   N, Ci, Co, Lin, K, pad, _st())
             return p
-        y, partials, P = conv1d_forward_raw(x, w_fwd, b, Co, K, pad, want_stats=use_batch)
+        if bf16:
+            y, partials, P = conv1d_forward_bf16_raw(x, w_fwd, b, Co, K, pad, want_stats=use_batch)
+        else:
+            y, partials, P = conv1d_forward_raw(x, w_fwd, b, Co, K, pad, want_stats=use_batch)
         if use_batch:
             rm, rv, cnt = (running_mean, running_var, nbt) if training else (None, None, None)
             mean, invstd = bn_batch_stats(y, partials, P, rm, rv, cnt, _bn_momentum(momentum, nbt), eps)
@@ -245,7 +315,7 @@ class ConvBlockFn(torch.autograd.Function):
               _f32(gamma), _f32(beta), _f32(mean), _f32(invstd), _f32(dy), _f32(dgamma), _f32(dbeta),
               _f32(ws), N, Co, Lo, 1 if ctx.batch_stats else 0, _st())
         dx, dw, db = conv1d_backward_raw(x, dy, w.shape, ctx.w_bwd, ctx.pad, ctx.needs_input_grad[0],
-                                         overlap=True)
+                                         overlap=True, bf16=ctx.bf16)
         return dx, dw, db, dgamma, dbeta, None, None, None, None, None, None, None, None, None
 
 

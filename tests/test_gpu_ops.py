@@ -405,3 +405,40 @@ def test_eval_fused_conv_bn_relu_pool(hip, oracle, shape):
     rp = oracle.bn_relu_pool_fwd(y, gamma, beta, rmean, invstd)
     np.testing.assert_allclose(host(p), rp, atol=3e-5)
     assert L.query("ecg_conv1d_bn_relu_pool_eval_supported", 7, 5, 3, 1) == 0
+
+
+def _bf16_round(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(torch.bfloat16).to(torch.float32).numpy()
+
+
+@pytest.mark.parametrize("case", [(3, 12, 32, 300), (2, 32, 64, 257), (2, 64, 128, 130), (2, 128, 256, 70), (1, 12, 32, 16)])
+def test_bf16_conv_is_exact_on_bf16_rounded_operands(hip, oracle, case):
+    """Mixed-precision path (config 5): the bf16 kernel must equal the oracle evaluated on the
+    bf16-rounded operands up to fp32 accumulation error — this pins operand layout, rounding mode
+    (nearest-even) and zero padding exactly; the loss of precision is only the operand rounding."""
+    from ecg_hip import _lib as L
+    N, Ci, Co, Lin = case
+    rng = np.random.default_rng(Ci * 7 + Lin)
+    x = rng.standard_normal((N, Ci, Lin)).astype(np.float32)
+    w = (rng.standard_normal((Co, Ci, 15)) / np.sqrt(Ci * 15)).astype(np.float32)
+    b = rng.standard_normal(Co).astype(np.float32)
+    dy = rng.standard_normal((N, Co, Lin)).astype(np.float32)
+    assert L.query("ecg_conv1d_bf16_supported", Ci, Co, 15, 7) == (3 if Ci % 32 == 0 else 1)
+    wb_fwd, wb_bwd = hip.conv1d_pack_bf16(dev(w), need_bwd=True)
+    y, _, _ = hip.conv1d_forward_bf16_raw(dev(x), wb_fwd, dev(b), Co, 15, 7, want_stats=False)
+    ry = oracle.conv1d_fwd(_bf16_round(x), _bf16_round(w), b, 7)
+    np.testing.assert_allclose(host(y), ry, atol=2e-5)
+    # ... and it is a bf16-accurate approximation of the fp32 convolution
+    full = oracle.conv1d_fwd(x, w, b, 7)
+    assert np.abs(host(y) - full).max() < 0.05 and np.abs(host(y) - full).max() > 1e-5
+    if Ci % 32 == 0:        # input-grad kernel = forward with the roles swapped: needs C_in % 32 == 0
+        dx = torch.empty(N, Ci, Lin, device="cuda")
+        L.call("ecg_conv1d_bwd_data_bf16", L.f32(dev(dy)), L.ptr(wb_bwd), L.f32(dx), N, Ci, Co, Lin, 15, 7, L.stream())
+        rdx = oracle.conv1d_bwd_data(_bf16_round(dy), _bf16_round(w), Lin, 7)
+        np.testing.assert_allclose(host(dx), rdx, atol=5e-5)
+    # statistics epilogue on the bf16 path
+    y2, partials, P = hip.conv1d_forward_bf16_raw(dev(x), wb_fwd, dev(b), Co, 15, 7, want_stats=True)
+    mean, invstd = hip.bn_batch_stats(y2, partials, P, None, None, None, 0.1, 1e-5)
+    omean, oinv = oracle.bn_stats(ry)
+    np.testing.assert_allclose(host(mean), omean, atol=5e-6)
+    np.testing.assert_allclose(host(invstd), oinv, rtol=5e-5)
