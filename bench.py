@@ -129,6 +129,9 @@ def main():
     ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32",
                     help="f32 (default, the parity path) or bf16 = opt-in mixed precision of BASELINE config 5: "
                          "bf16 conv operands in forward/input-grad, fp32 accumulate, fp32 weight-grad and the rest")
+    ap.add_argument("--graph", action="store_true",
+                    help="replay the whole step as one captured hipGraph (ecg_hip.graph.GraphedTrainStep); "
+                         "single GPU only; pays off when the step is host-bound (small batches)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -170,6 +173,17 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
+    if args.graph:
+        if world > 1:
+            raise SystemExit("--graph is single-GPU only")
+        from ecg_hip.graph import GraphedTrainStep
+        gstep = GraphedTrainStep(model, opt, batch)
+
+        def run(_model, loader, _opt, _dev):          # same contract as the loop API: mean loss of the epoch
+            for b in loader:
+                gstep(*b)
+            return gstep.mean_loss_and_reset(len(loader))
+
     run(model, ListLoader(batch, args.warmup), opt, dev)
     barrier()
     t0 = time.perf_counter()
@@ -181,9 +195,10 @@ def main():
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed = t.item()
 
-    # instrumented pass (HIP events around every ABI launch on the launch stream)
+    # instrumented pass (HIP events around every ABI launch on the launch stream); always eager
+    run_eager = train_one_epoch_demo if demo else train_one_epoch
     with _lib.kernel_timing() as kt:
-        run(model, ListLoader(batch, min(args.steps, 10)), opt, dev)
+        run_eager(model, ListLoader(batch, min(args.steps, 10)), opt, dev)
     roof, breakdown, instr_ms = kernel_roofline(kt.result, B)
 
     if rank == 0:
@@ -198,7 +213,8 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"{'ECGMultimodal (FiLM)' if demo else 'ECGCNN(5)'} train step fwd+BCE+bwd+AdamW, "
                                    f"12x{T} fp32, batch {B}/GPU, global batch {B * world}",
-                       "global_batch": B * world, "parallelism": f"dp{world}", "loop": "src.training API + FlatAdamW",
+                       "global_batch": B * world, "parallelism": f"dp{world}",
+                       "loop": "hipGraph replay of the whole step (GraphedTrainStep)" if args.graph else "src.training API + FlatAdamW",
                        "final_loss": round(float(last_loss), 6)},
             "step_conv_tflops": round(value * step_f / 1e12, 2),
             "step_frac_of_fp32_peak": round(value * step_f / 1e12 / (PEAK_F32_TFLOPS * world), 4),

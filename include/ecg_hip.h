@@ -265,6 +265,13 @@ int ecg_adamw_step(float *p, const float *g, float *m, float *v, size_t n, int s
                    float lr, float beta1, float beta2, float eps, float weight_decay,
                    float grad_scale, ecg_stream_t stream);
 
+/* Same update with the step counter on the device (step_dev[0] = number of steps taken so far,
+ * incremented by the call): nothing host-side changes between steps, so the whole train step can
+ * be captured once in a hipGraph and replayed (ecg_hip.graph.GraphedTrainStep). */
+int ecg_adamw_step_graph(float *p, const float *g, float *m, float *v, size_t n, int *step_dev,
+                         float lr, float beta1, float beta2, float eps, float weight_decay,
+                         float grad_scale, ecg_stream_t stream);
+
 /* Per-lead z-score of a window batch, (x-mean)/(std+1e-6) with population std —
  * src/datasets/ptbxl.py:122-127.  x [rows][T] -> out [rows][T]. */
 int ecg_zscore_rows(const float *x, float *out, int rows, int T, ecg_stream_t stream);

@@ -55,6 +55,7 @@ class FlatAdamW(torch.optim.Optimizer):
         self.flat_v = torch.zeros_like(self.flat_param)
         self.flat_grad = None
         self._step = 0
+        self._step_dev = None            # device-side step counter (graph-capturable mode)
         self.process_group = process_group
         if world_size is None:
             world_size = 1
@@ -120,8 +121,13 @@ class FlatAdamW(torch.optim.Optimizer):
                 loss = closure()
         grp = self.param_groups[0]
         g, scale = self.reduce_gradients()
-        self._step += 1
         b1, b2 = grp["betas"]
+        if self._step_dev is not None:        # capturable: the kernel reads and bumps the device counter
+            L.call("ecg_adamw_step_graph", L.f32(self.flat_param), L.f32(g), L.f32(self.flat_m),
+                   L.f32(self.flat_v), g.numel(), L.ptr(self._step_dev), float(grp["lr"]), float(b1),
+                   float(b2), float(grp["eps"]), float(grp["weight_decay"]), scale, L.stream())
+            return loss
+        self._step += 1
         if g.is_cuda:
             L.call("ecg_adamw_step", L.f32(self.flat_param), L.f32(g), L.f32(self.flat_m),
                    L.f32(self.flat_v), g.numel(), self._step, float(grp["lr"]), float(b1), float(b2),
@@ -130,13 +136,25 @@ class FlatAdamW(torch.optim.Optimizer):
             raise L.EcgHipError("FlatAdamW: parameters must live on the GPU (no CPU fallback)")
         return loss
 
+    def make_capturable(self):
+        """Move the step counter to the device so `step()` can be captured in a HIP graph."""
+        if self._step_dev is None:
+            self._step_dev = torch.full((1,), self._step, dtype=torch.int32, device=self.flat_param.device)
+        return self
+
+    @property
+    def steps_taken(self):
+        return int(self._step_dev.item()) if self._step_dev is not None else self._step
+
     # checkpointing of optimizer state (the reference saves none; kept for completeness)
     def state_dict(self):
-        return {"step": self._step, "exp_avg": self.flat_m, "exp_avg_sq": self.flat_v,
+        return {"step": self.steps_taken, "exp_avg": self.flat_m, "exp_avg_sq": self.flat_v,
                 "param_groups": [{k: v for k, v in self.param_groups[0].items() if k != "params"}]}
 
     def load_state_dict(self, sd):
         self._step = int(sd["step"])
+        if self._step_dev is not None:
+            self._step_dev.fill_(self._step)
         self.flat_m.copy_(sd["exp_avg"])
         self.flat_v.copy_(sd["exp_avg_sq"])
         self.param_groups[0].update(sd["param_groups"][0])

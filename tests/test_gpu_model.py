@@ -339,3 +339,41 @@ def test_bf16_mixed_precision_train_step_config5():
         cos = float(g @ r) / (np.linalg.norm(g) * np.linalg.norm(r) + 1e-20)
         # bf16 rounding noise accumulates towards the first block (3 bf16 input-grad convs deep)
         assert rel < 0.2 and cos > 0.98, (k, rel, cos)
+
+
+def test_graphed_train_step_matches_eager():
+    """A captured hipGraph of the whole step (fwd + BCE + bwd + FlatAdamW with a device-side step
+    counter) replays to the same parameters as the eager loop."""
+    from ecg_hip.graph import GraphedTrainStep
+    from ecg_hip.optim import FlatAdamW
+    from ecg_hip import functional as hipF
+    from src.models.ecg_multimodal import ECGMultimodal
+    from src.utils.seed import set_seed
+    batch = tuple(t.to(DEV) for t in R.synthetic_batch(16, 1000, 5, demo=True))
+    set_seed(7)
+    eager = ECGMultimodal().to(DEV).train()
+    eopt = FlatAdamW(eager.parameters(), lr=1e-3, weight_decay=1e-4)
+    set_seed(7)
+    graphed = ECGMultimodal().to(DEV).train()
+    gopt = FlatAdamW(graphed.parameters(), lr=1e-3, weight_decay=1e-4)
+    sd0 = {k: v.clone() for k, v in graphed.state_dict().items()}
+    step = GraphedTrainStep(graphed, gopt, batch, warmup=2)
+    # the constructor's warm-up/capture iterations advanced the model: rewind it completely
+    graphed.load_state_dict(sd0)
+    gopt.flat_m.zero_(), gopt.flat_v.zero_(), gopt._step_dev.zero_()
+    losses = []
+    for _ in range(4):
+        eopt.zero_grad()
+        loss = hipF.binary_cross_entropy_with_logits(eager(*batch[:-1]), batch[-1])
+        loss.backward()
+        eopt.step()
+        losses.append(loss.item())
+        gl = step(*batch)
+        assert abs(gl.item() - losses[-1]) < 1e-6
+    assert gopt.steps_taken == 4 and eopt.steps_taken == 4
+    assert abs(step.mean_loss_and_reset(4) - float(np.mean(losses))) < 1e-6
+    for (k, a), (_, b) in zip(graphed.state_dict().items(), eager.state_dict().items()):
+        if k.endswith("num_batches_tracked"):
+            assert int(a.item()) == int(b.item()) == 4
+        else:
+            np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), atol=1e-6, err_msg=k)
