@@ -533,7 +533,7 @@ class TailFn(torch.autograd.Function):
             _call("ecg_transpose", _f32(_contig(Wp)), _f32(WpT), F, F0, _st())
         z, logits = _empty(g, M, F), _empty(g, M, C)
         D = H1 = H = 0
-        xdc = WfT = h1 = h2 = film = zc = None
+        xdc = h1 = h2 = film = zc = None
         if demo:
             xdc = _contig(xd)
             D, H1, H = xdc.shape[1], W0.shape[0], W2.shape[0]
