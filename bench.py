@@ -57,7 +57,7 @@ def conv_flops_per_window(T):
     return fwd, step
 
 
-SINGLE_LAUNCH = ("ecg_conv1d_fwd", "ecg_conv1d_bwd_data",     # entry points that are exactly one kernel
+SINGLE_LAUNCH = ("ecg_conv1d_fwd", "ecg_conv1d_bwd_data", "ecg_conv1d_bwd_data_ld",   # entry points that are exactly one kernel
                  "ecg_conv1d_fwd_bf16", "ecg_conv1d_bwd_data_bf16")
 
 

@@ -86,6 +86,20 @@ int ecg_conv1d_fwd(const float *x, const float *w_fwd, const float *bias, float 
 int ecg_conv1d_bwd_data(const float *dy, const float *w_bwd, float *dx,
                         int N, int C_in, int C_out, int L, int K, int pad, ecg_stream_t stream);
 
+/* Row-padded dY.  The backward of a ConvBlock hands dY from the BatchNorm backward to the two
+ * conv gradients; it is an internal tensor, so its layout is ours to choose.  When
+ * ecg_conv1d_dy_row_stride returns ldy > Lo (a multiple of 64 floats), give dY that row stride
+ * ([N][C_out][ldy], zeros in [Lo, ldy) — ecg_bn_relu_pool_bwd_ld / _gap_bwd_ld write them) and the
+ * weight gradient streams it global -> LDS by DMA instead of through registers.  The _ld entry
+ * points accept any ldy >= Lo where the MFMA kernels apply and require ldy == Lo elsewhere; the
+ * plain entry points are the ldy == Lo case. */
+int ecg_conv1d_dy_row_stride(int N, int C_in, int C_out, int L, int K, int pad);
+int ecg_conv1d_bwd_data_ld(const float *dy, int ldy, const float *w_bwd, float *dx,
+                           int N, int C_in, int C_out, int L, int K, int pad, ecg_stream_t stream);
+int ecg_conv1d_bwd_weight_bias_ld(const float *dy, int ldy, const float *x, float *dw, float *db,
+                                  float *ws, int N, int C_in, int C_out, int L, int K, int pad,
+                                  ecg_stream_t stream);
+
 /* Workspace (floats) for ecg_conv1d_bwd_weight_bias. */
 size_t ecg_conv1d_bwd_weight_ws_floats(int N, int C_in, int C_out, int L, int K, int pad);
 /* dw[co,ci,k] = sum_n sum_t dy[n,co,t]*x[n,ci,t+k-pad] (state_dict layout [C_out][C_in][K]);
@@ -147,6 +161,11 @@ int ecg_bn_relu_pool_bwd(const float *y, const float *dp, const float *gamma, co
                          const float *mean, const float *invstd,
                          float *dy, float *dgamma, float *dbeta, float *ws,
                          int N, int C, int L, int train, ecg_stream_t stream);
+/* Same, dy rows at stride ldy >= L with the pad [L, ldy) zero-filled. */
+int ecg_bn_relu_pool_bwd_ld(const float *y, const float *dp, const float *gamma, const float *beta,
+                            const float *mean, const float *invstd,
+                            float *dy, int ldy, float *dgamma, float *dbeta, float *ws,
+                            int N, int C, int L, int train, ecg_stream_t stream);
 
 /* Inference: a whole ConvBlock in ONE launch — Conv1d, eval-mode BatchNorm1d (running statistics)
  * folded into the epilogue, ReLU and MaxPool1d(2); only the pooled activation p [N][C_out][Lo/2]
@@ -169,6 +188,10 @@ int ecg_bn_relu_pool_gap_bwd(const float *y, const float *dg, const float *gamma
                              const float *mean, const float *invstd,
                              float *dy, float *dgamma, float *dbeta, float *ws,
                              int N, int C, int L, int train, ecg_stream_t stream);
+int ecg_bn_relu_pool_gap_bwd_ld(const float *y, const float *dg, const float *gamma,
+                                const float *beta, const float *mean, const float *invstd,
+                                float *dy, int ldy, float *dgamma, float *dbeta, float *ws,
+                                int N, int C, int L, int train, ecg_stream_t stream);
 
 /* Unfused leaves (used when a caller hooks an inner module, e.g. Grad-CAM on net[0]:
  * scripts/00_demo_inference.py:36-37). */

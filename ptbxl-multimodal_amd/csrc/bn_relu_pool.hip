@@ -201,22 +201,29 @@ __global__ __launch_bounds__(64) void bn_bwd_finalize_kernel(
 }
 
 // dy[t] = gamma*invstd * (da[t] - k1 - xhat[t]*k2).  thread <-> output pair (2j, 2j+1).
+// dy rows have stride ldy >= L; the pad [L, ldy) is written as zeros (Lh = ceil(ldy/2) pairs per
+// row): the weight-gradient kernel streams such rows by LDS-DMA and needs the zeros.
 template <bool FUSED>
 __global__ __launch_bounds__(kBlock) void bn_bwd_dx_kernel(
     const float *__restrict__ y, const float *__restrict__ g, const float *__restrict__ gamma,
     const float *__restrict__ beta, const float *__restrict__ mean,
     const float *__restrict__ invstd, const float *__restrict__ coef, float *__restrict__ dy,
-    int C, int L, int Lh, size_t total, float bcast) {
+    int C, int L, int ldy, int Lh, size_t total, float bcast) {
     size_t idx = (size_t)blockIdx.x * kBlock + threadIdx.x;
     if (idx >= total) return;
     size_t row = idx / Lh;
     int j = (int)(idx - row * Lh);
+    float *d = dy + row * (size_t)ldy;
+    const int t0 = 2 * j;
+    if (t0 >= L) {                 // pad pair
+        d[t0] = 0.f;
+        if (t0 + 1 < ldy) d[t0 + 1] = 0.f;
+        return;
+    }
     int c = (int)(row % C);
     const float mu = mean[c], is = invstd[c], ga = gamma[c], sc = is * ga;
     const float k1 = coef[2 * c], k2 = coef[2 * c + 1], gi = ga * is;
     const float *r = y + row * L;
-    float *d = dy + row * L;
-    const int t0 = 2 * j;
     const bool has1 = t0 + 1 < L;
     float y0 = r[t0], y1 = has1 ? r[t0 + 1] : 0.f;
     float da0 = 0.f, da1 = 0.f;
@@ -234,6 +241,7 @@ __global__ __launch_bounds__(kBlock) void bn_bwd_dx_kernel(
     }
     d[t0] = gi * (da0 - k1 - (y0 - mu) * is * k2);
     if (has1) d[t0 + 1] = gi * (da1 - k1 - (y1 - mu) * is * k2);
+    else if (t0 + 1 < ldy) d[t0 + 1] = 0.f;
 }
 
 // ---------------------------------------------------------------------------------------
@@ -357,8 +365,8 @@ ECG_API size_t ecg_bn_bwd_ws_floats(int N, int C, int L) { return ecg_bn_relu_po
 template <bool FUSED>
 static int bn_bwd_impl(const float *y, const float *g, const float *gamma, const float *beta,
                        const float *mean, const float *invstd, float *dy, float *dgamma,
-                       float *dbeta, float *ws, int N, int C, int L, int train, hipStream_t st,
-                       float bcast = 0.f) {
+                       float *dbeta, float *ws, int N, int C, int L, int ldy, int train,
+                       hipStream_t st, float bcast = 0.f) {
     const int S = stat_splits(N, C);
     float *partials = ws, *coef = ws + (size_t)C * S * 2;
     hipLaunchKernelGGL((bn_bwd_reduce_kernel<FUSED>), dim3(C, S), dim3(kBlock), 0, st, y, g, gamma,
@@ -369,23 +377,32 @@ static int bn_bwd_impl(const float *y, const float *g, const float *gamma, const
                        (double)N * L, dgamma, dbeta, coef, train);
     rc = check_launch("bn_bwd_finalize_kernel");
     if (rc) return rc;
-    const int Lh = (L + 1) / 2;
+    const int Lh = (ldy + 1) / 2;
     size_t total = (size_t)N * C * Lh;
     hipLaunchKernelGGL((bn_bwd_dx_kernel<FUSED>), dim3(cdiv(total, kBlock)), dim3(kBlock), 0, st, y,
-                       g, gamma, beta, mean, invstd, coef, dy, C, L, Lh, total, bcast);
+                       g, gamma, beta, mean, invstd, coef, dy, C, L, ldy, Lh, total, bcast);
     return check_launch("bn_bwd_dx_kernel");
+}
+
+ECG_API int ecg_bn_relu_pool_bwd_ld(const float *y, const float *dp, const float *gamma,
+                                    const float *beta, const float *mean, const float *invstd,
+                                    float *dy, int ldy, float *dgamma, float *dbeta, float *ws,
+                                    int N, int C, int L, int train, ecg_stream_t stream) {
+    int rc = check_ncl("bn_relu_pool_bwd", N, C, L);
+    if (rc) return rc;
+    ECG_REQUIRE(y && gamma && beta && mean && invstd && dy && ws, "bn_relu_pool_bwd: null pointer");
+    ECG_REQUIRE(dp || L < 2, "bn_relu_pool_bwd: dp is NULL");
+    ECG_REQUIRE(ldy >= L, "bn_relu_pool_bwd: dY row stride %d < row length %d", ldy, L);
+    return bn_bwd_impl<true>(y, dp, gamma, beta, mean, invstd, dy, dgamma, dbeta, ws, N, C, L, ldy,
+                             train, as_stream(stream));
 }
 
 ECG_API int ecg_bn_relu_pool_bwd(const float *y, const float *dp, const float *gamma,
                                  const float *beta, const float *mean, const float *invstd,
                                  float *dy, float *dgamma, float *dbeta, float *ws, int N, int C,
                                  int L, int train, ecg_stream_t stream) {
-    int rc = check_ncl("bn_relu_pool_bwd", N, C, L);
-    if (rc) return rc;
-    ECG_REQUIRE(y && gamma && beta && mean && invstd && dy && ws, "bn_relu_pool_bwd: null pointer");
-    ECG_REQUIRE(dp || L < 2, "bn_relu_pool_bwd: dp is NULL");
-    return bn_bwd_impl<true>(y, dp, gamma, beta, mean, invstd, dy, dgamma, dbeta, ws, N, C, L,
-                             train, as_stream(stream));
+    return ecg_bn_relu_pool_bwd_ld(y, dp, gamma, beta, mean, invstd, dy, L, dgamma, dbeta, ws, N, C, L,
+                                   train, stream);
 }
 
 ECG_API int ecg_bn_apply_fwd(const float *y, const float *gamma, const float *beta,
@@ -406,7 +423,7 @@ ECG_API int ecg_bn_bwd(const float *y, const float *dout, const float *gamma, co
     int rc = check_ncl("bn_bwd", N, C, L);
     if (rc) return rc;
     ECG_REQUIRE(y && dout && gamma && mean && invstd && dy && ws, "bn_bwd: null pointer");
-    return bn_bwd_impl<false>(y, dout, gamma, nullptr, mean, invstd, dy, dgamma, dbeta, ws, N, C, L,
+    return bn_bwd_impl<false>(y, dout, gamma, nullptr, mean, invstd, dy, dgamma, dbeta, ws, N, C, L, L,
                               train, as_stream(stream));
 }
 
@@ -445,16 +462,24 @@ ECG_API int ecg_maxpool2_bwd(const float *x, const float *dp, float *dx, int row
     return check_launch("maxpool2_bwd_kernel");
 }
 
-ECG_API int ecg_bn_relu_pool_gap_bwd(const float *y, const float *dg, const float *gamma,
-                                     const float *beta, const float *mean, const float *invstd,
-                                     float *dy, float *dgamma, float *dbeta, float *ws, int N,
-                                     int C, int L, int train, ecg_stream_t stream) {
+ECG_API int ecg_bn_relu_pool_gap_bwd_ld(const float *y, const float *dg, const float *gamma,
+                                        const float *beta, const float *mean, const float *invstd,
+                                        float *dy, int ldy, float *dgamma, float *dbeta, float *ws,
+                                        int N, int C, int L, int train, ecg_stream_t stream) {
     int rc = check_ncl("bn_relu_pool_gap_bwd", N, C, L);
     if (rc) return rc;
     ECG_REQUIRE(y && dg && gamma && beta && mean && invstd && dy && ws,
                 "bn_relu_pool_gap_bwd: null pointer");
     ECG_REQUIRE(L >= 2, "bn_relu_pool_gap_bwd: L=%d leaves an empty pooled row", L);
-    return bn_bwd_impl<true>(y, dg, gamma, beta, mean, invstd, dy, dgamma, dbeta, ws, N, C, L,
+    ECG_REQUIRE(ldy >= L, "bn_relu_pool_gap_bwd: dY row stride %d < row length %d", ldy, L);
+    return bn_bwd_impl<true>(y, dg, gamma, beta, mean, invstd, dy, dgamma, dbeta, ws, N, C, L, ldy,
                              train, as_stream(stream), 1.0f / (float)(L / 2));
 }
 
+ECG_API int ecg_bn_relu_pool_gap_bwd(const float *y, const float *dg, const float *gamma,
+                                     const float *beta, const float *mean, const float *invstd,
+                                     float *dy, float *dgamma, float *dbeta, float *ws, int N,
+                                     int C, int L, int train, ecg_stream_t stream) {
+    return ecg_bn_relu_pool_gap_bwd_ld(y, dg, gamma, beta, mean, invstd, dy, L, dgamma, dbeta, ws, N, C,
+                                       L, train, stream);
+}

@@ -17,15 +17,16 @@ int pack_weights_grouped(const float *const *w, float *const *w_fwd, float *cons
 // conv1d_mfma.hip
 bool mfma_fwd_supported(int Cin, int Cout, int K, int pad);
 int mfma_fwd_stat_partials(int N, int Cin, int Cout, int Lo);
-int mfma_fwd(const float *x, const float *wp, const float *bias, float *y, float *partials, int N,
-             int Cin, int Cout, int L, int K, int pad, hipStream_t st);
+int mfma_fwd(const float *x, int ldx, const float *wp, const float *bias, float *y, float *partials,
+             int N, int Cin, int Cout, int L, int K, int pad, hipStream_t st);
 int mfma_fwd_eval_pool(const float *x, const float *wp, const float *bias, const float *gamma,
                        const float *beta, const float *mean, const float *var, float eps, float *p,
                        int N, int Cin, int Cout, int L, int K, int pad, hipStream_t st);
 bool mfma_wgrad_supported(int Cin, int Cout, int K, int pad);
 size_t mfma_wgrad_ws_floats(int N, int Cin, int Cout, int L, int K);
-int mfma_wgrad(const float *dy, const float *x, float *dw, float *db, float *ws, int N, int Cin,
-               int Cout, int L, int K, int pad, hipStream_t st);
+bool mfma_wgrad_dma_supported(int Cin, int Cout, int K);
+int mfma_wgrad(const float *dy, int ldy, const float *x, float *dw, float *db, float *ws, int N,
+               int Cin, int Cout, int L, int K, int pad, hipStream_t st);
 
 static int check_conv_shape(int N, int Cin, int Cout, int L, int K, int pad) {
     ECG_REQUIRE(N > 0 && Cin > 0 && Cout > 0 && L > 0, "conv1d: N=%d C_in=%d C_out=%d L=%d must be > 0",
@@ -73,21 +74,41 @@ ECG_API int ecg_conv1d_fwd(const float *x, const float *w_fwd, const float *bias
     if (rc) return rc;
     ECG_REQUIRE(x && w_fwd && y, "conv1d_fwd: null pointer");
     if (mfma_fwd_supported(C_in, C_out, K, pad))
-        return mfma_fwd(x, w_fwd, bias, y, stat_partials, N, C_in, C_out, L, K, pad, as_stream(stream));
+        return mfma_fwd(x, L, w_fwd, bias, y, stat_partials, N, C_in, C_out, L, K, pad, as_stream(stream));
     return direct_fwd(x, w_fwd, bias, y, stat_partials, N, C_in, C_out, L, K, pad, as_stream(stream));
+}
+
+// Row stride the fused BatchNorm backward should give dY for this layer: rows padded to a
+// multiple of 64 floats (pad zero-filled) let the weight-gradient kernel stream dY by LDS-DMA.
+// Returns Lo (dense rows) when the shape is not served by the MFMA kernels that understand it.
+ECG_API int ecg_conv1d_dy_row_stride(int N, int C_in, int C_out, int L, int K, int pad) {
+    (void)N;
+    const int Lo = L + 2 * pad - K + 1;
+    if (Lo <= 0) return Lo;
+    if (mfma_wgrad_dma_supported(C_in, C_out, K) && mfma_fwd_supported(C_out, C_in, K, K - 1 - pad))
+        return cdiv(Lo, 64) * 64;
+    return Lo;
 }
 
 // Input gradient = forward conv of dy with the tap-flipped, channel-transposed weights
 // (w_bwd [K][C_out][C_in]) and padding K-1-pad: roles of C_in / C_out swap.
-ECG_API int ecg_conv1d_bwd_data(const float *dy, const float *w_bwd, float *dx, int N, int C_in,
-                                int C_out, int L, int K, int pad, ecg_stream_t stream) {
+ECG_API int ecg_conv1d_bwd_data_ld(const float *dy, int ldy, const float *w_bwd, float *dx, int N,
+                                   int C_in, int C_out, int L, int K, int pad, ecg_stream_t stream) {
     int rc = check_conv_shape(N, C_in, C_out, L, K, pad);
     if (rc) return rc;
     ECG_REQUIRE(dy && w_bwd && dx, "conv1d_bwd_data: null pointer");
     const int Lo = L + 2 * pad - K + 1, padb = K - 1 - pad;
+    ECG_REQUIRE(ldy >= Lo, "conv1d_bwd_data: dY row stride %d < row length %d", ldy, Lo);
     if (mfma_fwd_supported(C_out, C_in, K, padb))
-        return mfma_fwd(dy, w_bwd, nullptr, dx, nullptr, N, C_out, C_in, Lo, K, padb, as_stream(stream));
+        return mfma_fwd(dy, ldy, w_bwd, nullptr, dx, nullptr, N, C_out, C_in, Lo, K, padb, as_stream(stream));
+    ECG_REQUIRE(ldy == Lo, "conv1d_bwd_data: this shape needs dense dY rows (stride %d != %d); "
+                "use the stride ecg_conv1d_dy_row_stride returns", ldy, Lo);
     return direct_fwd(dy, w_bwd, nullptr, dx, nullptr, N, C_out, C_in, Lo, K, padb, as_stream(stream));
+}
+
+ECG_API int ecg_conv1d_bwd_data(const float *dy, const float *w_bwd, float *dx, int N, int C_in,
+                                int C_out, int L, int K, int pad, ecg_stream_t stream) {
+    return ecg_conv1d_bwd_data_ld(dy, L + 2 * pad - K + 1, w_bwd, dx, N, C_in, C_out, L, K, pad, stream);
 }
 
 ECG_API size_t ecg_conv1d_bwd_weight_ws_floats(int N, int C_in, int C_out, int L, int K, int pad) {
@@ -95,15 +116,26 @@ ECG_API size_t ecg_conv1d_bwd_weight_ws_floats(int N, int C_in, int C_out, int L
     return direct_wgrad_ws_floats(N, C_in, C_out, K);
 }
 
-ECG_API int ecg_conv1d_bwd_weight_bias(const float *dy, const float *x, float *dw, float *db,
-                                       float *ws, int N, int C_in, int C_out, int L, int K, int pad,
-                                       ecg_stream_t stream) {
+ECG_API int ecg_conv1d_bwd_weight_bias_ld(const float *dy, int ldy, const float *x, float *dw,
+                                          float *db, float *ws, int N, int C_in, int C_out, int L,
+                                          int K, int pad, ecg_stream_t stream) {
     int rc = check_conv_shape(N, C_in, C_out, L, K, pad);
     if (rc) return rc;
     ECG_REQUIRE(dy && x && dw && ws, "conv1d_bwd_weight_bias: null pointer");
+    const int Lo = L + 2 * pad - K + 1;
+    ECG_REQUIRE(ldy >= Lo, "conv1d_bwd_weight_bias: dY row stride %d < row length %d", ldy, Lo);
     if (mfma_wgrad_supported(C_in, C_out, K, pad))
-        return mfma_wgrad(dy, x, dw, db, ws, N, C_in, C_out, L, K, pad, as_stream(stream));
+        return mfma_wgrad(dy, ldy, x, dw, db, ws, N, C_in, C_out, L, K, pad, as_stream(stream));
+    ECG_REQUIRE(ldy == Lo, "conv1d_bwd_weight_bias: this shape needs dense dY rows (stride %d != %d); "
+                "use the stride ecg_conv1d_dy_row_stride returns", ldy, Lo);
     return direct_wgrad(dy, x, dw, db, ws, N, C_in, C_out, L, K, pad, as_stream(stream));
+}
+
+ECG_API int ecg_conv1d_bwd_weight_bias(const float *dy, const float *x, float *dw, float *db,
+                                       float *ws, int N, int C_in, int C_out, int L, int K, int pad,
+                                       ecg_stream_t stream) {
+    return ecg_conv1d_bwd_weight_bias_ld(dy, L + 2 * pad - K + 1, x, dw, db, ws, N, C_in, C_out, L, K,
+                                         pad, stream);
 }
 
 ECG_API int ecg_conv1d_bn_relu_pool_eval_supported(int C_in, int C_out, int K, int pad) {

@@ -60,8 +60,8 @@ struct EvalEpi { const float *gamma, *beta, *mean, *var; float eps; };
 template <int CO_T, int T_T, int WCO, int WT, int EPI>
 __global__ __launch_bounds__(256, 2) void conv1d_mfma_fwd_kernel(
     const float *__restrict__ x, const float *__restrict__ wp, const float *__restrict__ bias,
-    float *__restrict__ y, float *__restrict__ partials, int Cin, int Cout, int L, int Lo, int pad,
-    int P, EvalEpi ev) {
+    float *__restrict__ y, float *__restrict__ partials, int Cin, int Cout, int L, int ldx, int Lo,
+    int pad, int P, EvalEpi ev) {
     constexpr bool STATS = (EPI == EPI_STATS);
     static_assert(WCO * WT == 4, "4 waves per workgroup");
     constexpr int KK = kKM, CI_C = 4, NST = KK * CI_C / 2;
@@ -87,7 +87,7 @@ __global__ __launch_bounds__(256, 2) void conv1d_mfma_fwd_kernel(
     const int half = lane >> 5, l31 = lane & 31;
     const int t0 = blockIdx.x * T_T, co0 = blockIdx.y * CO_T, n = blockIdx.z;
     const int wco = (wave / WT) * (CO_T / WCO), wt = (wave % WT) * (T_T / WT);
-    const float *xn = x + (size_t)n * Cin * L;
+    const float *xn = x + (size_t)n * Cin * ldx;     // ldx >= L: row stride of the input tensor
 
     f32x16 acc[MC][MT];
 #pragma unroll
@@ -113,7 +113,7 @@ __global__ __launch_bounds__(256, 2) void conv1d_mfma_fwd_kernel(
         const int e = min(tid + 256 * j, XEL - 1);
         const int ci = e / XS, pos = e - ci * XS;
         const int s = t0 - pad + pos;
-        xoff[j] = ci * L + min(max(s, 0), L - 1);
+        xoff[j] = ci * ldx + min(max(s, 0), L - 1);
         xmask |= ((s >= 0) && (s < L)) ? (1u << j) : 0u;
     }
     float xreg[XLOADS];
@@ -124,7 +124,7 @@ __global__ __launch_bounds__(256, 2) void conv1d_mfma_fwd_kernel(
                 (const __attribute__((address_space(1))) void *)(wp + (size_t)ci0 * Cout + co0 + woff[j]),
                 (__attribute__((address_space(3))) void *)(img + (j * 4 + wave) * 256), 16, 0, 0);
     };
-    auto load_x = [&](int j, int ci0) { xreg[j] = xn[(size_t)ci0 * L + xoff[j]]; };
+    auto load_x = [&](int j, int ci0) { xreg[j] = xn[(size_t)ci0 * ldx + xoff[j]]; };
     auto commit_x = [&](int j, float *img) {
         const int e = tid + 256 * j;
         const unsigned keep = 0u - ((xmask >> j) & 1u);
@@ -274,14 +274,14 @@ int mfma_fwd_stat_partials(int N, int Cin, int Cout, int Lo) {
 
 template <int CO_T, int T_T, int WCO, int WT>
 static void launch_fwd(const float *x, const float *wp, const float *bias, float *y,
-                       float *partials, const EvalEpi *ev, int N, int Cin, int Cout, int L, int Lo,
-                       int pad, hipStream_t st) {
+                       float *partials, const EvalEpi *ev, int N, int Cin, int Cout, int L, int ldx,
+                       int Lo, int pad, hipStream_t st) {
     dim3 grid(cdiv(Lo, T_T), Cout / CO_T, N), block(256);
     const int P = N * (int)grid.x;
     const EvalEpi none{nullptr, nullptr, nullptr, nullptr, 0.f};
 #define ECG_FWD(MODE, EV) \
     hipLaunchKernelGGL((conv1d_mfma_fwd_kernel<CO_T, T_T, WCO, WT, MODE>), grid, block, 0, st, x, wp, \
-                       bias, y, partials, Cin, Cout, L, Lo, pad, P, EV)
+                       bias, y, partials, Cin, Cout, L, ldx, Lo, pad, P, EV)
     if (ev) ECG_FWD(EPI_EVAL, *ev);
     else if (partials) ECG_FWD(EPI_STATS, none);
     else ECG_FWD(EPI_PLAIN, none);
@@ -289,20 +289,21 @@ static void launch_fwd(const float *x, const float *wp, const float *bias, float
 }
 
 static int mfma_fwd_any(const float *x, const float *wp, const float *bias, float *y,
-                        float *partials, const EvalEpi *ev, int N, int Cin, int Cout, int L, int K,
-                        int pad, hipStream_t st) {
+                        float *partials, const EvalEpi *ev, int N, int Cin, int Cout, int L, int ldx,
+                        int K, int pad, hipStream_t st) {
     const int Lo = L + 2 * pad - K + 1;
     const FwdCfg c = fwd_cfg(N, Cout, Lo);
     if (c.co_t == 64)
-        launch_fwd<64, 128, 2, 2>(x, wp, bias, y, partials, ev, N, Cin, Cout, L, Lo, pad, st);
+        launch_fwd<64, 128, 2, 2>(x, wp, bias, y, partials, ev, N, Cin, Cout, L, ldx, Lo, pad, st);
     else
-        launch_fwd<32, 256, 1, 4>(x, wp, bias, y, partials, ev, N, Cin, Cout, L, Lo, pad, st);
+        launch_fwd<32, 256, 1, 4>(x, wp, bias, y, partials, ev, N, Cin, Cout, L, ldx, Lo, pad, st);
     return check_launch("conv1d_mfma_fwd_kernel");
 }
 
-int mfma_fwd(const float *x, const float *wp, const float *bias, float *y, float *partials, int N,
-             int Cin, int Cout, int L, int K, int pad, hipStream_t st) {
-    return mfma_fwd_any(x, wp, bias, y, partials, nullptr, N, Cin, Cout, L, K, pad, st);
+// ldx >= L is the row stride of x (dgrad reads a row-padded dY through it)
+int mfma_fwd(const float *x, int ldx, const float *wp, const float *bias, float *y, float *partials,
+             int N, int Cin, int Cout, int L, int K, int pad, hipStream_t st) {
+    return mfma_fwd_any(x, wp, bias, y, partials, nullptr, N, Cin, Cout, L, ldx, K, pad, st);
 }
 
 // eval-mode ConvBlock in one launch: p = MaxPool2(ReLU(BN_running(conv(x))))
@@ -310,7 +311,7 @@ int mfma_fwd_eval_pool(const float *x, const float *wp, const float *bias, const
                        const float *beta, const float *mean, const float *var, float eps, float *p,
                        int N, int Cin, int Cout, int L, int K, int pad, hipStream_t st) {
     const EvalEpi ev{gamma, beta, mean, var, eps};
-    return mfma_fwd_any(x, wp, bias, p, nullptr, &ev, N, Cin, Cout, L, K, pad, st);
+    return mfma_fwd_any(x, wp, bias, p, nullptr, &ev, N, Cin, Cout, L, L, K, pad, st);
 }
 
 // =======================================================================================
@@ -328,7 +329,7 @@ int mfma_fwd_eval_pool(const float *x, const float *wp, const float *bias, const
 template <int M_T, int R_T, int WM, int WR, int WK, int T_T, int KK>
 __global__ __launch_bounds__(256, 2) void conv1d_mfma_wgrad_kernel(
     const float *__restrict__ dy, const float *__restrict__ x, float *__restrict__ slab, int N,
-    int Cin, int Cout, int L, int Lo, int pad, int S) {
+    int Cin, int Cout, int L, int Lo, int ldy, int pad, int S) {
     static_assert(WM * WR * WK == 4, "4 waves per workgroup");
     constexpr int MC = M_T / WM / 32, MR = R_T / WR / 32;
     constexpr int TW = T_T / WK;                        // t range of one wave per staged tile
@@ -403,9 +404,9 @@ __global__ __launch_bounds__(256, 2) void conv1d_mfma_wgrad_kernel(
     auto stage_setup = [&](int it) {
         const int n = n_begin + it / ntt;
         t0 = (it % ntt) * T_T;
-        dyn = dy + ((size_t)n * Cout + co0) * Lo + t0;
+        dyn = dy + ((size_t)n * Cout + co0) * ldy + t0;
         xn = x + (size_t)n * Cin * L;
-        dvoff = drow0 * Lo + min(dtt, Lo - 1 - t0);           // same VGPR offset for every dY load
+        dvoff = drow0 * ldy + min(dtt, Lo - 1 - t0);          // same VGPR offset for every dY load
         dmask = 0;
 #pragma unroll
         for (int q = 0; q < PPR; ++q) dmask |= (t0 + dtt + 256 * q < Lo) ? (1u << q) : 0u;
@@ -414,8 +415,8 @@ __global__ __launch_bounds__(256, 2) void conv1d_mfma_wgrad_kernel(
         if (o < DLOADS) {
             // row = drow0 + (o/PPR)*RPP, tt = dtt + (o%PPR)*256: the (o-dependent) part is uniform
             const int extra = (o % PPR) * 256;
-            const float *pj = dyn + (size_t)(o / PPR) * RPP * Lo;
-            dreg[o] = pj[PPR == 1 ? dvoff : drow0 * Lo + min(dtt + extra, Lo - 1 - t0)];
+            const float *pj = dyn + (size_t)(o / PPR) * RPP * ldy;
+            dreg[o] = pj[PPR == 1 ? dvoff : drow0 * ldy + min(dtt + extra, Lo - 1 - t0)];
         } else {
             const int j = o - DLOADS;
             const int sidx = t0 + xpos[j];
@@ -571,6 +572,210 @@ __global__ __launch_bounds__(256, 2) void conv1d_mfma_wgrad_kernel(
     }
 }
 
+// ---------------------------------------------------------------------------------------
+// Weight gradient, dY streamed by LDS-DMA.  Needs a ROW-PADDED dY: row stride ldy a multiple of
+// 64 floats with zeros in [Lo, ldy) (ecg_bn_relu_pool_bwd_ld writes it that way), 16-byte aligned
+// base.  Then every (n, 64-wide t tile) of dY is M_T/4 whole 1 KB wave transfers straight into LDS
+// (no VGPRs, no ds_write, no tail masks: the pad supplies the zeros that cancel the garbage x
+// columns of a ragged last tile).
+//   LDS dY image [M_T][64] floats, 16-byte chunk c of row m stored at chunk c ^ (m & 15): the
+//   ds_read_b128 of the A fragments is conflict-free.  K-index assignment inside a group of four
+//   reduction steps (8 consecutive t): lane half h owns t = 8g + 4h + j at step j, so ONE b128
+//   read per lane feeds four MFMA steps.  The x tile (B operand) is register-staged as in the
+//   kernel above and read at +4h+j.
+// grid = (ceil(R/R_T), Cout/M_T, S); T_T = 64; slab layout as above.
+template <int M_T, int R_T, int WM, int WR, int KK>
+__global__ __launch_bounds__(256, 2) void conv1d_mfma_wgrad_dma_kernel(
+    const float *__restrict__ dy, const float *__restrict__ x, float *__restrict__ slab, int N,
+    int Cin, int Cout, int L, int Lo, int ldy, int pad, int S) {
+    static_assert(WM * WR == 4, "4 waves per workgroup");
+    constexpr int T_T = 64;
+    constexpr int MC = M_T / WM / 32, MR = R_T / WR / 32;
+    constexpr int NST = T_T / 2, NGRP = NST / 4;        // 32 reduction steps = 8 groups of 4
+    constexpr int XSPAN = T_T + KK - 1;
+    constexpr int XS = ((XSPAN - KK + 31) / 32) * 32 + KK;   // >= XSPAN and == KK (mod 32)
+    constexpr int NCI = (R_T + KK - 2) / KK + 1;
+    constexpr int XEL = NCI * XS, XLOADS = (XEL + 255) / 256;
+    constexpr int AEL = M_T * T_T;                      // floats of the dY image
+    constexpr int NDMA = AEL / 256;                     // 1 KB pieces (4 rows each)
+    constexpr int DPW = NDMA / 4;                       // pieces per wave per stage
+    constexpr int IMG = ((AEL + XEL + 63) / 64) * 64;   // keeps image 1 16-byte aligned
+    static_assert(XS >= XSPAN, "x row stride too small");
+    static_assert(NDMA % 4 == 0, "dY image must split evenly over the four waves");
+    static_assert(XLOADS <= 32, "mask bits");
+    static_assert(NST >= 2 * XLOADS + DPW, "not enough steps to spread the staging over");
+
+    __shared__ __attribute__((aligned(1024))) float lds[2 * IMG];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int half = lane >> 5, l31 = lane & 31;
+    const int R = Cin * KK;
+    const int r0 = blockIdx.x * R_T, co0 = blockIdx.y * M_T, s = blockIdx.z;
+    const int wr = wave % WR, wm = wave / WR;
+    const int wm0 = wm * (M_T / WM), wr0 = wr * (R_T / WR);
+    const int ci_base = r0 / KK;
+    const int n_begin = (int)((long long)N * s / S), n_end = (int)((long long)N * (s + 1) / S);
+
+    int xcol[MR];
+#pragma unroll
+    for (int j = 0; j < MR; ++j) {
+        int r = r0 + wr0 + 32 * j + l31;
+        if (r >= R) r = R - 1;                 // clamped columns compute garbage that is never stored
+        const int ci = r / KK;
+        xcol[j] = (ci - ci_base) * XS + (r - ci * KK);
+    }
+
+    f32x16 acc[MC][MR];
+#pragma unroll
+    for (int a = 0; a < MC; ++a)
+#pragma unroll
+        for (int b = 0; b < MR; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+    float bsum[MC];
+#pragma unroll
+    for (int a = 0; a < MC; ++a) bsum[a] = 0.f;
+    const bool want_bias = (blockIdx.x == 0) && (wr == 0);
+
+    // ---- staging: loop-invariant per-thread pieces ------------------------------------------
+    int doff[DPW];          // dY piece j of this wave: element offset from the stage base
+#pragma unroll
+    for (int j = 0; j < DPW; ++j) {
+        const int row = (j * 4 + wave) * 4 + (lane >> 4);           // row inside the M_T tile
+        doff[j] = row * ldy + (((lane & 15) ^ (row & 15)) << 2);    // LDS chunk c <- global chunk c^(row&15)
+    }
+    int xci[XLOADS], xpos[XLOADS];
+#pragma unroll
+    for (int j = 0; j < XLOADS; ++j) {
+        const int e = min(tid + 256 * j, XEL - 1);
+        xci[j] = min(ci_base + e / XS, Cin - 1) * L;
+        xpos[j] = e % XS - pad;
+    }
+    float xreg[XLOADS];
+    unsigned xmask = 0, cxmask = 0;
+    const int ntt = (Lo + T_T - 1) / T_T;
+    const int total = (n_end - n_begin) * ntt;
+
+    // stage coordinates advance incrementally (uniform, no division in the loop)
+    int sn = n_begin, stt = 0;          // stage whose x tile is loaded next
+    int dn = n_begin, dtt = 0;          // stage whose dY tile is DMA'd next
+    auto advance = [&]() { if (++stt == ntt) { stt = 0; ++sn; } };
+    auto dma_a = [&](int j, float *img) {               // one 1 KB piece of stage (dn, dtt)'s dY tile
+        const float *base = dy + ((size_t)min(dn, n_end - 1) * Cout + co0) * ldy + dtt * T_T;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(base + doff[j]),
+                                         (__attribute__((address_space(3))) void *)(img + (j * 4 + wave) * 256),
+                                         16, 0, 0);
+    };
+    auto load_x = [&](int j) {                          // x tile element of stage (sn, stt)
+        const float *xn = x + (size_t)min(sn, n_end - 1) * Cin * L;
+        const int sidx = stt * T_T + xpos[j];
+        xreg[j] = xn[xci[j] + min(max(sidx, 0), L - 1)];
+        const unsigned bit = ((sidx >= 0) && (sidx < L)) ? (1u << j) : 0u;
+        xmask = (j == 0) ? bit : (xmask | bit);
+    };
+    auto commit_x = [&](int j, float *img) {
+        const int e = tid + 256 * j;
+        const unsigned keep = 0u - ((cxmask >> j) & 1u);
+        if (256 * (j + 1) <= XEL || e < XEL)
+            img[AEL + e] = __uint_as_float(__float_as_uint(xreg[j]) & keep);
+    };
+
+    // prologue: stage 0 -> image 0, x tile of stage 1 -> registers
+    if (total > 0) {
+#pragma unroll
+        for (int j = 0; j < DPW; ++j) dma_a(j, lds);
+#pragma unroll
+        for (int j = 0; j < XLOADS; ++j) load_x(j);
+        cxmask = xmask;
+#pragma unroll
+        for (int j = 0; j < XLOADS; ++j) commit_x(j, lds);
+        advance();
+        dn = sn; dtt = stt;                             // stage 1
+#pragma unroll
+        for (int j = 0; j < XLOADS; ++j) load_x(j);
+        advance();                                      // stage 2
+    }
+    __syncthreads();
+
+    const int aoff = (wm0 + l31) * T_T, swz = (l31 & 15) << 2;
+    for (int it = 0; it < total; ++it) {
+        const float *dys = lds + (it & 1) * IMG, *xs = dys + AEL;
+        float *nxt = lds + ((it + 1) & 1) * IMG;
+        cxmask = xmask;                                    // mask of stage it+1 (now in registers)
+
+        const float *arow = dys + aoff;
+        const float *brow = xs + 4 * half;
+        auto lda = [&](int g, f32x4 *a) {                  // group g: chunk 2g+half, swizzled
+#pragma unroll
+            for (int i = 0; i < MC; ++i)
+                a[i] = *reinterpret_cast<const f32x4 *>(arow + 32 * i * T_T + ((((2 * g) << 2) + (half << 2)) ^ swz));
+        };
+        auto ldb = [&](int st, float *b) {
+            const int tp = 8 * (st >> 2) + (st & 3);
+#pragma unroll
+            for (int j = 0; j < MR; ++j) b[j] = brow[xcol[j] + tp];
+        };
+        f32x4 aq_c[MC], aq_n[MC];
+        float b_c[MR], b_n[MR];
+        lda(0, aq_c);
+        ldb(0, b_c);
+#pragma unroll
+        for (int st = 0; st < NST; ++st) {
+            const int j4 = st & 3;
+            ldb(st + 1 < NST ? st + 1 : 0, b_n);
+            if (j4 == 2 && (st >> 2) + 1 < NGRP) lda((st >> 2) + 1, aq_n);
+            // staging, one operation per step: x commits, x loads, then the dY DMA pieces.
+            // UNCONDITIONAL (stage coordinates are clamped, the last stages restage a valid tile
+            // nobody reads): under a branch hipcc puts s_waitcnt vmcnt(0) in front of every load.
+            if (st < XLOADS) commit_x(st, nxt);
+            else if (st < 2 * XLOADS) load_x(st - XLOADS);
+            else if (st < 2 * XLOADS + DPW) dma_a(st - 2 * XLOADS, nxt);
+            __builtin_amdgcn_sched_barrier(0);         // keep reads + staging ABOVE these MFMAs
+#pragma unroll
+            for (int i = 0; i < MC; ++i) bsum[i] += aq_c[i][j4];
+#pragma unroll
+            for (int i = 0; i < MC; ++i)
+#pragma unroll
+                for (int j = 0; j < MR; ++j) acc[i][j] = mfma32(aq_c[i][j4], b_c[j], acc[i][j]);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < MR; ++j) b_c[j] = b_n[j];
+            if (j4 == 3) {
+#pragma unroll
+                for (int i = 0; i < MC; ++i) aq_c[i] = aq_n[i];
+            }
+        }
+        dn = sn; dtt = stt;
+        advance();
+        __syncthreads();      // image it&1 free again; image (it+1)&1 complete (vmcnt(0) + barrier)
+    }
+
+    if (want_bias) {
+#pragma unroll
+        for (int i = 0; i < MC; ++i) bsum[i] += __shfl_xor(bsum[i], 32, 64);
+    }
+    const size_t wslab = (size_t)Cout * R;
+    float *out = slab + (size_t)s * wslab;
+#pragma unroll
+    for (int i = 0; i < MC; ++i)
+#pragma unroll
+        for (int j = 0; j < MR; ++j) {
+            const int r = r0 + wr0 + 32 * j + l31;
+            if (r < R) {
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    const int co = co0 + wm0 + 32 * i + acc_row(q, half);
+                    out[(size_t)co * R + r] = acc[i][j][q];
+                }
+            }
+        }
+    if (want_bias && half == 0) {
+#pragma unroll
+        for (int i = 0; i < MC; ++i)
+            slab[(size_t)S * wslab + (size_t)s * Cout + co0 + wm0 + 32 * i + l31] = bsum[i];
+    }
+}
+
 // conv1d_direct.hip: dw[i] = sum_s slab[s][i] in fixed order
 int wgrad_reduce(const float *ws, float *dw, float *db, size_t wslab, int Cout, int S,
                  hipStream_t st);
@@ -604,21 +809,28 @@ size_t mfma_wgrad_ws_floats(int N, int Cin, int Cout, int L, int K) {
     return (size_t)c.splits * ((size_t)Cout * Cin * K + Cout);
 }
 
-int mfma_wgrad(const float *dy, const float *x, float *dw, float *db, float *ws, int N, int Cin,
-               int Cout, int L, int K, int pad, hipStream_t st) {
+// dY rows that the DMA kernel can stream: 64-float multiples with a zero pad (see the kernel)
+bool mfma_wgrad_dma_supported(int Cin, int Cout, int K) {
+    (void)Cin;
+    return K == kKM && Cout % 64 == 0;
+}
+
+int mfma_wgrad(const float *dy, int ldy, const float *x, float *dw, float *db, float *ws, int N,
+               int Cin, int Cout, int L, int K, int pad, hipStream_t st) {
     const int Lo = L + 2 * pad - K + 1;
     const int R = Cin * K;
     const WgCfg c = wgrad_cfg(N, Cin, Cout);
     dim3 grid(cdiv(R, c.r_t), Cout / c.m_t, c.splits), block(256);
-    if (c.m_t == 128)
-        hipLaunchKernelGGL((conv1d_mfma_wgrad_kernel<128, 128, 2, 2, 1, 64, kKM>), grid, block, 0, st,
-                           dy, x, ws, N, Cin, Cout, L, Lo, pad, c.splits);
-    else if (c.m_t == 64)
-        hipLaunchKernelGGL((conv1d_mfma_wgrad_kernel<64, 128, 2, 2, 1, 64, kKM>), grid, block, 0, st,
-                           dy, x, ws, N, Cin, Cout, L, Lo, pad, c.splits);
-    else
-        hipLaunchKernelGGL((conv1d_mfma_wgrad_kernel<32, 192, 1, 1, 4, 128, kKM>), grid, block, 0, st,
-                           dy, x, ws, N, Cin, Cout, L, Lo, pad, c.splits);
+    const bool dma = mfma_wgrad_dma_supported(Cin, Cout, K) && ldy % 64 == 0 && ldy >= cdiv(Lo, 64) * 64 &&
+                     (reinterpret_cast<uintptr_t>(dy) & 15) == 0;
+#define ECG_WG(KERNEL) \
+    hipLaunchKernelGGL(KERNEL, grid, block, 0, st, dy, x, ws, N, Cin, Cout, L, Lo, ldy, pad, c.splits)
+    if (dma && c.m_t == 128) ECG_WG((conv1d_mfma_wgrad_dma_kernel<128, 128, 2, 2, kKM>));
+    else if (dma) ECG_WG((conv1d_mfma_wgrad_dma_kernel<64, 128, 2, 2, kKM>));
+    else if (c.m_t == 128) ECG_WG((conv1d_mfma_wgrad_kernel<128, 128, 2, 2, 1, 64, kKM>));
+    else if (c.m_t == 64) ECG_WG((conv1d_mfma_wgrad_kernel<64, 128, 2, 2, 1, 64, kKM>));
+    else ECG_WG((conv1d_mfma_wgrad_kernel<32, 192, 1, 1, 4, 128, kKM>));
+#undef ECG_WG
     int rc = check_launch("conv1d_mfma_wgrad_kernel");
     if (rc) return rc;
     return wgrad_reduce(ws, dw, db, (size_t)Cout * R, Cout, c.splits, st);

@@ -27,6 +27,9 @@ SIGNATURES = {
     "ecg_conv1d_bwd_data": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "ecg_conv1d_bwd_weight_ws_floats": (_sz, [_i, _i, _i, _i, _i, _i]),
     "ecg_conv1d_bwd_weight_bias": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "ecg_conv1d_dy_row_stride": (_i, [_i] * 6),
+    "ecg_conv1d_bwd_data_ld": (_i, [_vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "ecg_conv1d_bwd_weight_bias_ld": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "ecg_conv1d_bf16_supported": (_i, [_i, _i, _i, _i]),
     "ecg_conv1d_bf16_packed_elems": (_sz, [_i, _i, _i]),
     "ecg_conv1d_pack_weights_bf16": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),
@@ -40,10 +43,12 @@ SIGNATURES = {
     "ecg_bn_relu_pool_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "ecg_bn_relu_pool_bwd_ws_floats": (_sz, [_i, _i, _i]),
     "ecg_bn_relu_pool_bwd": (_i, [_vp] * 10 + [_i, _i, _i, _i, _vp]),
+    "ecg_bn_relu_pool_bwd_ld": (_i, [_vp] * 7 + [_i] + [_vp] * 3 + [_i, _i, _i, _i, _vp]),
     "ecg_conv1d_bn_relu_pool_eval_supported": (_i, [_i, _i, _i, _i]),
     "ecg_conv1d_bn_relu_pool_eval_fwd": (_i, [_vp] * 7 + [_f, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "ecg_bn_relu_pool_gap_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "ecg_bn_relu_pool_gap_bwd": (_i, [_vp] * 10 + [_i, _i, _i, _i, _vp]),
+    "ecg_bn_relu_pool_gap_bwd_ld": (_i, [_vp] * 7 + [_i] + [_vp] * 3 + [_i, _i, _i, _i, _vp]),
     "ecg_bn_apply_fwd": (_i, [_vp] * 6 + [_i, _i, _i, _vp]),
     "ecg_bn_bwd_ws_floats": (_sz, [_i, _i, _i]),
     "ecg_bn_bwd": (_i, [_vp] * 9 + [_i, _i, _i, _i, _vp]),

@@ -182,9 +182,13 @@ def conv1d_forward_raw(x, w_fwd, bias, Co, K, pad, want_stats):
     return y, partials, P
 
 
-def conv1d_backward_raw(x, dy, w_shape, w_bwd, pad, need_dx, need_db=True, overlap=False, bf16=False):
+def conv1d_backward_raw(x, dy, w_shape, w_bwd, pad, need_dx, need_db=True, overlap=False, bf16=False,
+                        ldy=None):
+    """dy is [N, C_out, ldy] with ldy >= Lo (row-padded, zero pad) when ldy is given."""
     N, Ci, Lin = x.shape
     Co, _, K = w_shape
+    if ldy is None:
+        ldy = Lin + 2 * pad - K + 1
     main = torch.cuda.current_stream()
     ws_floats = max(1, _query("ecg_conv1d_bwd_weight_ws_floats", N, Ci, Co, Lin, K, pad))
 
@@ -192,7 +196,7 @@ def conv1d_backward_raw(x, dy, w_shape, w_bwd, pad, need_dx, need_db=True, overl
         dw = _empty(x, Co, Ci, K)
         db = _empty(x, Co) if need_db else None
         ws = _empty(x, ws_floats)
-        _call("ecg_conv1d_bwd_weight_bias", _f32(dy), _f32(x), _f32(dw), _f32(db), _f32(ws),
+        _call("ecg_conv1d_bwd_weight_bias_ld", _f32(dy), ldy, _f32(x), _f32(dw), _f32(db), _f32(ws),
               N, Ci, Co, Lin, K, pad, _st())
         return dw, db
 
@@ -215,7 +219,8 @@ def conv1d_backward_raw(x, dy, w_shape, w_bwd, pad, need_dx, need_db=True, overl
         if bf16:
             _call("ecg_conv1d_bwd_data_bf16", _f32(dy), L.ptr(w_bwd), _f32(dx), N, Ci, Co, Lin, K, pad, _st())
         else:
-            _call("ecg_conv1d_bwd_data", _f32(dy), _f32(w_bwd), _f32(dx), N, Ci, Co, Lin, K, pad, _st())
+            _call("ecg_conv1d_bwd_data_ld", _f32(dy), ldy, _f32(w_bwd), _f32(dx), N, Ci, Co, Lin, K, pad,
+                  _st())
     return dx, dw, db
 
 
@@ -308,14 +313,19 @@ class ConvBlockFn(torch.autograd.Function):
         x, w, y, gamma, beta, mean, invstd = ctx.saved_tensors
         dp = _contig(dp)
         N, Co, Lo = y.shape
-        dy = torch.empty_like(y)
+        # dY never leaves this function: give it the row stride the conv gradients stream best
+        # (rows padded to 64 floats, zero pad -> LDS-DMA in the weight gradient)
+        need_dx = ctx.needs_input_grad[0]
+        ldy = Lo if (ctx.bf16 and need_dx) else _query("ecg_conv1d_dy_row_stride", N, x.shape[1], Co,
+                                                       x.shape[2], w.shape[2], ctx.pad)
+        dy = _empty(y, N, Co, ldy)
         dgamma, dbeta = _empty(y, Co), _empty(y, Co)
         ws = _empty(y, _query("ecg_bn_relu_pool_bwd_ws_floats", N, Co, Lo))
-        _call("ecg_bn_relu_pool_gap_bwd" if ctx.gap else "ecg_bn_relu_pool_bwd", _f32(y), _f32(dp),
-              _f32(gamma), _f32(beta), _f32(mean), _f32(invstd), _f32(dy), _f32(dgamma), _f32(dbeta),
-              _f32(ws), N, Co, Lo, 1 if ctx.batch_stats else 0, _st())
-        dx, dw, db = conv1d_backward_raw(x, dy, w.shape, ctx.w_bwd, ctx.pad, ctx.needs_input_grad[0],
-                                         overlap=True, bf16=ctx.bf16)
+        _call("ecg_bn_relu_pool_gap_bwd_ld" if ctx.gap else "ecg_bn_relu_pool_bwd_ld", _f32(y), _f32(dp),
+              _f32(gamma), _f32(beta), _f32(mean), _f32(invstd), _f32(dy), ldy, _f32(dgamma),
+              _f32(dbeta), _f32(ws), N, Co, Lo, 1 if ctx.batch_stats else 0, _st())
+        dx, dw, db = conv1d_backward_raw(x, dy, w.shape, ctx.w_bwd, ctx.pad, need_dx,
+                                         overlap=True, bf16=ctx.bf16, ldy=ldy)
         return dx, dw, db, dgamma, dbeta, None, None, None, None, None, None, None, None, None
 
 

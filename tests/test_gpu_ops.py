@@ -138,6 +138,78 @@ def test_bn_relu_pool_fwd_bwd(hip, oracle, shape, train):
         assert np.array_equal(host(dy) == 0, rdy == 0)
 
 
+# (N, Ci, Co, L): row-padded dY (ldy = 64-multiple, zero pad) through the _ld entry points — the
+# layout ConvBlockFn.backward uses so that the weight gradient streams dY by LDS-DMA
+@pytest.mark.parametrize("case", [(3, 32, 64, 250), (2, 64, 128, 125), (5, 128, 256, 62), (2, 64, 128, 64),
+                                  (1, 32, 64, 1), (4, 128, 256, 129), (37, 64, 128, 70)])
+def test_row_padded_dy_entry_points(hip, oracle, case):
+    from ecg_hip import _lib as L
+    N, Ci, Co, Lin = case
+    K, pad = 15, 7
+    rng = np.random.default_rng(sum(case))
+    x = rng.standard_normal((N, Ci, Lin)).astype(np.float32)
+    w = (rng.standard_normal((Co, Ci, K)) / np.sqrt(Ci * K)).astype(np.float32)
+    dy = rng.standard_normal((N, Co, Lin)).astype(np.float32)
+    ldy = L.query("ecg_conv1d_dy_row_stride", N, Ci, Co, Lin, K, pad)
+    assert ldy % 64 == 0 and Lin <= ldy < Lin + 64
+    dyp = np.zeros((N, Co, ldy), np.float32)
+    dyp[:, :, :Lin] = dy
+    xd, wd, dyd = dev(x), dev(w), dev(dyp)
+    _, w_bwd = hip.conv1d_pack(wd)
+    dx, dw, db = hip.conv1d_backward_raw(xd, dyd, w.shape, w_bwd, pad, need_dx=True, ldy=ldy)
+    # identical arithmetic to the dense-row kernels: same products, same accumulation order per tile
+    dx0, dw0, db0 = hip.conv1d_backward_raw(xd, dev(dy), w.shape, w_bwd, pad, need_dx=True)
+    np.testing.assert_array_equal(host(dx), host(dx0))
+    np.testing.assert_allclose(host(dx), oracle.conv1d_bwd_data(dy, w, Lin, pad), atol=5e-5)
+    rdw, rdb = oracle.conv1d_bwd_weight(dy, x, K, pad)
+    scale = np.sqrt(N * Lin)
+    np.testing.assert_allclose(host(dw), rdw, atol=2e-6 * scale + 2e-5)
+    np.testing.assert_allclose(host(db), rdb, atol=2e-6 * scale + 2e-5)
+    np.testing.assert_allclose(host(dw), host(dw0), atol=2e-6 * scale + 2e-5)
+
+
+def test_row_padded_dy_is_refused_where_unsupported(hip):
+    from ecg_hip import _lib as L
+    assert L.query("ecg_conv1d_dy_row_stride", 4, 12, 32, 100, 15, 7) == 100     # block 0: dense rows
+    assert L.query("ecg_conv1d_dy_row_stride", 4, 7, 12, 50, 3, 1) == 50
+    x, dy = torch.zeros(2, 7, 50, device="cuda"), torch.zeros(2, 12, 64, device="cuda")
+    w_bwd = torch.zeros(3, 12, 7, device="cuda")
+    with pytest.raises(L.EcgHipError, match="dense dY rows"):
+        hip.conv1d_backward_raw(x, dy, (12, 7, 3), w_bwd, 1, need_dx=True, ldy=64)
+
+
+@pytest.mark.parametrize("shape", [(3, 64, 125), (2, 128, 62), (2, 64, 1000), (2, 32, 2), (1, 64, 63)])
+@pytest.mark.parametrize("gap", [False, True])
+def test_bn_relu_pool_bwd_writes_row_padded_dy(hip, oracle, shape, gap):
+    from ecg_hip import _lib as L
+    N, C, Lo = shape
+    rng = np.random.default_rng(N + C + Lo)
+    y = (rng.standard_normal(shape) * 1.5 + 0.3).astype(np.float32)
+    gamma = (1 + 0.2 * rng.standard_normal(C)).astype(np.float32)
+    beta = (0.2 * rng.standard_normal(C)).astype(np.float32)
+    mean, invstd = oracle.bn_stats(y)
+    g = rng.standard_normal((N, C) if gap else (N, C, Lo // 2)).astype(np.float32)
+    ldy = (Lo + 63) // 64 * 64
+    yd, gd, bd, md, isd, gg = map(dev, (y, gamma, beta, mean, invstd, g))
+    ws = torch.empty(L.query("ecg_bn_relu_pool_bwd_ws_floats", N, C, Lo), device="cuda")
+    outs = []
+    for stride in (Lo, ldy):
+        dy = torch.full((N, C, stride), float("nan"), device="cuda")       # the kernel must write every element
+        dgam, dbet = torch.empty(C, device="cuda"), torch.empty(C, device="cuda")
+        L.call("ecg_bn_relu_pool_gap_bwd_ld" if gap else "ecg_bn_relu_pool_bwd_ld",
+               *map(L.f32, (yd, gg, gd, bd, md, isd, dy)), stride, *map(L.f32, (dgam, dbet, ws)),
+               N, C, Lo, 1, L.stream())
+        outs.append((host(dy), host(dgam), host(dbet)))
+    (d0, g0, b0), (d1, g1, b1) = outs
+    np.testing.assert_array_equal(d1[:, :, :Lo], d0)
+    assert not d1[:, :, Lo:].any()                                          # zero pad, no NaN left
+    np.testing.assert_array_equal(g0, g1)
+    np.testing.assert_array_equal(b0, b1)
+    dp = np.repeat(g[:, :, None] / (Lo // 2), Lo // 2, axis=2).astype(np.float32) if gap else g
+    rdy, _, _ = oracle.bn_relu_pool_bwd(y, dp, gamma, beta, mean, invstd, True)
+    np.testing.assert_allclose(d0, rdy, atol=2e-5)
+
+
 def test_unfused_leaves_compose_to_fused(hip, oracle):
     """BatchNormFn -> ReLUFn -> MaxPool2Fn (hook path) equals the fused kernel, fwd and bwd."""
     torch.manual_seed(0)
