@@ -295,9 +295,21 @@ int ecg_adamw_step_graph(float *p, const float *g, float *m, float *v, size_t n,
                          float lr, float beta1, float beta2, float eps, float weight_decay,
                          float grad_scale, ecg_stream_t stream);
 
-/* Per-lead z-score of a window batch, (x-mean)/(std+1e-6) with population std —
- * src/datasets/ptbxl.py:122-127.  x [rows][T] -> out [rows][T]. */
-int ecg_zscore_rows(const float *x, float *out, int rows, int T, ecg_stream_t stream);
+/* ---- input pipeline: the step before the model -----------------------
+ * Reference: `_load_ecg` = wfdb.rdsamp + float32 cast + transpose (src/datasets/ptbxl.py:14-41) and
+ * `_normalize` (ptbxl.py:122-127), repeated in ptbxl_ecg_multimodal.py and ptbxl_af.py.
+ * Both entry points reproduce the reference's float32 arithmetic bit for bit (its per-lead sums run
+ * left to right because it normalises a transposed view).
+ *
+ * ecg_wfdb16_physical: WFDB format-16 digital samples d [B][T][leads] (the .dat layout: time-major,
+ * leads interleaved) -> physical units out [B][leads][T] = float32((d - baseline) / gain), gain and
+ * baseline per (window, lead) from the .hea signal lines; sample -32768 (format-16 "invalid") -> NaN.
+ * leads <= 16. */
+int ecg_wfdb16_physical(const int16_t *d, const double *gain, const int *baseline, float *out,
+                        int B, int T, int leads, ecg_stream_t stream);
+/* Per-lead z-score, (x-mean)/(std+1e-6) with population std.  x [rows][T] -> out [rows][T] (in place
+ * allowed); stats [rows][2] receives (mean, std + 1e-6) per row. */
+int ecg_zscore_rows(const float *x, float *out, float *stats, int rows, int T, ecg_stream_t stream);
 
 #ifdef __cplusplus
 }

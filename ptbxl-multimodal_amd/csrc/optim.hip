@@ -83,33 +83,6 @@ __global__ __launch_bounds__(256) void adamw_graph_kernel(float *__restrict__ p,
 }
 __global__ void adamw_step_bump_kernel(int *step_dev) { step_dev[0] += 1; }
 
-// One workgroup per (window, lead) row: mean and population std in double, then the affine.
-__global__ __launch_bounds__(256) void zscore_rows_kernel(const float *__restrict__ x,
-                                                          float *__restrict__ out, int T) {
-    __shared__ double red[4];
-    __shared__ double bc[2];
-    const float *r = x + (size_t)blockIdx.x * T;
-    float *o = out + (size_t)blockIdx.x * T;
-    const int tl = threadIdx.x, wave = tl >> 6, lane = tl & 63;
-    double a = 0.0;
-    for (int t = tl; t < T; t += 256) a += (double)r[t];
-    a = wave_sum(a);
-    if (lane == 0) red[wave] = a;
-    __syncthreads();
-    if (tl == 0) bc[0] = (red[0] + red[1] + red[2] + red[3]) / (double)T;
-    __syncthreads();
-    const double mu = bc[0];
-    double q = 0.0;
-    for (int t = tl; t < T; t += 256) { double d = (double)r[t] - mu; q += d * d; }
-    q = wave_sum(q);
-    if (lane == 0) red[wave] = q;
-    __syncthreads();
-    if (tl == 0) bc[1] = sqrt((red[0] + red[1] + red[2] + red[3]) / (double)T) + 1e-6;
-    __syncthreads();
-    const double sd = bc[1];
-    for (int t = tl; t < T; t += 256) o[t] = (float)(((double)r[t] - mu) / sd);
-}
-
 }  // namespace ecg
 
 using namespace ecg;
@@ -148,10 +121,4 @@ ECG_API int ecg_adamw_step_graph(float *p, const float *g, float *m, float *v, s
     if (rc) return rc;
     hipLaunchKernelGGL(adamw_step_bump_kernel, dim3(1), dim3(1), 0, st, step_dev);
     return check_launch("adamw_step_bump_kernel");
-}
-
-ECG_API int ecg_zscore_rows(const float *x, float *out, int rows, int T, ecg_stream_t stream) {
-    ECG_REQUIRE(x && out && rows > 0 && T > 0, "zscore_rows: bad argument");
-    hipLaunchKernelGGL(zscore_rows_kernel, dim3(rows), dim3(256), 0, as_stream(stream), x, out, T);
-    return check_launch("zscore_rows_kernel");
 }

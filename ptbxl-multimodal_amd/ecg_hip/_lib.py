@@ -71,7 +71,8 @@ SIGNATURES = {
     "ecg_linear_wgrad_grouped": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp]),
     "ecg_adamw_step": (_i, [_vp, _vp, _vp, _vp, _sz, _i, _f, _f, _f, _f, _f, _f, _vp]),
     "ecg_adamw_step_graph": (_i, [_vp, _vp, _vp, _vp, _sz, _vp, _f, _f, _f, _f, _f, _f, _vp]),
-    "ecg_zscore_rows": (_i, [_vp, _vp, _i, _i, _vp]),
+    "ecg_wfdb16_physical": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
+    "ecg_zscore_rows": (_i, [_vp, _vp, _vp, _i, _i, _vp]),
 }
 
 _lock = threading.Lock()

@@ -620,10 +620,29 @@ def sigmoid(x):
     return out
 
 
-def zscore_per_lead(x):
-    """(x - mean)/(std + 1e-6) per lead row, population std (reference src/datasets/ptbxl.py:122-127)."""
+def zscore_per_lead(x, out=None, return_stats=False):
+    """(x - mean)/(std + 1e-6) per lead row, population std, bit-identical to the reference's float32
+    numpy arithmetic (src/datasets/ptbxl.py:122-127).  `out` may alias x (in place)."""
     x = _contig(x)
     T = x.shape[-1]
-    out = torch.empty_like(x)
-    _call("ecg_zscore_rows", _f32(x), _f32(out), x.numel() // T, T, _st())
-    return out
+    rows = x.numel() // T
+    if out is None:
+        out = torch.empty_like(x)
+    stats = _empty(x, rows, 2)
+    _call("ecg_zscore_rows", _f32(x), _f32(out), _f32(stats), rows, T, _st())
+    return (out, stats) if return_stats else out
+
+
+def wfdb16_to_windows(d, gain, baseline, normalize=True):
+    """WFDB format-16 samples d int16 [B, T, leads] (time-major, as stored in .dat) + per-(window, lead)
+    gain (float64) / baseline (int32) [B, leads]  ->  fp32 windows [B, leads, T], per-lead z-scored:
+    `_load_ecg` + `_normalize` of the reference (src/datasets/ptbxl.py:14-41,122-127) on the GPU."""
+    if d.dtype != torch.int16 or gain.dtype != torch.float64 or baseline.dtype != torch.int32:
+        raise L.EcgHipError("wfdb16_to_windows: d must be int16, gain float64, baseline int32")
+    d, gain, baseline = _contig(d), _contig(gain), _contig(baseline)
+    B, T, leads = d.shape
+    if tuple(gain.shape) != (B, leads) or tuple(baseline.shape) != (B, leads):
+        raise L.EcgHipError("wfdb16_to_windows: gain/baseline must be [B, leads]")
+    x = torch.empty(B, leads, T, dtype=torch.float32, device=d.device)
+    _call("ecg_wfdb16_physical", L.ptr(d), L.ptr(gain), L.ptr(baseline), _f32(x), B, T, leads, _st())
+    return zscore_per_lead(x, out=x) if normalize else x

@@ -298,15 +298,6 @@ def test_adamw_flat_step_vs_oracle_and_torch(hip, oracle):
         np.testing.assert_allclose(host(p), tp.detach().numpy(), atol=2e-7, rtol=2e-6)
 
 
-def test_zscore_rows(hip):
-    g = golden("g3_eval_known_answer")
-    x = (g["ecg"][0] * 37.5 + 4.0).astype(np.float32)          # un-normalised-looking leads
-    out = host(hip.zscore_per_lead(dev(x)))
-    x64 = x.astype(np.float64)
-    ref = (x64 - x64.mean(axis=1, keepdims=True)) / (x64.std(axis=1, keepdims=True) + 1e-6)
-    np.testing.assert_allclose(out, ref, atol=2e-6)
-
-
 FULL = [(256, 12, 32, 1000), (256, 32, 64, 500), (256, 64, 128, 250), (256, 128, 256, 125)]
 
 
