@@ -55,6 +55,34 @@ __global__ __launch_bounds__(256) void wfdb16_physical_kernel(
     }
 }
 
+// Left-to-right walk over one row with the loads kept well ahead of the dependent add chain: the
+// row streams through two register batches of kNB float4 (the next batch is in flight while the
+// chain consumes the current one).  Loads are unconditional with clamped addresses; elements past
+// T are skipped at the chain.
+constexpr int kNB = 8;
+
+template <typename F>
+__device__ __forceinline__ void walk_row_vec(const float *__restrict__ r, int T, F &&step) {
+    const int n4 = T >> 2;                      // T % 4 == 0 on this path
+    const f32x4 *r4 = reinterpret_cast<const f32x4 *>(r);
+    f32x4 cur[kNB], nxt[kNB];
+#pragma unroll
+    for (int j = 0; j < kNB; ++j) cur[j] = r4[min(j, n4 - 1)];
+    for (int i = 0; i < n4; i += kNB) {
+#pragma unroll
+        for (int j = 0; j < kNB; ++j) nxt[j] = r4[min(i + kNB + j, n4 - 1)];
+#pragma unroll
+        for (int j = 0; j < kNB; ++j) {
+            if (i + j < n4) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) step(cur[j][k]);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < kNB; ++j) cur[j] = nxt[j];
+    }
+}
+
 // LANES active lanes per wave, one row each (fewer lanes per wave = more waves = more CUs busy and
 // fewer distinct cache lines per load instruction when there are few rows).
 template <int LANES>
@@ -67,36 +95,17 @@ __global__ __launch_bounds__(64) void zscore_stats_kernel(const float *__restric
     const float n = (float)T;
     const bool vec = ((T & 3) == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0);
     float acc = 0.f;
-    if (vec) {
-#pragma unroll 4
-        for (int t = 0; t < T; t += 4) {
-            const f32x4 v = *reinterpret_cast<const f32x4 *>(r + t);
-            acc = acc + v[0]; acc = acc + v[1];
-            acc = acc + v[2]; acc = acc + v[3];
-        }
-    } else {
-        for (int t = 0; t < T; ++t) acc = acc + r[t];
-    }
+    if (vec) walk_row_vec(r, T, [&](float v) { acc = acc + v; });
+    else for (int t = 0; t < T; ++t) acc = acc + r[t];
     const float mean = acc / n;
     float q = 0.f;
-    if (vec) {
-#pragma unroll 4
-        for (int t = 0; t < T; t += 4) {
-            const f32x4 v = *reinterpret_cast<const f32x4 *>(r + t);
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const float dv = v[k] - mean;
-                const float sq = dv * dv;
-                q = q + sq;
-            }
-        }
-    } else {
-        for (int t = 0; t < T; ++t) {
-            const float dv = r[t] - mean;
-            const float sq = dv * dv;
-            q = q + sq;
-        }
-    }
+    auto sq_step = [&](float v) {
+        const float dv = v - mean;
+        const float sq = dv * dv;
+        q = q + sq;
+    };
+    if (vec) walk_row_vec(r, T, sq_step);
+    else for (int t = 0; t < T; ++t) sq_step(r[t]);
     stats[2 * (size_t)row] = mean;
     // sqrt through fp64: rounding a double sqrt to float is the correctly rounded float sqrt
     const float sd = (float)sqrt((double)(q / n));
