@@ -307,6 +307,12 @@ int ecg_adamw_step_graph(float *p, const float *g, float *m, float *v, size_t n,
  * leads <= 16. */
 int ecg_wfdb16_physical(const int16_t *d, const double *gain, const int *baseline, float *out,
                         int B, int T, int leads, ecg_stream_t stream);
+/* Both steps in one launch where a whole window fits in 64 KB of LDS (12 leads: T up to about 1340; longer
+ * windows run the two entry points around this one back to back): d [B][T][leads] -> z-scored
+ * out [B][leads][T]; stats [B*leads][2] receives (mean, std + 1e-6) of the physical signal.  HBM
+ * traffic is the algorithmic 2 B in + 4 B out per sample. */
+int ecg_wfdb16_zscore(const int16_t *d, const double *gain, const int *baseline, float *out,
+                      float *stats, int B, int T, int leads, ecg_stream_t stream);
 /* Per-lead z-score, (x-mean)/(std+1e-6) with population std.  x [rows][T] -> out [rows][T] (in place
  * allowed); stats [rows][2] receives (mean, std + 1e-6) per row. */
 int ecg_zscore_rows(const float *x, float *out, float *stats, int rows, int T, ecg_stream_t stream);

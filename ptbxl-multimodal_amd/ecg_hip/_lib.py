@@ -72,6 +72,7 @@ SIGNATURES = {
     "ecg_adamw_step": (_i, [_vp, _vp, _vp, _vp, _sz, _i, _f, _f, _f, _f, _f, _f, _vp]),
     "ecg_adamw_step_graph": (_i, [_vp, _vp, _vp, _vp, _sz, _vp, _f, _f, _f, _f, _f, _f, _vp]),
     "ecg_wfdb16_physical": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
+    "ecg_wfdb16_zscore": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "ecg_zscore_rows": (_i, [_vp, _vp, _vp, _i, _i, _vp]),
 }
 

@@ -633,10 +633,11 @@ def zscore_per_lead(x, out=None, return_stats=False):
     return (out, stats) if return_stats else out
 
 
-def wfdb16_to_windows(d, gain, baseline, normalize=True):
+def wfdb16_to_windows(d, gain, baseline, normalize=True, return_stats=False):
     """WFDB format-16 samples d int16 [B, T, leads] (time-major, as stored in .dat) + per-(window, lead)
     gain (float64) / baseline (int32) [B, leads]  ->  fp32 windows [B, leads, T], per-lead z-scored:
-    `_load_ecg` + `_normalize` of the reference (src/datasets/ptbxl.py:14-41,122-127) on the GPU."""
+    `_load_ecg` + `_normalize` of the reference (src/datasets/ptbxl.py:14-41,122-127) on the GPU, one
+    launch.  normalize=False stops at the physical signal."""
     if d.dtype != torch.int16 or gain.dtype != torch.float64 or baseline.dtype != torch.int32:
         raise L.EcgHipError("wfdb16_to_windows: d must be int16, gain float64, baseline int32")
     d, gain, baseline = _contig(d), _contig(gain), _contig(baseline)
@@ -644,5 +645,9 @@ def wfdb16_to_windows(d, gain, baseline, normalize=True):
     if tuple(gain.shape) != (B, leads) or tuple(baseline.shape) != (B, leads):
         raise L.EcgHipError("wfdb16_to_windows: gain/baseline must be [B, leads]")
     x = torch.empty(B, leads, T, dtype=torch.float32, device=d.device)
-    _call("ecg_wfdb16_physical", L.ptr(d), L.ptr(gain), L.ptr(baseline), _f32(x), B, T, leads, _st())
-    return zscore_per_lead(x, out=x) if normalize else x
+    if not normalize:
+        _call("ecg_wfdb16_physical", L.ptr(d), L.ptr(gain), L.ptr(baseline), _f32(x), B, T, leads, _st())
+        return x
+    stats = _empty(x, B * leads, 2)
+    _call("ecg_wfdb16_zscore", L.ptr(d), L.ptr(gain), L.ptr(baseline), _f32(x), _f32(stats), B, T, leads, _st())
+    return (x, stats) if return_stats else x

@@ -38,8 +38,11 @@ def test_committed_reference_windows_bit_for_bit(hip):
 
 
 # (B, T, leads): ragged transpose tiles, T not a multiple of 4 (scalar walk), one lead, 16 leads, T=1
+# T <= 1344 (12 leads) runs the fused LDS-resident kernel, longer windows the three streaming launches;
+# 1344/1345 straddle the switch
 @pytest.mark.parametrize("shape", [(5, 1000, 12), (3, 257, 12), (2, 5000, 12), (4, 63, 1), (2, 300, 16),
-                                   (7, 1, 12), (1, 1022, 3), (33, 128, 12)])
+                                   (7, 1, 12), (1, 1022, 3), (33, 128, 12), (2, 16000, 12), (2, 20000, 3),
+                                   (1, 40001, 2), (1, 40000, 2), (3, 5001, 12), (2, 1344, 12), (2, 1345, 12), (2, 1300, 12)])
 def test_wfdb16_to_windows_vs_oracle_exact(hip, shape):
     B, T, leads = shape
     rng = np.random.default_rng(B * 7 + T + leads)
@@ -50,7 +53,11 @@ def test_wfdb16_to_windows_vs_oracle_exact(hip, shape):
     phys = host(hip.wfdb16_to_windows(dev(d), dev(gain), dev(base), normalize=False))
     want_p = np.stack([np.ascontiguousarray(io_ref.load_ecg(d[i], gain[i], base[i])) for i in range(B)])
     assert np.array_equal(phys, want_p)
-    x = host(hip.wfdb16_to_windows(dev(d), dev(gain), dev(base)))
+    xt, stats = hip.wfdb16_to_windows(dev(d), dev(gain), dev(base), return_stats=True)
+    x = host(xt)
+    if leads > 1:
+        want_mean = np.concatenate([io_ref.load_ecg(d[i], gain[i], base[i]).mean(axis=1) for i in range(B)])
+        assert np.array_equal(host(stats)[:, 0], want_mean)
     if leads == 1:
         # a one-lead [T,1] buffer is contiguous either way, numpy then sums pairwise: not the layout the
         # reference ever sees (12 leads) — compare with the left-to-right restatement instead

@@ -58,14 +58,14 @@ def main():
         out = {"metric": "input_windows_per_s", "value": round(B / (ms * 1e-3), 1), "unit": "windows/s",
                "config": {"workload": f"wfdb16 -> z-scored fp32, B={B}, 12x{T}"}, "ms_per_batch": round(ms, 4),
                "dtype": "i16->f32", "data": "synthetic", "entry_point_ms": {k: round(v, 4) for k, v in per.items()}}
-        # ecg_zscore_rows is two launches (stats + apply); HBM-streaming accounting per sample:
-        #   physical 2 B read + 4 B write; stats 2 x 4 B read (second walk hits L2/MALL); apply 4 B + 4 B
-        alg = {"ecg_wfdb16_physical": 6.0 * samples, "ecg_zscore_rows": 16.0 * samples}
-        out["roofline"] = {k: {"bound": "hbm", "achieved": round(alg[k] / (per[k] * 1e-3) / 1e9, 1), "peak": PEAK_HBM_GBS,
-                               "unit": "GB/s", "frac": round(alg[k] / (per[k] * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
-                               "algorithmic_bytes": alg[k]} for k in alg if k in per}
-        out["roofline"]["note"] = ("ecg_zscore_rows holds the left-to-right float32 chains that make the result "
-                                   "bit-identical to numpy: one lane per (window, lead) row, latency-bound by design")
+        # algorithmic HBM bytes: 2 B/sample in (int16) + 4 B/sample out (fp32), whatever the launch plan
+        alg = 6.0 * samples
+        t = per["ecg_wfdb16_zscore"]
+        out["roofline"] = {"kernel": "ecg_wfdb16_zscore", "bound": "hbm", "achieved": round(alg / (t * 1e-3) / 1e9, 1),
+                           "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(alg / (t * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
+                           "algorithmic_bytes": alg, "traffic": None,
+                           "note": "bound by the left-to-right float32 chains (one lane per (window, lead) row) that "
+                                   "make the result bit-identical to the reference's numpy arithmetic, not by HBM"}
         # packed loader, PCIe inclusive
         with tempfile.TemporaryDirectory() as tmp:
             path = os.path.join(tmp, "b.ecgpack")
