@@ -99,13 +99,13 @@ def kernel_roofline(timings, B):
     return out, breakdown, total_ms
 
 
-def cpu_baseline(B, T, seconds):
+def cpu_baseline(B, T, seconds, demo, labels):
     """The oracle (stock-torch CPU restatement of the reference loop body) on the host cores."""
     from oracle import ref_models as R
     R.seed_all(42)
-    model = R.RefECGMultimodal().train()
+    model = (R.RefECGMultimodal(num_labels=labels) if demo else R.RefECGCNN(num_labels=labels)).train()
     opt = R.make_adamw(model, 1e-4, 1e-4)
-    batch = R.synthetic_batch(B, T, 5, demo=True)
+    batch = R.synthetic_batch(B, T, labels, demo=demo)
     R.train_step(model, opt, batch)                     # warm-up
     n, t0 = 0, time.perf_counter()
     while True:
@@ -115,7 +115,8 @@ def cpu_baseline(B, T, seconds):
         if dt >= seconds or n >= 200:
             break
     return {"value": round(B * n / dt, 1), "unit": "windows/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"oracle/ref_models.py train_step (stock torch CPU ops), ECGMultimodal B={B} 12x{T}, {n} steps in {dt:.1f}s"}
+            "sample": f"oracle/ref_models.py train_step (stock torch CPU ops), {'ECGMultimodal' if demo else f'ECGCNN({labels})'} "
+                      f"B={B} 12x{T}, {n} steps in {dt:.1f}s"}
 
 
 def main():
@@ -125,7 +126,12 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=256, help="windows per GPU")
     ap.add_argument("--length", type=int, default=1000)
-    ap.add_argument("--model", choices=["multimodal", "cnn"], default="multimodal")
+    ap.add_argument("--model", choices=["multimodal", "cnn"], default="cnn",
+                    help="cnn = ECGCNN (BASELINE.json configs[1], the configuration the metric is quoted on); "
+                         "multimodal = ECGMultimodal with the FiLM fusion (configs[2]/[3]); the other one is timed too "
+                         "and reported under 'also'")
+    ap.add_argument("--no-also", action="store_true", help="skip the secondary measurement of the other model")
+    ap.add_argument("--labels", type=int, default=5, help="output labels (1 = the AF-binary shape of BASELINE config 5)")
     ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32",
                     help="f32 (default, the parity path) or bf16 = opt-in mixed precision of BASELINE config 5: "
                          "bf16 conv operands in forward/input-grad, fp32 accumulate, fp32 weight-grad and the rest")
@@ -155,17 +161,6 @@ def main():
     _lib.call("ecg_check_device")
 
     B, T = args.batch, args.length
-    set_seed(42)
-    demo = args.model == "multimodal"
-    model = (ECGMultimodal() if demo else ECGCNN(num_labels=5)).to(dev)
-    if world > 1:
-        ddp.broadcast_module_state(model, 0)
-    opt = FlatAdamW(model.parameters(), lr=1e-4, weight_decay=1e-4)
-    g = torch.Generator().manual_seed(1234 + rank)            # each rank its own shard of the global batch
-    x = torch.randn(B, 12, T, generator=g).to(dev)
-    y = (torch.rand(B, 5, generator=g) < 0.3).float().to(dev)
-    batch = (x, torch.rand(B, 5, generator=g).to(dev), y) if demo else (x, y)
-    run = train_one_epoch_demo if demo else train_one_epoch
 
     def barrier():
         torch.cuda.synchronize()
@@ -173,27 +168,51 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
-    if args.graph:
+    def build(demo):
+        set_seed(42)
+        model = (ECGMultimodal(num_labels=args.labels) if demo else ECGCNN(num_labels=args.labels)).to(dev)
         if world > 1:
-            raise SystemExit("--graph is single-GPU only")
-        from ecg_hip.graph import GraphedTrainStep
-        gstep = GraphedTrainStep(model, opt, batch)
+            ddp.broadcast_module_state(model, 0)
+        opt = FlatAdamW(model.parameters(), lr=1e-4, weight_decay=1e-4)
+        g = torch.Generator().manual_seed(1234 + rank)            # each rank its own shard of the global batch
+        x = torch.randn(B, 12, T, generator=g).to(dev)
+        y = (torch.rand(B, args.labels, generator=g) < 0.3).float().to(dev)
+        batch = (x, torch.rand(B, 5, generator=g).to(dev), y) if demo else (x, y)
+        return model, opt, batch
 
-        def run(_model, loader, _opt, _dev):          # same contract as the loop API: mean loss of the epoch
-            for b in loader:
-                gstep(*b)
-            return gstep.mean_loss_and_reset(len(loader))
+    def timed(demo, model, opt, batch, steps, warmup):
+        """W untimed steps, then exactly K steps between barrier+synchronize; max over ranks."""
+        run = train_one_epoch_demo if demo else train_one_epoch
+        if args.graph:
+            if world > 1:
+                raise SystemExit("--graph is single-GPU only")
+            from ecg_hip.graph import GraphedTrainStep
+            gstep = GraphedTrainStep(model, opt, batch)
 
-    run(model, ListLoader(batch, args.warmup), opt, dev)
-    barrier()
-    t0 = time.perf_counter()
-    last_loss = run(model, ListLoader(batch, args.steps), opt, dev)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        elapsed = t.item()
+            def run(_model, loader, _opt, _dev):          # same contract as the loop API: mean loss of the epoch
+                for b in loader:
+                    gstep(*b)
+                return gstep.mean_loss_and_reset(len(loader))
+
+        run(model, ListLoader(batch, warmup), opt, dev)
+        barrier()
+        t0 = time.perf_counter()
+        last_loss = run(model, ListLoader(batch, steps), opt, dev)
+        barrier()
+        elapsed = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+            elapsed = t.item()
+        return elapsed, last_loss
+
+    def workload_name(demo):
+        return (f"{'ECGMultimodal (FiLM)' if demo else f'ECGCNN({args.labels})'} train step fwd+BCE+bwd+AdamW, "
+                f"12x{T} fp32, batch {B}/GPU, global batch {B * world}")
+
+    demo = args.model == "multimodal"
+    model, opt, batch = build(demo)
+    elapsed, last_loss = timed(demo, model, opt, batch, args.steps, args.warmup)
 
     # instrumented pass (HIP events around every ABI launch on the launch stream); always eager
     run_eager = train_one_epoch_demo if demo else train_one_epoch
@@ -205,14 +224,13 @@ def main():
         value = world * B * args.steps / elapsed
         fwd_f, step_f = conv_flops_per_window(T)
         line = {
-            "metric": "ECG windows/s (train step) at 12x1000, batch 256", "value": round(value, 1), "unit": "windows/s",
+            "metric": f"ECG windows/s (train step) at 12x{T}, batch {B}", "value": round(value, 1), "unit": "windows/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None,
             "dtype": "f32" if args.dtype == "f32" else "bf16 conv operands (fwd, input-grad) / f32 accumulate, weight-grad, BN, tail",
             "data": "synthetic",
-            "config": {"workload": f"{'ECGMultimodal (FiLM)' if demo else 'ECGCNN(5)'} train step fwd+BCE+bwd+AdamW, "
-                                   f"12x{T} fp32, batch {B}/GPU, global batch {B * world}",
+            "config": {"workload": workload_name(demo),
                        "global_batch": B * world, "parallelism": f"dp{world}",
                        "loop": "hipGraph replay of the whole step (GraphedTrainStep)" if args.graph else "src.training API + FlatAdamW",
                        "final_loss": round(float(last_loss), 6)},
@@ -222,7 +240,19 @@ def main():
             "instrumented_ms_per_step": round(instr_ms / min(args.steps, 10), 4),
         }
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(B, T, args.cpu_seconds)
+            line["cpu_baseline"] = cpu_baseline(B, T, args.cpu_seconds, demo, args.labels)
+
+    # secondary line item: the other model of the path on the same shape (all ranks take part)
+    also = None
+    if not args.no_also and not args.graph:
+        del model, opt, batch
+        m2, o2, b2 = build(not demo)
+        e2, _ = timed(not demo, m2, o2, b2, args.steps, min(args.warmup, 5))
+        also = {"workload": workload_name(not demo), "value": round(world * B * args.steps / e2, 1),
+                "unit": "windows/s", "ms_per_step": round(1e3 * e2 / args.steps, 4)}
+    if rank == 0:
+        if also:
+            line["also"] = also
         print(json.dumps(line), flush=True)
     if world > 1:
         torch.distributed.barrier()
