@@ -27,6 +27,10 @@ def init_distributed(backend=None):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("ECG_HIP_REHEARSE_ON_ONE_GPU") == "1":
+        # development aid for a one-GPU box: every rank shares device 0 and the exchange runs over gloo
+        # (RCCL refuses two ranks on one device) — exercises the multi-rank code path, not its speed
+        backend, local = "gloo", 0
     if world > 1 and not dist.is_initialized():
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
