@@ -55,13 +55,24 @@ __device__ __forceinline__ int acc_row(int r, int half) { return (r & 3) + 8 * (
 // partials; EPI_EVAL folds the eval-mode BatchNorm affine, ReLU and MaxPool1d(2) into the store —
 // the inference path writes only the pooled activation (one launch per ConvBlock).
 enum { EPI_PLAIN = 0, EPI_STATS = 1, EPI_EVAL = 2 };
+
+// XCD-aware block order.  Workgroups are dealt round-robin over the 8 XCDs (b and b+8 share an L2),
+// so neighbouring block ids — which here would be the tiles that read the SAME input panel — land on
+// eight different L2s and each fetches the panel again.  This bijective remap gives every XCD a
+// contiguous chunk of the logical tile order instead (cdna_hip_programming.md T1, any grid size):
+// tiles that share a panel sit next to each other in the chunk, are dispatched back to back and hit
+// in their XCD's L2.  Placement is a speed matter only; nothing depends on it for correctness.
+__device__ __forceinline__ int xcd_chunked(int bid, int nwg) {
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+}
 struct EvalEpi { const float *gamma, *beta, *mean, *var; float eps; };
 
 template <int CO_T, int T_T, int WCO, int WT, int EPI>
 __global__ __launch_bounds__(256, 2) void conv1d_mfma_fwd_kernel(
     const float *__restrict__ x, const float *__restrict__ wp, const float *__restrict__ bias,
     float *__restrict__ y, float *__restrict__ partials, int Cin, int Cout, int L, int ldx, int Lo,
-    int pad, int P, EvalEpi ev) {
+    int pad, int P, int tiles_t, EvalEpi ev) {
     constexpr bool STATS = (EPI == EPI_STATS);
     static_assert(WCO * WT == 4, "4 waves per workgroup");
     constexpr int KK = kKM, CI_C = 4, NST = KK * CI_C / 2;
@@ -85,7 +96,12 @@ __global__ __launch_bounds__(256, 2) void conv1d_mfma_fwd_kernel(
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int half = lane >> 5, l31 = lane & 31;
-    const int t0 = blockIdx.x * T_T, co0 = blockIdx.y * CO_T, n = blockIdx.z;
+    // logical tile order: the C_out tiles of one (n, t tile) are adjacent — they read the same x panel
+    const int CT = Cout / CO_T;
+    const int tile = xcd_chunked(blockIdx.x, gridDim.x);
+    const int tile_co = tile % CT, tile_nt = tile / CT;
+    const int tile_t = tile_nt % tiles_t, n = tile_nt / tiles_t;
+    const int t0 = tile_t * T_T, co0 = tile_co * CO_T;
     const int wco = (wave / WT) * (CO_T / WCO), wt = (wave % WT) * (T_T / WT);
     const float *xn = x + (size_t)n * Cin * ldx;     // ldx >= L: row stride of the input tensor
 
@@ -245,7 +261,7 @@ __global__ __launch_bounds__(256, 2) void conv1d_mfma_fwd_kernel(
             float s = 0.f;
 #pragma unroll
             for (int j = 0; j < WT; ++j) s += red[((wrow * WT + j) * (CO_T / WCO) + lc) * 2 + w];
-            const int pidx = n * gridDim.x + blockIdx.x;
+            const int pidx = n * tiles_t + tile_t;
             partials[((size_t)(co0 + col) * P + pidx) * 2 + w] = s;
         }
     }
@@ -276,12 +292,13 @@ template <int CO_T, int T_T, int WCO, int WT>
 static void launch_fwd(const float *x, const float *wp, const float *bias, float *y,
                        float *partials, const EvalEpi *ev, int N, int Cin, int Cout, int L, int ldx,
                        int Lo, int pad, hipStream_t st) {
-    dim3 grid(cdiv(Lo, T_T), Cout / CO_T, N), block(256);
-    const int P = N * (int)grid.x;
+    const int tiles_t = cdiv(Lo, T_T);
+    dim3 grid((unsigned)((size_t)tiles_t * (Cout / CO_T) * N)), block(256);
+    const int P = N * tiles_t;
     const EvalEpi none{nullptr, nullptr, nullptr, nullptr, 0.f};
 #define ECG_FWD(MODE, EV) \
     hipLaunchKernelGGL((conv1d_mfma_fwd_kernel<CO_T, T_T, WCO, WT, MODE>), grid, block, 0, st, x, wp, \
-                       bias, y, partials, Cin, Cout, L, ldx, Lo, pad, P, EV)
+                       bias, y, partials, Cin, Cout, L, ldx, Lo, pad, P, tiles_t, EV)
     if (ev) ECG_FWD(EPI_EVAL, *ev);
     else if (partials) ECG_FWD(EPI_STATS, none);
     else ECG_FWD(EPI_PLAIN, none);
@@ -354,7 +371,11 @@ __global__ __launch_bounds__(256, 2) void conv1d_mfma_wgrad_kernel(
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int half = lane >> 5, l31 = lane & 31;
     const int R = Cin * KK;
-    const int r0 = blockIdx.x * R_T, co0 = blockIdx.y * M_T, s = blockIdx.z;
+    // logical order: the R tiles of one (C_out tile, split) are adjacent — they read the same dY slice
+    const int RT = (R + R_T - 1) / R_T, CT = Cout / M_T;
+    const int tile = xcd_chunked(blockIdx.x, gridDim.x);
+    const int tile_r = tile % RT, tile_cs = tile / RT;
+    const int r0 = tile_r * R_T, co0 = (tile_cs % CT) * M_T, s = tile_cs / CT;
     const int wk = wave % WK, wr = (wave / WK) % WR, wm = wave / (WK * WR);
     const int wm0 = wm * (M_T / WM), wr0 = wr * (R_T / WR), wt0 = wk * TW;
     const int ci_base = r0 / KK;
@@ -380,7 +401,7 @@ __global__ __launch_bounds__(256, 2) void conv1d_mfma_wgrad_kernel(
     float bsum[MC];
 #pragma unroll
     for (int a = 0; a < MC; ++a) bsum[a] = 0.f;
-    const bool want_bias = (blockIdx.x == 0) && (wr == 0);
+    const bool want_bias = (tile_r == 0) && (wr == 0);
 
     // ---- staging: loop-invariant per-thread pieces ------------------------------------------
     constexpr int RPP = (T_T >= 256) ? 1 : 256 / T_T;       // dY rows fetched per pass
@@ -610,7 +631,11 @@ __global__ __launch_bounds__(256, 2) void conv1d_mfma_wgrad_dma_kernel(
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int half = lane >> 5, l31 = lane & 31;
     const int R = Cin * KK;
-    const int r0 = blockIdx.x * R_T, co0 = blockIdx.y * M_T, s = blockIdx.z;
+    // logical order: the R tiles of one (C_out tile, split) are adjacent — they read the same dY slice
+    const int RT = (R + R_T - 1) / R_T, CT = Cout / M_T;
+    const int tile = xcd_chunked(blockIdx.x, gridDim.x);
+    const int tile_r = tile % RT, tile_cs = tile / RT;
+    const int r0 = tile_r * R_T, co0 = (tile_cs % CT) * M_T, s = tile_cs / CT;
     const int wr = wave % WR, wm = wave / WR;
     const int wm0 = wm * (M_T / WM), wr0 = wr * (R_T / WR);
     const int ci_base = r0 / KK;
@@ -635,7 +660,7 @@ __global__ __launch_bounds__(256, 2) void conv1d_mfma_wgrad_dma_kernel(
     float bsum[MC];
 #pragma unroll
     for (int a = 0; a < MC; ++a) bsum[a] = 0.f;
-    const bool want_bias = (blockIdx.x == 0) && (wr == 0);
+    const bool want_bias = (tile_r == 0) && (wr == 0);
 
     // ---- staging: loop-invariant per-thread pieces ------------------------------------------
     int doff[DPW];          // dY piece j of this wave: element offset from the stage base
@@ -820,7 +845,7 @@ int mfma_wgrad(const float *dy, int ldy, const float *x, float *dw, float *db, f
     const int Lo = L + 2 * pad - K + 1;
     const int R = Cin * K;
     const WgCfg c = wgrad_cfg(N, Cin, Cout);
-    dim3 grid(cdiv(R, c.r_t), Cout / c.m_t, c.splits), block(256);
+    dim3 grid((unsigned)(cdiv(R, c.r_t) * (Cout / c.m_t) * c.splits)), block(256);
     const bool dma = mfma_wgrad_dma_supported(Cin, Cout, K) && ldy % 64 == 0 && ldy >= cdiv(Lo, 64) * 64 &&
                      (reinterpret_cast<uintptr_t>(dy) & 15) == 0;
 #define ECG_WG(KERNEL) \
