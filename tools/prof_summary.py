@@ -19,6 +19,24 @@ def main():
               f"us/step={float(r['TotalDurationNs']) / 1e3 / steps:8.1f} {float(r['Percentage']):5.1f}%")
     tr = glob.glob(d + "/**/*_kernel_trace.csv", recursive=True)
     if tr:
+        # the conv kernels serve several layers each: split every kernel's dispatches into layers by duration
+        # (clusters within +-12 %), so that a layer's average can be read against bench.py's per-entry-point time
+        per = {}
+        for r in csv.DictReader(open(tr[0])):
+            per.setdefault(r["Kernel_Name"], []).append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+        print("per-layer split of the conv kernels (dispatch durations clustered within 12 %):")
+        for name, ds in sorted(per.items(), key=lambda kv: -sum(kv[1])):
+            if "conv1d" not in name:
+                continue
+            ds.sort(reverse=True)
+            clusters = []
+            for v in ds:
+                if clusters and v >= 0.88 * clusters[-1][0]:
+                    clusters[-1].append(v)
+                else:
+                    clusters.append([v])
+            short = name.replace("void ecg::", "").replace("ecg::", "")[:60]
+            print(f"  {short:60s} " + "  ".join(f"{sum(c) / len(c) / 1e3:7.1f} us x{len(c) / steps:4.1f}/step" for c in clusters))
         ev = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"])) for r in csv.DictReader(open(tr[0])))
         busy = sum(e - s for s, e in ev)
         span = ev[-1][1] - ev[0][0]
