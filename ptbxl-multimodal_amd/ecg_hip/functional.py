@@ -261,11 +261,13 @@ class ConvBlockFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, w, b, gamma, beta, running_mean, running_var, nbt, training, momentum,
-                eps, pad, gap=False, packed=None):
+                eps, pad, gap=False, packed=None, grad_enabled=True):
         x, w = _contig(x), _contig(w)
         Co, _, K = w.shape
         use_batch = training or running_mean is None
-        need_grad = any(ctx.needs_input_grad)
+        # grad mode is always off INSIDE forward and needs_input_grad ignores torch.no_grad(): the caller
+        # samples torch.is_grad_enabled() and hands it in, so that inference takes the one-launch kernel
+        need_grad = grad_enabled and any(ctx.needs_input_grad)
         sup = _query("ecg_conv1d_bf16_supported", x.shape[1], Co, K, pad) if _conv_precision == "bf16" else 0
         need_dx = need_grad and ctx.needs_input_grad[0]
         bf16 = bool(sup & 1) and (not need_dx or bool(sup & 2))     # block 0 (no input-grad) only needs the forward
@@ -326,7 +328,7 @@ class ConvBlockFn(torch.autograd.Function):
               _f32(dbeta), _f32(ws), N, Co, Lo, 1 if ctx.batch_stats else 0, _st())
         dx, dw, db = conv1d_backward_raw(x, dy, w.shape, ctx.w_bwd, ctx.pad, need_dx,
                                          overlap=True, bf16=ctx.bf16, ldy=ldy)
-        return dx, dw, db, dgamma, dbeta, None, None, None, None, None, None, None, None, None
+        return dx, dw, db, dgamma, dbeta, None, None, None, None, None, None, None, None, None, None
 
 
 # --------------------------------------------------------------------------------------
@@ -524,7 +526,7 @@ def conv_block(x, conv, bn, gap=False, packed=None):
     """Fused Conv1d -> BatchNorm1d -> ReLU -> MaxPool1d(2) [-> AdaptiveAvgPool1d(1).squeeze(-1)]."""
     return ConvBlockFn.apply(x, conv.weight, conv.bias, bn.weight, bn.bias, bn.running_mean,
                              bn.running_var, bn.num_batches_tracked, bn.training, bn.momentum,
-                             bn.eps, conv.padding[0], gap, packed)
+                             bn.eps, conv.padding[0], gap, packed, torch.is_grad_enabled())
 
 
 class TailFn(torch.autograd.Function):

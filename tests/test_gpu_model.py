@@ -247,6 +247,39 @@ def test_eval_loop_api_and_device_side_loss():
         assert abs(out[k] - refm[k]) < 1e-6 or (np.isnan(out[k]) and np.isnan(refm[k]))
 
 
+def test_inference_takes_the_one_launch_conv_blocks():
+    """model.eval() under torch.no_grad() (the reference's eval loops, src/training/loop.py:47-48): blocks 0-2
+    run as ONE launch each (conv + running-stat BN + ReLU + pool); with grad enabled the same weights take
+    the train-capable sequence; both agree with the stock-torch restatement."""
+    from ecg_hip import _lib
+    from src.models.ecg_multimodal import ECGMultimodal
+    from src.utils.seed import set_seed
+    set_seed(42)
+    m = ECGMultimodal().to(DEV).eval()
+    R.seed_all(42)
+    ref = R.RefECGMultimodal().eval()
+    with torch.no_grad():                       # give the running statistics some non-trivial values
+        for mod, rmod in zip(m.modules(), ref.modules()):
+            if isinstance(mod, torch.nn.BatchNorm1d):
+                rm, rv = torch.randn(mod.num_features) * 0.2, torch.rand(mod.num_features) + 0.5
+                mod.running_mean.copy_(rm), mod.running_var.copy_(rv)
+                rmod.running_mean.copy_(rm), rmod.running_var.copy_(rv)
+    x, xd, _ = R.synthetic_batch(6, 1000, 5, demo=True)
+    with _lib.kernel_timing() as kt, torch.no_grad():
+        out = m(x.to(DEV), xd.to(DEV))
+    names = [k[0] for k in kt.result]
+    assert names.count("ecg_conv1d_bn_relu_pool_eval_fwd") == 3, names
+    assert "ecg_bn_finalize" not in names
+    with _lib.kernel_timing() as kt2:
+        out_g = m(x.to(DEV), xd.to(DEV))        # grad mode on: parameters need gradients
+    assert "ecg_conv1d_bn_relu_pool_eval_fwd" not in [k[0] for k in kt2.result]
+    with torch.no_grad():
+        want = ref(x, xd)
+    assert (out.cpu() - want).abs().max() <= 1e-4
+    assert (out_g.detach().cpu() - want).abs().max() <= 1e-4
+    assert (out - out_g).abs().max() <= 5e-5
+
+
 def test_legacy_concat_fusion_model_vs_stock_torch():
     """§8(f)-4: the reconstructed concat-fusion model on the HIP leaves against the same module
     tree built from stock torch layers (no reference output exists for it)."""

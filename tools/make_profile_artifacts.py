@@ -60,7 +60,7 @@ def mean(v):
 
 def main():
     os.makedirs(PROF, exist_ok=True)
-    for f in glob.glob(os.path.join(OUT, f"{TAG}_bench*.json")) + glob.glob(os.path.join(OUT, f"{TAG}_input_pipeline.json")):
+    for f in glob.glob(os.path.join(OUT, f"{TAG}_bench*.json")) + glob.glob(os.path.join(OUT, f"{TAG}_input_pipeline.json")) + glob.glob(os.path.join(OUT, f"{TAG}_inference.json")):
         shutil.copy(f, os.path.join(PROF, os.path.basename(f)))
     stats = newest(os.path.join(OUT, f"prof_{TAG}", "**", "*_kernel_stats.csv"))
     shutil.copy(stats, os.path.join(PROF, f"{TAG}_kernel_stats.csv"))
