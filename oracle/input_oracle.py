@@ -1,6 +1,6 @@
 """CPU restatement of the reference's INPUT path — TEST INFRASTRUCTURE ONLY.
 
-Only tests/, __graft_entry__.smoke() and tools/bench_input.py's cpu_baseline leg may import this
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg (--workload input) may import this
 module; the product path (ecg_hip.functional.wfdb16_to_windows, ecg_hip.pack) never does.
 
 What it restates

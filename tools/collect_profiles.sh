@@ -16,7 +16,7 @@ python bench.py --steps 50 --warmup 10 --dtype bf16 --no-cpu-baseline > "$O/${TA
 python bench.py --steps 50 --warmup 10 --graph --no-cpu-baseline > "$O/${TAG}_bench_graph_replay.json" 2>/dev/null || exit 1
 python bench.py --model cnn --labels 1 --length 5000 --dtype bf16 --steps 20 --warmup 5 --no-cpu-baseline --no-also > "$O/${TAG}_bench_config5_bf16.json" 2>/dev/null || exit 1
 python bench.py --model cnn --labels 1 --length 5000 --steps 20 --warmup 5 --no-cpu-baseline --no-also > "$O/${TAG}_bench_config5_f32.json" 2>/dev/null || exit 1
-python tools/bench_input.py > "$O/${TAG}_input_pipeline.json" 2>/dev/null || exit 1
+python bench.py --workload input > "$O/${TAG}_input_pipeline.json" 2>/dev/null || exit 1
 python tools/bench_eval.py > "$O/${TAG}_inference.json" 2>/dev/null || exit 1
 echo "variants done"
 cd /tmp && export TMPDIR=/tmp
