@@ -16,6 +16,51 @@ def _empty(ref, *shape):
 
 
 # --------------------------------------------------------------------------------------
+# Gradient sinks.  FlatAdamW keeps ONE flat gradient buffer; when it registers a view of that buffer for
+# a parameter, the backward kernels write that parameter's gradient straight into it and autograd's
+# AccumulateGrad adopts the view as `.grad` (no copy) — the optimizer's per-step gather (`torch.cat` of
+# ~28 tensors) and the all-reduce staging disappear.  A sink is only handed out while the parameter's
+# `.grad` is None (zero_grad(set_to_none=True), the default): if a gradient is already there, autograd will
+# ADD the new one to it, and the kernel must not have overwritten the accumulated value.
+# --------------------------------------------------------------------------------------
+import weakref as _weakref
+
+_grad_sinks = {}          # parameter data_ptr -> (weakref(parameter), flat view)
+
+
+def register_grad_sinks(params, views):
+    for p, v in zip(params, views):
+        _grad_sinks[p.data_ptr()] = (_weakref.ref(p), v)
+
+
+def unregister_grad_sinks(keys):
+    for k in keys:
+        _grad_sinks.pop(k, None)
+
+
+def _grad_out(key, ref, *shape):
+    """Destination of a parameter gradient: a FRESH view of the registered sink (AccumulateGrad only adopts
+    a tensor nobody else holds) or a new tensor."""
+    ent = _grad_sinks.get(key) if key is not None else None
+    if ent is not None:
+        p, v = ent[0](), ent[1]
+        if p is not None and p.grad is None and v.device == ref.device and v.numel() == _numel(shape):
+            return v.view(shape)
+    return torch.empty(shape, dtype=torch.float32, device=ref.device)
+
+
+def _numel(shape):
+    n = 1
+    for d in shape:
+        n *= int(d)
+    return n
+
+
+def _key(t):
+    return None if t is None else t.data_ptr()
+
+
+# --------------------------------------------------------------------------------------
 # Side stream for weight gradients.  In a ConvBlock's backward only the input-gradient is on the
 # critical path (the next block's BN-backward passes wait for it); the weight-gradient (MFMA
 # kernel + slab reduce) has no consumer until the optimizer.  It is launched on a second HIP
@@ -183,7 +228,7 @@ def conv1d_forward_raw(x, w_fwd, bias, Co, K, pad, want_stats):
 
 
 def conv1d_backward_raw(x, dy, w_shape, w_bwd, pad, need_dx, need_db=True, overlap=False, bf16=False,
-                        ldy=None):
+                        ldy=None, sink_keys=(None, None)):
     """dy is [N, C_out, ldy] with ldy >= Lo (row-padded, zero pad) when ldy is given."""
     N, Ci, Lin = x.shape
     Co, _, K = w_shape
@@ -193,8 +238,8 @@ def conv1d_backward_raw(x, dy, w_shape, w_bwd, pad, need_dx, need_db=True, overl
     ws_floats = max(1, _query("ecg_conv1d_bwd_weight_ws_floats", N, Ci, Co, Lin, K, pad))
 
     def weight_grad():
-        dw = _empty(x, Co, Ci, K)
-        db = _empty(x, Co) if need_db else None
+        dw = _grad_out(sink_keys[0], x, Co, Ci, K)
+        db = _grad_out(sink_keys[1], x, Co) if need_db else None
         ws = _empty(x, ws_floats)
         _call("ecg_conv1d_bwd_weight_bias_ld", _f32(dy), ldy, _f32(x), _f32(dw), _f32(db), _f32(ws),
               N, Ci, Co, Lin, K, pad, _st())
@@ -308,6 +353,7 @@ class ConvBlockFn(torch.autograd.Function):
                   _f32(p), N, Co, Lo, _st())
         ctx.save_for_backward(x, w, y, gamma, beta, mean, invstd)
         ctx.w_bwd, ctx.pad, ctx.batch_stats, ctx.gap = w_bwd, pad, use_batch, gap
+        ctx.sink_keys = (_key(w), _key(b), _key(gamma), _key(beta))
         return p
 
     @staticmethod
@@ -321,13 +367,14 @@ class ConvBlockFn(torch.autograd.Function):
         ldy = Lo if (ctx.bf16 and need_dx) else _query("ecg_conv1d_dy_row_stride", N, x.shape[1], Co,
                                                        x.shape[2], w.shape[2], ctx.pad)
         dy = _empty(y, N, Co, ldy)
-        dgamma, dbeta = _empty(y, Co), _empty(y, Co)
+        kw, kb, kg, kbe = ctx.sink_keys
+        dgamma, dbeta = _grad_out(kg, y, Co), _grad_out(kbe, y, Co)
         ws = _empty(y, _query("ecg_bn_relu_pool_bwd_ws_floats", N, Co, Lo))
         _call("ecg_bn_relu_pool_gap_bwd_ld" if ctx.gap else "ecg_bn_relu_pool_bwd_ld", _f32(y), _f32(dp),
               _f32(gamma), _f32(beta), _f32(mean), _f32(invstd), _f32(dy), ldy, _f32(dgamma),
               _f32(dbeta), _f32(ws), N, Co, Lo, 1 if ctx.batch_stats else 0, _st())
         dx, dw, db = conv1d_backward_raw(x, dy, w.shape, ctx.w_bwd, ctx.pad, need_dx,
-                                         overlap=True, bf16=ctx.bf16, ldy=ldy)
+                                         overlap=True, bf16=ctx.bf16, ldy=ldy, sink_keys=(kw, kb))
         return dx, dw, db, dgamma, dbeta, None, None, None, None, None, None, None, None, None, None
 
 
@@ -516,7 +563,24 @@ class BceWithLogitsFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dloss):
         (dx,) = ctx.saved_tensors
+        one = _unit_grads.get(dloss.device)
+        if one is not None and dloss.data_ptr() == one.data_ptr():
+            return dx, None, None, None          # seeded by backward_from_loss(): d(loss)/d(loss) = 1 exactly
         return dx * dloss, None, None, None
+
+
+# `loss.backward()` makes autograd fill a fresh ones_like(loss) and BceWithLogitsFn multiply its gradient by
+# it: two tiny launches per step.  The training loops seed the backward pass with this cached constant 1
+# instead; the multiply is then skipped (identical values, the tensor is never written).
+_unit_grads = {}
+
+
+def backward_from_loss(loss):
+    """Same as `loss.backward()` for a scalar loss, without the ones_like fill and the x1 multiply."""
+    one = _unit_grads.get(loss.device)
+    if one is None:
+        one = _unit_grads[loss.device] = torch.ones((), dtype=loss.dtype, device=loss.device)
+    loss.backward(one)
 
 
 # --------------------------------------------------------------------------------------
@@ -558,6 +622,7 @@ class TailFn(torch.autograd.Function):
               _f32(film), _f32(zc), _f32(logits), M, F0, F, D, H1, H, C, _st())
         ctx.save_for_backward(g, xdc, Wp, W0, W2, Wf, Wh, z, h1, h2, film, zc)
         ctx.dims = (M, F0, F, D, H1, H, C, demo)
+        ctx.sink_keys = tuple(_key(t) for t in (Wp, bp, W0, b0, W2, b2, Wf, bf, Wh, bh))
         ctx.set_materialize_grads(False)       # an unused `z` output must not cost a zero-fill
         return logits, z
 
@@ -579,12 +644,13 @@ class TailFn(torch.autograd.Function):
         _call("ecg_tail_bwd_chain", _f32(dlogits), _f32(dze), _f32(z), _f32(h1), _f32(h2), _f32(film),
               _f32(Wp), _f32(W0), _f32(W2), _f32(Wf), _f32(Wh), _f32(dzc), _f32(dz), _f32(dfilm),
               _f32(dh2m), _f32(dh1m), _f32(dg), _f32(dxd), M, F0, F, D, H1, H, C, int(demo), _st())
-        dWp, dbp = torch.empty_like(Wp), _empty(g, F)
-        dWh, dbh = torch.empty_like(Wh), _empty(g, C)
+        k = ctx.sink_keys                       # (Wp, bp, W0, b0, W2, b2, Wf, bf, Wh, bh)
+        dWp, dbp = _grad_out(k[0], g, *Wp.shape), _grad_out(k[1], g, F)
+        dWh, dbh = _grad_out(k[8], g, *Wh.shape), _grad_out(k[9], g, C)
         if demo:
-            dW0, db0 = torch.empty_like(W0), _empty(g, H1)
-            dW2, db2 = torch.empty_like(W2), _empty(g, H)
-            dWf, dbf = torch.empty_like(Wf), _empty(g, 2 * F)
+            dW0, db0 = _grad_out(k[2], g, *W0.shape), _grad_out(k[3], g, H1)
+            dW2, db2 = _grad_out(k[4], g, *W2.shape), _grad_out(k[5], g, H)
+            dWf, dbf = _grad_out(k[6], g, *Wf.shape), _grad_out(k[7], g, 2 * F)
             Gs, Xs = [dz, dfilm, dh2m, dh1m, dlogits], [g, h2, h1, xd, zc]
             dWs, dbs = [dWp, dWf, dW2, dW0, dWh], [dbp, dbf, db2, db0, dbh]
         else:

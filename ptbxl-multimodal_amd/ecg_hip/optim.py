@@ -53,7 +53,21 @@ class FlatAdamW(torch.optim.Optimizer):
         self.flat_param = flatten_tensors_(self._params)
         self.flat_m = torch.zeros_like(self.flat_param)
         self.flat_v = torch.zeros_like(self.flat_param)
-        self.flat_grad = None
+        # persistent flat gradient; on the GPU the backward kernels write each parameter's gradient straight
+        # into its slice (functional.register_grad_sinks), so the per-step gather usually has nothing to do
+        self.flat_grad = torch.zeros_like(self.flat_param)
+        self._gptrs, self._offs, views, off = [], [0], [], 0
+        for p in self._params:
+            v = self.flat_grad[off:off + p.numel()]
+            views.append(v)
+            self._gptrs.append(v.data_ptr())
+            off += p.numel()
+            self._offs.append(off)
+        self._sink_keys = []
+        if self.flat_param.is_cuda:
+            from . import functional as F
+            F.register_grad_sinks(self._params, views)
+            self._sink_keys = [p.data_ptr() for p in self._params]
         self._step = 0
         self._step_dev = None            # device-side step counter (graph-capturable mode)
         self.process_group = process_group
@@ -74,10 +88,37 @@ class FlatAdamW(torch.optim.Optimizer):
             for p in self._params[self._n_early:]:
                 p.register_post_accumulate_grad_hook(self._on_late_grad)
 
+    def __del__(self):
+        try:
+            from . import functional as F
+            F.unregister_grad_sinks(self._sink_keys)
+        except Exception:
+            pass
+
     @staticmethod
     def _flat(p):
         g = p.grad
         return torch.zeros_like(p).view(-1) if g is None else g.reshape(-1)
+
+    def _gather(self, lo, hi):
+        """Make the flat gradient hold the gradients of parameters lo..hi-1.  Nothing to do when every .grad
+        already IS its slice of the flat buffer (written there by the backward kernels); one concatenation
+        when none is; element-wise repair when only some are (a cat must not read what it overwrites)."""
+        ps = self._params[lo:hi]
+        placed = [p.grad is not None and p.grad.data_ptr() == q for p, q in zip(ps, self._gptrs[lo:hi])]
+        if all(placed):
+            return
+        if not any(placed):
+            torch.cat([self._flat(p) for p in ps], out=self.flat_grad[self._offs[lo]:self._offs[hi]])
+            return
+        for i, (p, ok) in enumerate(zip(ps, placed), start=lo):
+            if ok:
+                continue
+            dst = self.flat_grad[self._offs[i]:self._offs[i + 1]]
+            if p.grad is None:
+                dst.zero_()
+            else:
+                dst.copy_(p.grad.reshape(-1))
 
     def _on_late_grad(self, _param):
         """Autograd hook: when the last gradient of the late bucket lands, gather that bucket into
@@ -87,10 +128,8 @@ class FlatAdamW(torch.optim.Optimizer):
             return
         self._late_pending = 0
         with torch.no_grad():
-            if self.flat_grad is None or self.flat_grad.numel() != self.flat_param.numel():
-                self.flat_grad = torch.empty_like(self.flat_param)
+            self._gather(self._n_early, len(self._params))
             late = self.flat_grad[self._split:]
-            torch.cat([self._flat(p) for p in self._params[self._n_early:]], out=late)
             self._late_work = torch.distributed.all_reduce(late, group=self.process_group, async_op=True)
 
     @torch.no_grad()
@@ -101,13 +140,14 @@ class FlatAdamW(torch.optim.Optimizer):
         if self._late_work is not None:                       # late bucket is in flight / done
             g = self.flat_grad
             early = g[:self._split]
-            torch.cat([self._flat(p) for p in self._params[:self._n_early]], out=early)
+            self._gather(0, self._n_early)
             torch.distributed.all_reduce(early, group=self.process_group)
             self._late_work.wait()
             self._late_work = None
             return g, 1.0 / self.world_size
         self._late_pending = 0
-        self.flat_grad = g = torch.cat([self._flat(p) for p in self._params])
+        g = self.flat_grad
+        self._gather(0, len(self._params))
         if self.world_size > 1:
             torch.distributed.all_reduce(g, group=self.process_group)
             return g, 1.0 / self.world_size

@@ -37,7 +37,7 @@ def train_one_epoch(model, loader: DataLoader, optimizer, device) -> float:
         optimizer.zero_grad()
         # the BCE launch also does `weighted += loss * batch_size` (double, on the device)
         loss = hipF.binary_cross_entropy_with_logits(_logits(model(x)), y, weighted, x.size(0))
-        loss.backward()
+        hipF.backward_from_loss(loss)            # loss.backward() minus two one-element launches
         optimizer.step()
     return (0.0 if weighted is None else weighted.item()) / len(loader.dataset)
 

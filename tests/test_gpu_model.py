@@ -280,6 +280,49 @@ def test_inference_takes_the_one_launch_conv_blocks():
     assert (out - out_g).abs().max() <= 5e-5
 
 
+def test_gradients_land_in_the_flat_buffer_and_still_accumulate():
+    """With FlatAdamW the backward kernels write every parameter gradient straight into its slice of the flat
+    gradient (no per-step gather); a second backward WITHOUT zero_grad must still accumulate correctly
+    (the sink is only used while .grad is None), and zero_grad(set_to_none=False) must not double anything."""
+    from ecg_hip.optim import FlatAdamW
+    from src.models.ecg_multimodal import ECGMultimodal
+    from src.training.loop_demo import bce_loss_fn
+    from src.utils.seed import set_seed
+    set_seed(42)
+    m = ECGMultimodal().to(DEV).train()
+    opt = FlatAdamW(m.parameters(), lr=1e-4, weight_decay=1e-4)
+    x, xd, y = (t.to(DEV) for t in R.synthetic_batch(8, 1000, 5, demo=True))
+    opt.zero_grad()
+    bce_loss_fn(m(x, xd), y).backward()
+    lo, hi = opt.flat_grad.data_ptr(), opt.flat_grad.data_ptr() + 4 * opt.flat_grad.numel()
+    for n, p in m.named_parameters():
+        assert lo <= p.grad.data_ptr() < hi, f"{n}: gradient was not written into the flat buffer"
+    g1 = {n: p.grad.clone() for n, p in m.named_parameters()}
+    flat1 = opt.flat_grad.clone()
+    assert torch.equal(flat1, torch.cat([g1[n].reshape(-1) for n, _ in m.named_parameters()]))
+    # same batch again, no zero_grad: autograd adds -> exactly twice (BN running stats do not enter the gradient)
+    bce_loss_fn(m(x, xd), y).backward()
+    for n, p in m.named_parameters():
+        assert torch.allclose(p.grad, 2 * g1[n], rtol=1e-6, atol=1e-12), n
+    # zero-filled (not None) gradients: the kernels must not write under autograd's feet
+    opt.zero_grad(set_to_none=False)
+    bce_loss_fn(m(x, xd), y).backward()
+    for n, p in m.named_parameters():
+        assert torch.allclose(p.grad, g1[n], rtol=1e-6, atol=1e-12), n
+    # a step from this state equals a step from freshly computed gradients
+    before = opt.flat_param.clone()
+    opt.step()
+    assert not torch.equal(before, opt.flat_param)
+    # dropping the optimizer unregisters its sinks: gradients become ordinary tensors again
+    del opt
+    import gc
+    gc.collect()
+    for p in m.parameters():
+        p.grad = None
+    bce_loss_fn(m(x, xd), y).backward()
+    assert all(not (lo <= p.grad.data_ptr() < hi) for p in m.parameters())
+
+
 def test_legacy_concat_fusion_model_vs_stock_torch():
     """§8(f)-4: the reconstructed concat-fusion model on the HIP leaves against the same module
     tree built from stock torch layers (no reference output exists for it)."""
