@@ -206,7 +206,7 @@ def main():
     ap.add_argument("--labels", type=int, default=5, help="output labels (1 = the AF-binary shape of BASELINE config 5)")
     ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32",
                     help="f32 (default, the parity path) or bf16 = opt-in mixed precision of BASELINE config 5: "
-                         "bf16 conv operands in forward/input-grad, fp32 accumulate, fp32 weight-grad and the rest")
+                         "bf16 conv operands in forward/input-grad/weight-grad, fp32 accumulate, fp32 everything else")
     ap.add_argument("--graph", action="store_true",
                     help="replay the whole step as one captured hipGraph (ecg_hip.graph.GraphedTrainStep); "
                          "single GPU only; pays off when the step is host-bound (small batches)")
@@ -304,7 +304,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32" if args.dtype == "f32" else "bf16 conv operands (fwd, input-grad) / f32 accumulate, weight-grad, BN, tail",
+            "dtype": "f32" if args.dtype == "f32" else "bf16 conv operands (fwd, input-grad, weight-grad) / f32 accumulate, activations, BN, tail, optimizer",
             "data": "synthetic",
             "config": {"workload": workload_name(demo),
                        "global_batch": B * world, "parallelism": f"dp{world}",

@@ -111,12 +111,21 @@ int ecg_conv1d_bwd_weight_bias(const float *dy, const float *x, float *dw, float
 
 /* ---- mixed precision (opt-in; BASELINE.json config 5: AF binary 12x5000, bf16) ----------------
  * Forward and input-grad with bf16 operands on the matrix cores (fp32 accumulate, fp32
- * activations in HBM); the weight gradient stays on ecg_conv1d_bwd_weight_bias (fp32).
+ * activations in HBM); the weight gradient has its own bf16 entry point below (C_out % 32 == 0)
+ * and otherwise stays on ecg_conv1d_bwd_weight_bias (fp32).
  * Packed weights are bf16: wb_fwd [ceil(C_in/16)][K][C_out][16], wb_bwd [ceil(C_out/16)][K][C_in][16]
  * (tap-flipped), ecg_conv1d_bf16_packed_elems(C_reduce, C_result, K) 2-byte elements each.
  * K must be 15; forward needs C_in % 4 == 0 and C_out % 32 == 0, the input-grad the same with the
- * roles swapped.  ecg_conv1d_bf16_supported returns a bit mask: 1 = forward, 2 = input-grad. */
+ * roles swapped.  ecg_conv1d_bf16_supported returns a bit mask: 1 = forward, 2 = input-grad, 4 = weight-grad. */
 int ecg_conv1d_bf16_supported(int C_in, int C_out, int K, int pad);
+/* Weight gradient with bf16 operands (bit 2 of ecg_conv1d_bf16_supported: K == 15, pad == 7,
+ * C_out % 32 == 0): dY and x are re-laid as [sample group of 16][channel][time][16] bf16 inside the
+ * workspace, the MFMA reduces over 16 samples per step; dW / db come out in fp32 (db from the bf16-rounded
+ * dY).  dy rows at stride ldy >= Lo.  Workspace in floats from the _ws_floats helper, 16-byte aligned. */
+size_t ecg_conv1d_bwd_weight_bf16_ws_floats(int N, int C_in, int C_out, int L, int K, int pad);
+int ecg_conv1d_bwd_weight_bias_bf16(const float *dy, int ldy, const float *x, float *dw, float *db,
+                                    float *ws, int N, int C_in, int C_out, int L, int K, int pad,
+                                    ecg_stream_t stream);
 size_t ecg_conv1d_bf16_packed_elems(int C_reduce, int C_result, int K);
 int ecg_conv1d_pack_weights_bf16(const float *w, void *wb_fwd, void *wb_bwd, int C_out, int C_in,
                                  int K, ecg_stream_t stream);

@@ -2,7 +2,7 @@
 // gfx950 matrix cores (v_mfma_f32_32x32x16_bf16, fp32 accumulate), fp32 activations in HBM.
 // This is the opt-in path of BASELINE.json config 5 ("AF binary, 12x5000, bf16 mixed precision");
 // the fp32 MFMA kernels of conv1d_mfma.hip remain the default and the parity path.  The weight
-// gradient stays on the fp32 kernels (weight gradients are kept in full precision).
+// gradient of this mode is in conv1d_wgrad_bf16.hip.
 //
 // Same im2col-free structure as the fp32 kernel, with a 16-channel reduction block per MFMA:
 //   D[co][t] += sum_{ci in chunk of 16} W[tap][co][ci] * X[t + tap][ci]       (one MFMA per tap)
@@ -292,10 +292,38 @@ static int check_bf16_shape(const char *who, int N, int Cin, int Cout, int L, in
     return ECG_OK;
 }
 
+namespace ecg {
+// conv1d_wgrad_bf16.hip
+bool wgrad_bf16_supported(int Cin, int Cout, int K, int pad);
+size_t wgrad_bf16_ws_floats(int N, int Cin, int Cout, int L, int K, int pad);
+int wgrad_bf16(const float *dy, int ldy, const float *x, float *dw, float *db, float *ws, int N, int Cin,
+               int Cout, int L, int K, int pad, hipStream_t st);
+}  // namespace ecg
+
 ECG_API int ecg_conv1d_bf16_supported(int C_in, int C_out, int K, int pad) {
-    // bit 0: forward (C_in % 4 == 0, C_out % 32 == 0); bit 1: input-grad (roles swapped)
+    // bit 0: forward (C_in % 4 == 0, C_out % 32 == 0); bit 1: input-grad (roles swapped);
+    // bit 2: weight-grad (K == 15, pad == 7, C_out % 32 == 0)
     return (bf16_fwd_supported(C_in, C_out, K, pad) ? 1 : 0) |
-           (bf16_fwd_supported(C_out, C_in, K, K - 1 - pad) ? 2 : 0);
+           (bf16_fwd_supported(C_out, C_in, K, K - 1 - pad) ? 2 : 0) |
+           (wgrad_bf16_supported(C_in, C_out, K, pad) ? 4 : 0);
+}
+
+ECG_API size_t ecg_conv1d_bwd_weight_bf16_ws_floats(int N, int C_in, int C_out, int L, int K, int pad) {
+    if (!wgrad_bf16_supported(C_in, C_out, K, pad) || N <= 0 || L + 2 * pad - K + 1 <= 0) return 0;
+    return wgrad_bf16_ws_floats(N, C_in, C_out, L, K, pad);
+}
+
+ECG_API int ecg_conv1d_bwd_weight_bias_bf16(const float *dy, int ldy, const float *x, float *dw, float *db,
+                                            float *ws, int N, int C_in, int C_out, int L, int K, int pad,
+                                            ecg_stream_t stream) {
+    int rc = check_bf16_shape("conv1d_bwd_weight_bias_bf16", N, C_in, C_out, L, K, pad);
+    if (rc) return rc;
+    ECG_REQUIRE(dy && x && dw && ws, "conv1d_bwd_weight_bias_bf16: null pointer");
+    ECG_REQUIRE(wgrad_bf16_supported(C_in, C_out, K, pad),
+                "conv1d_bwd_weight_bias_bf16: needs K == 15, pad == 7, C_out %% 32 == 0 (query ecg_conv1d_bf16_supported)");
+    ECG_REQUIRE(ldy >= L + 2 * pad - K + 1, "conv1d_bwd_weight_bias_bf16: dY row stride %d too small", ldy);
+    ECG_REQUIRE((reinterpret_cast<uintptr_t>(ws) & 15) == 0, "conv1d_bwd_weight_bias_bf16: workspace must be 16-byte aligned");
+    return wgrad_bf16(dy, ldy, x, dw, db, ws, N, C_in, C_out, L, K, pad, as_stream(stream));
 }
 
 ECG_API size_t ecg_conv1d_bf16_packed_elems(int C_reduce, int C_result, int K) {

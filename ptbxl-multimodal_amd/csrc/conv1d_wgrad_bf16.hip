@@ -1,0 +1,294 @@
+// conv1d_wgrad_bf16.hip — mixed-precision weight gradient (the opt-in path of BASELINE.json config 5):
+// bf16 operands on v_mfma_f32_32x32x16_bf16, fp32 accumulate, fp32 dW / db out.
+//
+//   dW[co][ci][k] = sum_n sum_t dY[n][co][t] * X[n][ci][t + k - pad]
+//
+// The reduction runs over (n, t).  A bf16 MFMA consumes 16 reduction indices at once, 8 per lane as ONE
+// 16-byte operand — so the 16 indices must be contiguous in memory for BOTH operands.  Along t that fails
+// for X (tap k shifts the window by one 2-byte element: unaligned).  Along n it works: the MFMA's K
+// dimension is a group of 16 SAMPLES at a fixed time step,
+//   A[co][j] = dY[16g + j][co][t],      B[j][(ci,k)] = X[16g + j][ci][t + k - pad],
+// and with both tensors re-laid as [sample group][channel][time][16 samples] (bf16, "n16") a tap shift
+// moves by whole 32-byte granules.  Two launches:
+//   pack_n16_kernel    fp32 [N][C][ld] -> bf16 [G][C][P][16], round to nearest even, zero-filled past N
+//                      and outside the row (for X that bakes the conv's zero padding into the layout)
+//   conv1d_wgrad_bf16_kernel   workgroup tile M_T (co) x R_T (r = ci*15 + k); a stage = (sample group,
+//                      16 time steps); both operand tiles go global -> LDS by DMA (no registers, no
+//                      masks — the layouts already contain every zero); per time step one conflict-free
+//                      ds_read_b128 per fragment (the two 16-byte halves of a granule are XOR-swizzled by
+//                      bit 3 of the granule index; the x rows are 31 granules apart so that the column
+//                      index r maps to consecutive granules mod 16).  Split over stages into slabs that
+//                      wgrad_reduce_kernel sums in fixed order, like the fp32 kernel.
+// Replaces autograd's conv weight-gradient (reference src/models/ecg_cnn.py:13 via loss.backward()).
+#include "common.h"
+
+namespace ecg {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned short u16;
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kKW = 15;
+constexpr int kTW = 16;        // time steps per stage
+constexpr int kXP = 31;        // x-tile granules per channel row: >= kTW + 14, == 15 (mod 16)
+
+__device__ __forceinline__ int acc_row_w(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }
+
+__device__ __forceinline__ unsigned pack2(float lo, float hi) {
+    const u16 a = __builtin_bit_cast(u16, (__bf16)lo), b = __builtin_bit_cast(u16, (__bf16)hi);
+    return (unsigned)a | ((unsigned)b << 16);
+}
+
+// dst[g][c][p][j] = src[16g + j][c][p - shift]  (0 outside the row or past N).  grid = (ceil(P/256), C, G)
+__global__ __launch_bounds__(256) void pack_n16_kernel(const float *__restrict__ src, u16 *__restrict__ dst,
+                                                       int N, int C, int ld, int Lsrc, int P, int shift) {
+    const int p = blockIdx.x * 256 + threadIdx.x, c = blockIdx.y, g = blockIdx.z;
+    if (p >= P) return;
+    const int t = p - shift;
+    const bool in_row = (t >= 0) && (t < Lsrc);
+    const int tc = min(max(t, 0), Lsrc - 1);
+    float v[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j)                     // 16 unconditional, clamped loads in flight ...
+        v[j] = src[((size_t)min(16 * g + j, N - 1) * C + c) * ld + tc];
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int j = 0; j < 16; ++j)                     // ... zeroing applied afterwards
+        v[j] = (in_row && 16 * g + j < N) ? v[j] : 0.f;
+    u32x4 lo, hi;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        lo[q] = pack2(v[2 * q], v[2 * q + 1]);
+        hi[q] = pack2(v[8 + 2 * q], v[8 + 2 * q + 1]);
+    }
+    u32x4 *o = reinterpret_cast<u32x4 *>(dst + (((size_t)g * C + c) * P + p) * 16);
+    o[0] = lo;
+    o[1] = hi;
+}
+
+// grid = (R tiles * C_out tiles * S) with the XCD-chunked order of conv1d_mfma.hip's kernels.
+template <int M_T, int R_T, int WM, int WR>
+__global__ __launch_bounds__(256, 3) void conv1d_wgrad_bf16_kernel(
+    const u16 *__restrict__ dyb, const u16 *__restrict__ xb, float *__restrict__ slab, int G, int Cin,
+    int Cout, int PA, int PX, int ntt, int S) {
+    static_assert(WM * WR == 4, "4 waves per workgroup");
+    constexpr int KK = kKW;
+    constexpr int MC = M_T / WM / 32, MR = R_T / WR / 32;
+    constexpr int NCI = (R_T + KK - 2) / KK + 1;
+    constexpr int ASLOTS = kTW * M_T * 2;                  // 16-byte slots of the dY image
+    constexpr int BSLOTS = NCI * kXP * 2;
+    constexpr int ADMA = ASLOTS / 64, BDMA = (BSLOTS + 63) / 64;
+    constexpr int APW = ADMA / 4, BPW = (BDMA + 3) / 4;    // DMA instructions per wave per stage
+    static_assert(ADMA % 4 == 0, "dY image must split evenly over the four waves");
+    constexpr int IMGB = (ASLOTS + BDMA * 64) * 16;
+
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[IMGB];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int half = lane >> 5, l31 = lane & 31;
+    const int R = Cin * KK;
+    const int RT = (R + R_T - 1) / R_T, CT = Cout / M_T;
+    // same XCD-aware order as the fp32 kernels: the R tiles of one (C_out tile, split) share a dY slice
+    int tile;
+    {
+        const int nwg = gridDim.x, bid = blockIdx.x;
+        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+        tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    }
+    const int tile_r = tile % RT, tile_cs = tile / RT;
+    const int r0 = tile_r * R_T, co0 = (tile_cs % CT) * M_T, s = tile_cs / CT;
+    const int wr = wave % WR, wm = wave / WR;
+    const int wm0 = wm * (M_T / WM), wr0 = wr * (R_T / WR);
+    const int ci_base = r0 / KK;
+    const int total = G * ntt;
+    const int st_begin = (int)((long long)total * s / S), st_end = (int)((long long)total * (s + 1) / S);
+
+    // B fragments: granule index (before the time offset) of column r = r0 + wr0 + 32j + l31
+    int qb0[MR];
+#pragma unroll
+    for (int j = 0; j < MR; ++j) {
+        int r = r0 + wr0 + 32 * j + l31;
+        if (r >= R) r = R - 1;                 // clamped columns compute garbage that is never stored
+        const int ci = r / KK;
+        qb0[j] = (ci - ci_base) * kXP + (r - ci * KK);
+    }
+
+    f32x16 acc[MC][MR];
+#pragma unroll
+    for (int a = 0; a < MC; ++a)
+#pragma unroll
+        for (int b = 0; b < MR; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+    float bsum[MC];
+#pragma unroll
+    for (int a = 0; a < MC; ++a) bsum[a] = 0.f;
+    const bool want_bias = (tile_r == 0) && (wr == 0);
+
+    // ---- DMA geometry: LDS slot -> element offset from the stage base (loop-invariant) -------------
+    // slot s = 2*granule + (half ^ bit3(granule)); A granule = t*M_T + co, B granule = ci_local*kXP + pos
+    int aoff[APW], boff[BPW];
+#pragma unroll
+    for (int j = 0; j < APW; ++j) {
+        const int sl = (j * 4 + wave) * 64 + lane;
+        const int qa = sl >> 1, h = (sl & 1) ^ ((qa >> 3) & 1);
+        const int t = qa / M_T, co = qa - t * M_T;
+        aoff[j] = (co * PA + t) * 16 + 8 * h;
+    }
+#pragma unroll
+    for (int j = 0; j < BPW; ++j) {
+        const int sl = min((j * 4 + wave) * 64 + lane, BSLOTS - 1);       // the tail of the last piece re-reads a valid slot
+        const int qb = sl >> 1, h = (sl & 1) ^ ((qb >> 3) & 1);
+        const int cl = qb / kXP, pos = qb - cl * kXP;
+        boff[j] = (min(ci_base + cl, Cin - 1) * PX + pos) * 16 + 8 * h;
+    }
+    unsigned char *aimg = lds, *bimg = lds + ASLOTS * 16;
+
+    for (int st = st_begin; st < st_end; ++st) {
+        const int g = st / ntt, t0 = (st - g * ntt) * kTW;
+        const u16 *abase = dyb + (((size_t)g * Cout + co0) * PA + t0) * 16;
+        const u16 *bbase = xb + ((size_t)g * Cin * PX + t0) * 16;
+#pragma unroll
+        for (int j = 0; j < APW; ++j)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(abase + aoff[j]),
+                                             (__attribute__((address_space(3))) void *)(aimg + (j * 4 + wave) * 1024),
+                                             16, 0, 0);
+#pragma unroll
+        for (int j = 0; j < BPW; ++j)
+            if ((j * 4 + wave) < BDMA)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(bbase + boff[j]),
+                                                 (__attribute__((address_space(3))) void *)(bimg + (j * 4 + wave) * 1024),
+                                                 16, 0, 0);
+        __builtin_amdgcn_s_waitcnt(0x0F70);     // vmcnt(0): this wave's DMA pieces have landed in LDS ...
+        __syncthreads();                        // ... and so have everybody else's
+
+        auto ld = [&](int t, bf16x8 *a, bf16x8 *b) {
+#pragma unroll
+            for (int i = 0; i < MC; ++i) {
+                const int qa = t * M_T + wm0 + 32 * i + l31;
+                a[i] = *reinterpret_cast<const bf16x8 *>(aimg + (2 * qa + (half ^ ((qa >> 3) & 1))) * 16);
+            }
+#pragma unroll
+            for (int j = 0; j < MR; ++j) {
+                const int qb = qb0[j] + t;
+                b[j] = *reinterpret_cast<const bf16x8 *>(bimg + (2 * qb + (half ^ ((qb >> 3) & 1))) * 16);
+            }
+        };
+        bf16x8 a_c[MC], b_c[MR], a_n[MC], b_n[MR];
+        ld(0, a_c, b_c);
+#pragma unroll
+        for (int t = 0; t < kTW; ++t) {
+            ld(t + 1 < kTW ? t + 1 : 0, a_n, b_n);
+            __builtin_amdgcn_sched_barrier(0);
+            if (want_bias) {                      // db rides on the A fragments (bf16-rounded dY, fp32 sum)
+#pragma unroll
+                for (int i = 0; i < MC; ++i)
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) bsum[i] += (float)a_c[i][e];
+            }
+#pragma unroll
+            for (int i = 0; i < MC; ++i)
+#pragma unroll
+                for (int j = 0; j < MR; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_c[i], b_c[j], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < MC; ++i) a_c[i] = a_n[i];
+#pragma unroll
+            for (int j = 0; j < MR; ++j) b_c[j] = b_n[j];
+        }
+        __syncthreads();            // everybody is done reading before the next stage's DMA lands
+    }
+
+    if (want_bias) {
+#pragma unroll
+        for (int i = 0; i < MC; ++i) bsum[i] += __shfl_xor(bsum[i], 32, 64);
+    }
+    const size_t wslab = (size_t)Cout * R;
+    float *out = slab + (size_t)s * wslab;
+#pragma unroll
+    for (int i = 0; i < MC; ++i)
+#pragma unroll
+        for (int j = 0; j < MR; ++j) {
+            const int r = r0 + wr0 + 32 * j + l31;
+            if (r < R) {
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    const int co = co0 + wm0 + 32 * i + acc_row_w(q, half);
+                    out[(size_t)co * R + r] = acc[i][j][q];
+                }
+            }
+        }
+    if (want_bias && half == 0) {
+#pragma unroll
+        for (int i = 0; i < MC; ++i)
+            slab[(size_t)S * wslab + (size_t)s * Cout + co0 + wm0 + 32 * i + l31] = bsum[i];
+    }
+}
+
+// conv1d_direct.hip: dw[i] = sum_s slab[s][i] in fixed order
+int wgrad_reduce(const float *ws, float *dw, float *db, size_t wslab, int Cout, int S, hipStream_t st);
+
+struct WgBf16Plan { int G, PA, PX, ntt, splits; size_t dyb_elems, xb_elems, slab_floats; };
+
+static WgBf16Plan wgrad_bf16_plan(int N, int Cin, int Cout, int Lo) {
+    WgBf16Plan p;
+    p.G = cdiv(N, 16);
+    p.ntt = cdiv(Lo, kTW);
+    p.PA = p.ntt * kTW;                  // dY rows padded to whole stages (zeros)
+    p.PX = p.PA + 16;                    // x rows: conv padding baked in, +kXP-1 granules readable past the last stage
+    const int m_t = Cout % 64 == 0 ? 64 : 32, r_t = Cout % 64 == 0 ? 128 : 256;
+    const int tiles = cdiv(Cin * kKW, r_t) * (Cout / m_t);
+    int s = 768 / tiles;                 // 3 resident workgroups per CU
+    const int total = p.G * p.ntt;
+    if (s > total) s = total;
+    if (s < 1) s = 1;
+    p.splits = s;
+    p.dyb_elems = (size_t)p.G * Cout * p.PA * 16;
+    p.xb_elems = (size_t)p.G * Cin * p.PX * 16;
+    p.slab_floats = (size_t)s * ((size_t)Cout * Cin * kKW + Cout);
+    return p;
+}
+
+bool wgrad_bf16_supported(int Cin, int Cout, int K, int pad) {
+    (void)Cin;
+    return K == kKW && pad == kKW / 2 && Cout % 32 == 0;
+}
+
+// workspace: slabs (fp32) | dY in n16 layout (bf16) | x in n16 layout (bf16)
+size_t wgrad_bf16_ws_floats(int N, int Cin, int Cout, int L, int K, int pad) {
+    const WgBf16Plan p = wgrad_bf16_plan(N, Cin, Cout, L + 2 * pad - K + 1);
+    return p.slab_floats + (p.dyb_elems + p.xb_elems + 1) / 2 + 16;
+}
+
+int wgrad_bf16(const float *dy, int ldy, const float *x, float *dw, float *db, float *ws, int N, int Cin,
+               int Cout, int L, int K, int pad, hipStream_t st) {
+    const int Lo = L + 2 * pad - K + 1;
+    const WgBf16Plan p = wgrad_bf16_plan(N, Cin, Cout, Lo);
+    float *slab = ws;
+    u16 *dyb = reinterpret_cast<u16 *>(ws + ((p.slab_floats + 3) / 4) * 4);      // 16-byte aligned
+    u16 *xb = dyb + p.dyb_elems;
+    hipLaunchKernelGGL(pack_n16_kernel, dim3(cdiv(p.PA, 256), Cout, p.G), dim3(256), 0, st, dy, dyb, N, Cout, ldy,
+                       Lo, p.PA, 0);
+    hipLaunchKernelGGL(pack_n16_kernel, dim3(cdiv(p.PX, 256), Cin, p.G), dim3(256), 0, st, x, xb, N, Cin, L, L,
+                       p.PX, pad);
+    int rc = check_launch("pack_n16_kernel");
+    if (rc) return rc;
+    const int R = Cin * K;
+    dim3 block(256);
+    if (Cout % 64 == 0) {
+        dim3 grid((unsigned)(cdiv(R, 128) * (Cout / 64) * p.splits));
+        hipLaunchKernelGGL((conv1d_wgrad_bf16_kernel<64, 128, 2, 2>), grid, block, 0, st, dyb, xb, slab, p.G, Cin,
+                           Cout, p.PA, p.PX, p.ntt, p.splits);
+    } else {                               // C_out = 32 (block 0): one 32-channel row of wide column tiles
+        dim3 grid((unsigned)(cdiv(R, 256) * (Cout / 32) * p.splits));
+        hipLaunchKernelGGL((conv1d_wgrad_bf16_kernel<32, 256, 1, 4>), grid, block, 0, st, dyb, xb, slab, p.G, Cin,
+                           Cout, p.PA, p.PX, p.ntt, p.splits);
+    }
+    rc = check_launch("conv1d_wgrad_bf16_kernel");
+    if (rc) return rc;
+    return wgrad_reduce(slab, dw, db, (size_t)Cout * R, Cout, p.splits, st);
+}
+
+}  // namespace ecg

@@ -36,6 +36,8 @@ SIGNATURES = {
     "ecg_conv1d_fwd_bf16_stat_partials": (_i, [_i, _i, _i, _i, _i, _i]),
     "ecg_conv1d_fwd_bf16": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "ecg_conv1d_bwd_data_bf16": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "ecg_conv1d_bwd_weight_bf16_ws_floats": (_sz, [_i] * 6),
+    "ecg_conv1d_bwd_weight_bias_bf16": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "ecg_bn_stat_partials_count": (_i, [_i, _i, _i]),
     "ecg_bn_stat_partials": (_i, [_vp, _vp, _i, _i, _i, _vp]),
     "ecg_bn_finalize": (_i, [_vp, _i, _ll, _vp, _vp, _vp, _vp, _vp, _i, _f, _f, _vp]),

@@ -114,8 +114,8 @@ def conv1d_pack(w, need_bwd=True):
 
 # --------------------------------------------------------------------------------------
 # Conv precision: "fp32" (default, the parity path: exact-fp32 MFMA) or "bf16" (opt-in mixed
-# precision, BASELINE.json config 5: bf16 operands / fp32 accumulate in forward and input-grad,
-# fp32 weight-grad, fp32 everything else).  ECG_HIP_CONV_PRECISION sets the process default.
+# precision, BASELINE.json config 5: bf16 operands / fp32 accumulate in forward, input-grad and
+# weight-grad; fp32 activations, gradients, BatchNorm, tail, optimizer).  ECG_HIP_CONV_PRECISION sets the process default.
 # --------------------------------------------------------------------------------------
 _conv_precision = _os.environ.get("ECG_HIP_CONV_PRECISION", "fp32")
 
@@ -235,14 +235,17 @@ def conv1d_backward_raw(x, dy, w_shape, w_bwd, pad, need_dx, need_db=True, overl
     if ldy is None:
         ldy = Lin + 2 * pad - K + 1
     main = torch.cuda.current_stream()
-    ws_floats = max(1, _query("ecg_conv1d_bwd_weight_ws_floats", N, Ci, Co, Lin, K, pad))
+    # mixed precision: bf16-operand weight gradient where the shape allows it (bit 2), fp32 otherwise
+    wg_bf16 = bf16 and bool(_query("ecg_conv1d_bf16_supported", Ci, Co, K, pad) & 4)
+    ws_floats = max(1, _query("ecg_conv1d_bwd_weight_bf16_ws_floats" if wg_bf16 else "ecg_conv1d_bwd_weight_ws_floats",
+                              N, Ci, Co, Lin, K, pad))
 
     def weight_grad():
         dw = _grad_out(sink_keys[0], x, Co, Ci, K)
         db = _grad_out(sink_keys[1], x, Co) if need_db else None
         ws = _empty(x, ws_floats)
-        _call("ecg_conv1d_bwd_weight_bias_ld", _f32(dy), ldy, _f32(x), _f32(dw), _f32(db), _f32(ws),
-              N, Ci, Co, Lin, K, pad, _st())
+        _call("ecg_conv1d_bwd_weight_bias_bf16" if wg_bf16 else "ecg_conv1d_bwd_weight_bias_ld", _f32(dy), ldy,
+              _f32(x), _f32(dw), _f32(db), _f32(ws), N, Ci, Co, Lin, K, pad, _st())
         return dw, db
 
     if overlap and _OVERLAP and need_dx:

@@ -486,7 +486,7 @@ def test_bf16_conv_is_exact_on_bf16_rounded_operands(hip, oracle, case):
     w = (rng.standard_normal((Co, Ci, 15)) / np.sqrt(Ci * 15)).astype(np.float32)
     b = rng.standard_normal(Co).astype(np.float32)
     dy = rng.standard_normal((N, Co, Lin)).astype(np.float32)
-    assert L.query("ecg_conv1d_bf16_supported", Ci, Co, 15, 7) == (3 if Ci % 32 == 0 else 1)
+    assert L.query("ecg_conv1d_bf16_supported", Ci, Co, 15, 7) == (3 if Ci % 32 == 0 else 1) + 4
     wb_fwd, wb_bwd = hip.conv1d_pack_bf16(dev(w), need_bwd=True)
     y, _, _ = hip.conv1d_forward_bf16_raw(dev(x), wb_fwd, dev(b), Co, 15, 7, want_stats=False)
     ry = oracle.conv1d_fwd(_bf16_round(x), _bf16_round(w), b, 7)
@@ -505,3 +505,38 @@ def test_bf16_conv_is_exact_on_bf16_rounded_operands(hip, oracle, case):
     omean, oinv = oracle.bn_stats(ry)
     np.testing.assert_allclose(host(mean), omean, atol=5e-6)
     np.testing.assert_allclose(host(invstd), oinv, rtol=5e-5)
+
+
+# (N, Ci, Co, L): ragged sample groups (N % 16 != 0), ragged time tiles (L % 16 != 0), L < one stage, every
+# block geometry with C_out % 64 == 0, a row-padded dY
+@pytest.mark.parametrize("case", [(16, 32, 64, 64), (5, 32, 64, 50), (37, 64, 128, 125), (3, 128, 256, 62),
+                                  (33, 32, 64, 7), (18, 64, 128, 250), (2, 12, 64, 40), (19, 12, 32, 300), (3, 12, 32, 1000),
+                                  (2, 20, 96, 33)])
+@pytest.mark.parametrize("padded", [False, True])
+def test_bf16_weight_grad_is_exact_on_bf16_rounded_operands(hip, oracle, case, padded):
+    """Mixed-precision weight gradient: equal to the oracle on bf16-rounded dY and x up to fp32 accumulation
+    order — pins the [group][channel][time][16 samples] layout, the baked-in zero padding, the XOR-swizzled
+    LDS images and the split/reduce; db comes from the bf16-rounded dY as documented."""
+    from ecg_hip import _lib as L
+    N, Ci, Co, Lin = case
+    rng = np.random.default_rng(sum(case))
+    x = rng.standard_normal((N, Ci, Lin)).astype(np.float32)
+    dy = rng.standard_normal((N, Co, Lin)).astype(np.float32)
+    assert L.query("ecg_conv1d_bf16_supported", Ci, Co, 15, 7) & 4
+    ldy = (Lin + 63) // 64 * 64 if padded else Lin
+    dyp = np.zeros((N, Co, ldy), np.float32)
+    dyp[:, :, :Lin] = dy
+    dw, db = torch.empty(Co, Ci, 15, device="cuda"), torch.empty(Co, device="cuda")
+    ws = torch.empty(L.query("ecg_conv1d_bwd_weight_bf16_ws_floats", N, Ci, Co, Lin, 15, 7), device="cuda")
+    dyd, xd = dev(dyp), dev(x)           # named: a temporary would be freed (and reused) before the launch reads it
+    L.call("ecg_conv1d_bwd_weight_bias_bf16", L.f32(dyd), ldy, L.f32(xd), L.f32(dw), L.f32(db), L.f32(ws),
+           N, Ci, Co, Lin, 15, 7, L.stream())
+    rdw, rdb = oracle.conv1d_bwd_weight(_bf16_round(dy), _bf16_round(x), 15, 7)
+    scale = np.sqrt(N * Lin)
+    np.testing.assert_allclose(host(dw), rdw, atol=2e-6 * scale + 2e-5)
+    np.testing.assert_allclose(host(db), rdb, atol=2e-6 * scale + 2e-5)
+    full, _ = oracle.conv1d_bwd_weight(dy, x, 15, 7)            # and a bf16-accurate approximation of the fp32 result
+    assert np.abs(host(dw) - full).max() < 0.02 * scale
+    with pytest.raises(L.EcgHipError, match="C_out"):
+        L.call("ecg_conv1d_bwd_weight_bias_bf16", L.f32(dyd), ldy, L.f32(xd), L.f32(dw), L.f32(db), L.f32(ws),
+               N, Ci, 48, Lin, 15, 7, L.stream())
