@@ -240,9 +240,9 @@ static WgBf16Plan wgrad_bf16_plan(int N, int Cin, int Cout, int Lo) {
     p.PX = p.PA + 16;                    // x rows: conv padding baked in, +kXP-1 granules readable past the last stage
     const int m_t = Cout % 64 == 0 ? 64 : 32, r_t = Cout % 64 == 0 ? 128 : 256;
     const int tiles = cdiv(Cin * kKW, r_t) * (Cout / m_t);
-    int s = 768 / tiles;                 // 3 resident workgroups per CU
+    int s = 768 / tiles;                 // 3 resident workgroups per CU ...
     const int total = p.G * p.ntt;
-    if (s > total) s = total;
+    if (s > total / 8) s = total / 8;    // ... but at least 8 stages per workgroup: a slab is written and re-read per split
     if (s < 1) s = 1;
     p.splits = s;
     p.dyb_elems = (size_t)p.G * Cout * p.PA * 16;

@@ -14,6 +14,7 @@ python bench.py --steps 50 --warmup 10 > "$O/${TAG}_bench.json" 2> "$O/${TAG}_be
 echo "bench done"
 python bench.py --steps 50 --warmup 10 --dtype bf16 --no-cpu-baseline > "$O/${TAG}_bench_bf16_optin.json" 2>/dev/null || exit 1
 python bench.py --steps 50 --warmup 10 --graph --no-cpu-baseline > "$O/${TAG}_bench_graph_replay.json" 2>/dev/null || exit 1
+python bench.py --steps 100 --warmup 20 --dtype bf16 --graph --no-cpu-baseline > "$O/${TAG}_bench_bf16_graph_replay.json" 2>/dev/null || exit 1
 python bench.py --model cnn --labels 1 --length 5000 --dtype bf16 --steps 20 --warmup 5 --no-cpu-baseline --no-also > "$O/${TAG}_bench_config5_bf16.json" 2>/dev/null || exit 1
 python bench.py --model cnn --labels 1 --length 5000 --steps 20 --warmup 5 --no-cpu-baseline --no-also > "$O/${TAG}_bench_config5_f32.json" 2>/dev/null || exit 1
 python bench.py --workload input > "$O/${TAG}_input_pipeline.json" 2>/dev/null || exit 1
