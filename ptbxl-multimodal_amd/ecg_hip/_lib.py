@@ -109,7 +109,15 @@ def last_error():
     return load().ecg_last_error().decode("utf-8", "replace")
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+_raw_device = getattr(torch._C, "_cuda_getDevice", None)
+
+
 def stream():
+    """hipStream_t of torch's current stream on the current device.  Called once per launch (~45 times a
+    step): the raw accessors cost ~0.3 us, torch.cuda.current_stream() ~8 us (it builds a Stream object)."""
+    if _raw_stream is not None and _raw_device is not None:
+        return _raw_stream(_raw_device())
     return torch.cuda.current_stream().cuda_stream
 
 
@@ -117,16 +125,23 @@ def ptr(t):
     """Device pointer of a tensor that satisfies the ABI contract (or None)."""
     if t is None:
         return None
+    if t.is_cuda and t.is_contiguous():
+        return t.data_ptr()
     if not t.is_cuda:
         raise EcgHipError("ecg_hip kernels need CUDA(HIP) tensors; got a CPU tensor "
                           "(move the model and inputs to 'cuda' — there is no CPU fallback)")
-    if not t.is_contiguous():
-        raise EcgHipError("ecg_hip kernels need contiguous tensors")
-    return t.data_ptr()
+    raise EcgHipError("ecg_hip kernels need contiguous tensors")
+
+
+_F32 = torch.float32
 
 
 def f32(t):
-    if t is not None and t.dtype != torch.float32:
+    if t is None:
+        return None
+    if t.dtype is _F32 and t.is_cuda and t.is_contiguous():
+        return t.data_ptr()
+    if t.dtype != torch.float32:
         raise EcgHipError(f"ecg_hip kernels compute in float32; got {t.dtype}")
     return ptr(t)
 
