@@ -5,6 +5,7 @@ a contiguous float32 CUDA tensor, the call raises.  Every wrapper launches on to
 current HIP stream and never synchronises.
 """
 import ctypes
+import functools
 import os
 import threading
 
@@ -195,6 +196,8 @@ def int_table(values):
     return (ctypes.c_int * len(values))(*[int(v) for v in values])
 
 
+@functools.lru_cache(maxsize=4096)
 def query(name, *args):
-    """Invoke a size/count helper (no error channel)."""
+    """Invoke a size/count helper (no error channel).  They are pure functions of their integer arguments,
+    so the answers are memoised: a train step asks ~30 of them with the same shapes every time."""
     return getattr(load(), name)(*args)
