@@ -248,33 +248,61 @@ __global__ __launch_bounds__(kTT) void conv1d_wgrad_generic_kernel(
     }
 }
 
-// dw[i] = sum_s slab[s][i] (fixed order -> bitwise reproducible); db likewise.  Each thread owns
-// one output and walks the S slabs with 4 independent loads in flight per iteration.
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float *__restrict__ slab,
-                                                          float *__restrict__ dw,
-                                                          float *__restrict__ db, size_t wslab,
-                                                          int Cout, int S) {
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+// dw[i] = sum_s slab[s][i], db likewise — in a FIXED order, so the result is bitwise reproducible.
+// A workgroup of G waves owns 64 consecutive outputs: wave w sums slabs w, w+G, w+2G, ... (coalesced
+// 256-byte rows, 4 independent loads in flight), the G partial sums are combined through LDS in wave
+// order.  G grows with the slab count so that small layers with many slabs (block 0: 256 slabs of
+// 23 KB) are not a handful of threads walking a long dependent chain.
+template <int G>
+__global__ __launch_bounds__(64 * G) void wgrad_reduce_kernel(const float *__restrict__ slab,
+                                                              float *__restrict__ dw,
+                                                              float *__restrict__ db, size_t wslab,
+                                                              int Cout, int S) {
+    __shared__ double part[G][64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const size_t i = (size_t)blockIdx.x * 64 + lane;
     const size_t total = wslab + Cout;
-    if (i >= total || (i >= wslab && !db)) return;
-    const float *src = i < wslab ? slab + i : slab + (size_t)S * wslab + (i - wslab);
-    const size_t stride = i < wslab ? wslab : (size_t)Cout;
+    const bool live = i < total && (i < wslab || db);
     double a = 0.0;
-    int s = 0;
-    for (; s + 4 <= S; s += 4) {
-        float v0 = src[(size_t)s * stride], v1 = src[(size_t)(s + 1) * stride];
-        float v2 = src[(size_t)(s + 2) * stride], v3 = src[(size_t)(s + 3) * stride];
-        a += (double)v0; a += (double)v1; a += (double)v2; a += (double)v3;
+    if (live) {
+        const float *src = i < wslab ? slab + i : slab + (size_t)S * wslab + (i - wslab);
+        const size_t stride = i < wslab ? wslab : (size_t)Cout;
+        int s = w;
+        for (; s + 3 * G < S; s += 4 * G) {
+            const float v0 = src[(size_t)s * stride], v1 = src[(size_t)(s + G) * stride];
+            const float v2 = src[(size_t)(s + 2 * G) * stride], v3 = src[(size_t)(s + 3 * G) * stride];
+            a += (double)v0; a += (double)v1; a += (double)v2; a += (double)v3;
+        }
+        for (; s < S; s += G) a += (double)src[(size_t)s * stride];
     }
-    for (; s < S; ++s) a += (double)src[(size_t)s * stride];
-    if (i < wslab) dw[i] = (float)a; else db[i - wslab] = (float)a;
+    if (G > 1) {
+        part[w][lane] = a;
+        __syncthreads();
+        if (w != 0) return;
+#pragma unroll
+        for (int g = 1; g < G; ++g) a += part[g][lane];
+    }
+    if (live) {
+        if (i < wslab) dw[i] = (float)a; else db[i - wslab] = (float)a;
+    }
 }
 
 int wgrad_reduce(const float *ws, float *dw, float *db, size_t wslab, int Cout, int S,
                  hipStream_t st) {
-    size_t total = wslab + Cout;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st, ws, dw, db,
-                       wslab, Cout, S);
+    const size_t total = wslab + Cout;
+    const dim3 grid(cdiv(total, 64));
+    // enough waves to fill the chip (~1024) without going below 8 slabs per wave
+    int G = 1;
+    while (G < 16 && (size_t)grid.x * G < 1024 && S / (2 * G) >= 8) G *= 2;
+#define ECG_RED(GG) hipLaunchKernelGGL((wgrad_reduce_kernel<GG>), grid, dim3(64 * GG), 0, st, ws, dw, db, wslab, Cout, S)
+    switch (G) {
+        case 1: ECG_RED(1); break;
+        case 2: ECG_RED(2); break;
+        case 4: ECG_RED(4); break;
+        case 8: ECG_RED(8); break;
+        default: ECG_RED(16); break;
+    }
+#undef ECG_RED
     return check_launch("wgrad_reduce_kernel");
 }
 
