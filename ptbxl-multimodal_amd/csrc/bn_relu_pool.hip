@@ -41,19 +41,27 @@ __global__ __launch_bounds__(kBlock) void bn_stat_partials_kernel(
         partials[((size_t)c * S + s) * 2 + tl] = red[0][tl] + red[1][tl] + red[2][tl] + red[3][tl];
 }
 
-// One wave per channel: double-precision, fixed-order combine of the P partials.
-__global__ __launch_bounds__(64) void bn_finalize_kernel(
+// One workgroup (4 waves) per channel: double-precision, fixed-order combine of the P partials
+// (thread t sums partials t, t+256, ...; lanes by butterfly; waves 0..3 in order).
+__global__ __launch_bounds__(256) void bn_finalize_kernel(
     const float *__restrict__ partials, int P, double count, float *__restrict__ mean,
     float *__restrict__ invstd, float *__restrict__ running_mean, float *__restrict__ running_var,
     long long *__restrict__ nbt, float momentum, float eps) {
-    const int c = blockIdx.x, lane = threadIdx.x;
+    __shared__ double red[4][2];
+    const int c = blockIdx.x, tl = threadIdx.x;
+    const float2 *pc = reinterpret_cast<const float2 *>(partials) + (size_t)c * P;
     double a = 0.0, q = 0.0;
-    for (int p = lane; p < P; p += 64) {
-        a += (double)partials[((size_t)c * P + p) * 2];
-        q += (double)partials[((size_t)c * P + p) * 2 + 1];
+    for (int p = tl; p < P; p += 256) {
+        const float2 v = pc[p];
+        a += (double)v.x;
+        q += (double)v.y;
     }
     a = wave_sum(a); q = wave_sum(q);
-    if (lane == 0) {
+    if ((tl & 63) == 0) { red[tl >> 6][0] = a; red[tl >> 6][1] = q; }
+    __syncthreads();
+    if (tl == 0) {
+        a = ((red[0][0] + red[1][0]) + red[2][0]) + red[3][0];
+        q = ((red[0][1] + red[1][1]) + red[2][1]) + red[3][1];
         double mu = a / count;
         double var = q / count - mu * mu;
         if (var < 0.0) var = 0.0;
@@ -315,7 +323,7 @@ ECG_API int ecg_bn_finalize(const float *stat_partials, int P, long long count, 
     ECG_REQUIRE(P > 0 && C > 0 && count > 0, "bn_finalize: P=%d C=%d count=%lld", P, C, count);
     ECG_REQUIRE((running_mean == nullptr) == (running_var == nullptr),
                 "bn_finalize: running_mean/var must both be given or both NULL");
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(64), 0, as_stream(stream), stat_partials,
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(256), 0, as_stream(stream), stat_partials,
                        P, (double)count, mean, invstd, running_mean, running_var,
                        num_batches_tracked, momentum, eps);
     return check_launch("bn_finalize_kernel");
