@@ -816,7 +816,8 @@ static WgCfg wgrad_cfg(int N, int Cin, int Cout) {
     const int tiles = cdiv(R, c.r_t) * (Cout / c.m_t);
     int s = 512 / tiles;               // fill, but never exceed, the 2 x 256 resident-workgroup slots:
                                        // one workgroup over and the launch takes two rounds.
-                                       // (64-channel tiles at 4 workgroups per CU measured no better here.)
+                                       // (64-channel tiles at 4 workgroups per CU measured no better here; nor did
+                                       // 128 x 256 column tiles for block 3: 273 vs 271 us, 236 VGPRs.)
     if (s > N) s = N;
     if (s < 1) s = 1;
     c.splits = s;
