@@ -16,7 +16,8 @@
 
 namespace ecg {
 
-constexpr int kSB = 4;   // samples per workgroup
+constexpr int kSB = 2;   // samples per workgroup
+typedef float vsb __attribute__((ext_vector_type(kSB)));
 constexpr int kLB = 32;  // global loads issued back-to-back before their first use
 
 // acc[s] += sum_{i<n} v_s[i][s] * w[i * stride]   (v_s in LDS as [n][kSB], w walks global memory).
@@ -31,16 +32,16 @@ __device__ __forceinline__ void dot_rows(float (&acc)[kSB], const float *__restr
         for (int u = 0; u < kLB; ++u) wv[u] = w[(size_t)(i + u) * stride];
 #pragma unroll
         for (int u = 0; u < kLB; ++u) {
-            const float4 v = *reinterpret_cast<const float4 *>(v_s + (i + u) * kSB);
-            acc[0] = __fmaf_rn(v.x, wv[u], acc[0]); acc[1] = __fmaf_rn(v.y, wv[u], acc[1]);
-            acc[2] = __fmaf_rn(v.z, wv[u], acc[2]); acc[3] = __fmaf_rn(v.w, wv[u], acc[3]);
+            const vsb v = *reinterpret_cast<const vsb *>(v_s + (i + u) * kSB);
+#pragma unroll
+            for (int q = 0; q < kSB; ++q) acc[q] = __fmaf_rn(v[q], wv[u], acc[q]);
         }
     }
     for (; i < n; ++i) {
         const float wv = w[(size_t)i * stride];
-        const float4 v = *reinterpret_cast<const float4 *>(v_s + i * kSB);
-        acc[0] = __fmaf_rn(v.x, wv, acc[0]); acc[1] = __fmaf_rn(v.y, wv, acc[1]);
-        acc[2] = __fmaf_rn(v.z, wv, acc[2]); acc[3] = __fmaf_rn(v.w, wv, acc[3]);
+        const vsb v = *reinterpret_cast<const vsb *>(v_s + i * kSB);
+#pragma unroll
+        for (int q = 0; q < kSB; ++q) acc[q] = __fmaf_rn(v[q], wv, acc[q]);
     }
 }
 
@@ -175,12 +176,14 @@ __global__ __launch_bounds__(256) void tail_bwd_chain_kernel(TailBwdArgs a) {
 
     // d zc = d logits Wh;  FiLM backward: d z = d zc (1+th), d film_g = d zc z (1-th^2), d film_b = d zc
     for (int o = tid; o < a.F; o += 256) {
-        float d[kSB] = {0.f, 0.f, 0.f, 0.f};
+        float d[kSB];
+#pragma unroll
+        for (int q = 0; q < kSB; ++q) d[q] = 0.f;
         for (int c = 0; c < a.C; ++c) {
             const float w = a.Wh[(size_t)c * a.F + o];
-            const float4 dl = *reinterpret_cast<const float4 *>(dlog_s + c * kSB);
-            d[0] = __fmaf_rn(dl.x, w, d[0]); d[1] = __fmaf_rn(dl.y, w, d[1]);
-            d[2] = __fmaf_rn(dl.z, w, d[2]); d[3] = __fmaf_rn(dl.w, w, d[3]);
+            const vsb dl = *reinterpret_cast<const vsb *>(dlog_s + c * kSB);
+#pragma unroll
+            for (int q = 0; q < kSB; ++q) d[q] = __fmaf_rn(dl[q], w, d[q]);
         }
 #pragma unroll
         for (int s = 0; s < kSB; ++s) {
@@ -237,7 +240,9 @@ __global__ __launch_bounds__(256) void tail_bwd_chain_kernel(TailBwdArgs a) {
 
     // d g = d z Wp: thread <-> input feature i
     for (int i = tid; i < a.F0; i += 256) {
-        float acc[kSB] = {0.f, 0.f, 0.f, 0.f};
+        float acc[kSB];
+#pragma unroll
+        for (int q = 0; q < kSB; ++q) acc[q] = 0.f;
         dot_rows(acc, dz_s, a.Wp + i, (size_t)a.F0, a.F);
 #pragma unroll
         for (int s = 0; s < kSB; ++s)
