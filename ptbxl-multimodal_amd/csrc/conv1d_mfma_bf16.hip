@@ -58,7 +58,7 @@ template <int CO_T, int T_T, int WCO, int WT, bool STATS>
 __global__ __launch_bounds__(256, 2) void conv1d_mfma_bf16_fwd_kernel(
     const float *__restrict__ x, const u16 *__restrict__ wb, const float *__restrict__ bias,
     float *__restrict__ y, float *__restrict__ partials, int Cin, int Cout, int L, int Lo, int pad,
-    int P) {
+    int P, int tiles_t) {
     static_assert(WCO * WT == 4, "4 waves per workgroup");
     constexpr int KK = kKB;
     constexpr int MC = CO_T / WCO / 32, MT = T_T / WT / 32;
@@ -81,7 +81,17 @@ __global__ __launch_bounds__(256, 2) void conv1d_mfma_bf16_fwd_kernel(
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int half = lane >> 5, l31 = lane & 31;
-    const int t0 = blockIdx.x * T_T, co0 = blockIdx.y * CO_T, n = blockIdx.z;
+    // XCD-aware tile order (as conv1d_mfma.hip): the C_out tiles of one (n, t tile) read the same x panel
+    int tile;
+    {
+        const int nwg = gridDim.x, bid = blockIdx.x;
+        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+        tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    }
+    const int CT = Cout / CO_T;
+    const int tile_co = tile % CT, tile_nt = tile / CT;
+    const int tile_t = tile_nt % tiles_t, n = tile_nt / tiles_t;
+    const int t0 = tile_t * T_T, co0 = tile_co * CO_T;
     const int wco = (wave / WT) * (CO_T / WCO), wt = (wave % WT) * (T_T / WT);
     const float *xn = x + (size_t)n * Cin * L;
     const int nchunks = (Cin + kCB - 1) / kCB;
@@ -231,7 +241,7 @@ __global__ __launch_bounds__(256, 2) void conv1d_mfma_bf16_fwd_kernel(
             float s = 0.f;
 #pragma unroll
             for (int j = 0; j < WT; ++j) s += red[((wrow * WT + j) * (CO_T / WCO) + lc) * 2 + w];
-            const int pidx = n * gridDim.x + blockIdx.x;
+            const int pidx = n * tiles_t + tile_t;
             partials[((size_t)(co0 + col) * P + pidx) * 2 + w] = s;
         }
     }
@@ -253,14 +263,15 @@ size_t bf16_packed_elems(int Cred, int Cout, int K) {       // reduction channel
 template <int CO_T, int T_T, int WCO, int WT>
 static void launch_bf16(const float *x, const u16 *wb, const float *bias, float *y, float *partials,
                         int N, int Cin, int Cout, int L, int Lo, int pad, hipStream_t st) {
-    dim3 grid(cdiv(Lo, T_T), Cout / CO_T, N), block(256);
-    const int P = N * (int)grid.x;
+    const int tiles_t = cdiv(Lo, T_T);
+    dim3 grid((unsigned)((size_t)tiles_t * (Cout / CO_T) * N)), block(256);
+    const int P = N * tiles_t;
     if (partials)
         hipLaunchKernelGGL((conv1d_mfma_bf16_fwd_kernel<CO_T, T_T, WCO, WT, true>), grid, block, 0, st,
-                           x, wb, bias, y, partials, Cin, Cout, L, Lo, pad, P);
+                           x, wb, bias, y, partials, Cin, Cout, L, Lo, pad, P, tiles_t);
     else
         hipLaunchKernelGGL((conv1d_mfma_bf16_fwd_kernel<CO_T, T_T, WCO, WT, false>), grid, block, 0, st,
-                           x, wb, bias, y, partials, Cin, Cout, L, Lo, pad, P);
+                           x, wb, bias, y, partials, Cin, Cout, L, Lo, pad, P, tiles_t);
 }
 
 int bf16_fwd(const float *x, const void *wb, const float *bias, float *y, float *partials, int N,
