@@ -186,6 +186,16 @@ int ecg_conv1d_bn_relu_pool_eval_fwd(const float *x, const float *w_fwd, const f
                                      const float *running_mean, const float *running_var,
                                      float eps, float *p, int N, int C_in, int C_out, int L,
                                      int K, int pad, ecg_stream_t stream);
+/* The same with the global average pool behind it (last block of the backbone): g [N][C_out] =
+ * mean_j max(0, max(a[2j], a[2j+1])), nothing else is written.  Covered when the conv output row fits
+ * one time tile of the kernel (Lo <= 128 for C_out % 64 == 0: 12x1000 windows; longer windows use
+ * ecg_conv1d_fwd + ecg_bn_relu_pool_gap_fwd). */
+int ecg_conv1d_bn_relu_pool_gap_eval_supported(int C_in, int C_out, int L, int K, int pad);
+int ecg_conv1d_bn_relu_pool_gap_eval_fwd(const float *x, const float *w_fwd, const float *bias,
+                                         const float *gamma, const float *beta,
+                                         const float *running_mean, const float *running_var,
+                                         float eps, float *g, int N, int C_in, int C_out, int L,
+                                         int K, int pad, ecg_stream_t stream);
 
 /* Last block of the backbone fused with AdaptiveAvgPool1d(1) (src/models/ecg_cnn.py:46,62):
  * g[n,c] = mean_j max(0, max(a[2j], a[2j+1])) — the pooled tensor is never materialised.

@@ -21,7 +21,8 @@ int mfma_fwd(const float *x, int ldx, const float *wp, const float *bias, float 
              int N, int Cin, int Cout, int L, int K, int pad, hipStream_t st);
 int mfma_fwd_eval_pool(const float *x, const float *wp, const float *bias, const float *gamma,
                        const float *beta, const float *mean, const float *var, float eps, float *p,
-                       int N, int Cin, int Cout, int L, int K, int pad, hipStream_t st);
+                       int N, int Cin, int Cout, int L, int K, int pad, hipStream_t st, int gap);
+bool mfma_fwd_eval_gap_supported(int Cin, int Cout, int L, int K, int pad);
 bool mfma_wgrad_supported(int Cin, int Cout, int K, int pad);
 size_t mfma_wgrad_ws_floats(int N, int Cin, int Cout, int L, int K);
 bool mfma_wgrad_dma_supported(int Cin, int Cout, int K);
@@ -158,5 +159,25 @@ ECG_API int ecg_conv1d_bn_relu_pool_eval_fwd(const float *x, const float *w_fwd,
     if (Lo / 2 == 0) return ECG_OK;
     ECG_REQUIRE(p, "conv1d_bn_relu_pool_eval_fwd: null output");
     return mfma_fwd_eval_pool(x, w_fwd, bias, gamma, beta, running_mean, running_var, eps, p, N,
-                              C_in, C_out, L, K, pad, as_stream(stream));
+                              C_in, C_out, L, K, pad, as_stream(stream), 0);
+}
+
+ECG_API int ecg_conv1d_bn_relu_pool_gap_eval_supported(int C_in, int C_out, int L, int K, int pad) {
+    return mfma_fwd_eval_gap_supported(C_in, C_out, L, K, pad) ? 1 : 0;
+}
+
+ECG_API int ecg_conv1d_bn_relu_pool_gap_eval_fwd(const float *x, const float *w_fwd, const float *bias,
+                                                 const float *gamma, const float *beta,
+                                                 const float *running_mean, const float *running_var,
+                                                 float eps, float *g, int N, int C_in, int C_out, int L,
+                                                 int K, int pad, ecg_stream_t stream) {
+    int rc = check_conv_shape(N, C_in, C_out, L, K, pad);
+    if (rc) return rc;
+    ECG_REQUIRE(x && w_fwd && gamma && beta && running_mean && running_var && g,
+                "conv1d_bn_relu_pool_gap_eval_fwd: null pointer");
+    ECG_REQUIRE(mfma_fwd_eval_gap_supported(C_in, C_out, L, K, pad),
+                "conv1d_bn_relu_pool_gap_eval_fwd: shape not covered (the conv output row must fit one time tile; "
+                "query ecg_conv1d_bn_relu_pool_gap_eval_supported)");
+    return mfma_fwd_eval_pool(x, w_fwd, bias, gamma, beta, running_mean, running_var, eps, g, N,
+                              C_in, C_out, L, K, pad, as_stream(stream), 1);
 }

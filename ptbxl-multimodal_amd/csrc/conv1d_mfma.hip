@@ -53,8 +53,9 @@ __device__ __forceinline__ int acc_row(int r, int half) { return (r & 3) + 8 * (
 // a condition gets sunk into a branch by hipcc and followed by s_waitcnt vmcnt(0).
 // Epilogue modes: EPI_PLAIN stores y; EPI_STATS also emits the train-mode BN (sum, sum^2)
 // partials; EPI_EVAL folds the eval-mode BatchNorm affine, ReLU and MaxPool1d(2) into the store —
-// the inference path writes only the pooled activation (one launch per ConvBlock).
-enum { EPI_PLAIN = 0, EPI_STATS = 1, EPI_EVAL = 2 };
+// the inference path writes only the pooled activation (one launch per ConvBlock); EPI_EVAL_GAP also folds
+// the global average pool behind it (last block, whole row inside one t tile): only g [N][C_out] is written.
+enum { EPI_PLAIN = 0, EPI_STATS = 1, EPI_EVAL = 2, EPI_EVAL_GAP = 3 };
 
 // XCD-aware block order.  Workgroups are dealt round-robin over the 8 XCDs (b and b+8 share an L2),
 // so neighbouring block ids — which here would be the tiles that read the SAME input panel — land on
@@ -66,14 +67,14 @@ __device__ __forceinline__ int xcd_chunked(int bid, int nwg) {
     const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
 }
-struct EvalEpi { const float *gamma, *beta, *mean, *var; float eps; };
+struct EvalEpi { const float *gamma, *beta, *mean, *var; float eps; int gap; };
 
 template <int CO_T, int T_T, int WCO, int WT, int EPI>
 __global__ __launch_bounds__(256, 2) void conv1d_mfma_fwd_kernel(
     const float *__restrict__ x, const float *__restrict__ wp, const float *__restrict__ bias,
     float *__restrict__ y, float *__restrict__ partials, int Cin, int Cout, int L, int ldx, int Lo,
     int pad, int P, int tiles_t, EvalEpi ev) {
-    constexpr bool STATS = (EPI == EPI_STATS);
+    constexpr bool STATS = (EPI == EPI_STATS), GAP = (EPI == EPI_EVAL_GAP);
     static_assert(WCO * WT == 4, "4 waves per workgroup");
     constexpr int KK = kKM, CI_C = 4, NST = KK * CI_C / 2;
     constexpr int MC = CO_T / WCO / 32, MT = T_T / WT / 32;
@@ -86,7 +87,7 @@ __global__ __launch_bounds__(256, 2) void conv1d_mfma_fwd_kernel(
     constexpr int XEL = CI_C * XS;
     constexpr int XLOADS = (XEL + 255) / 256;
     constexpr int IMG = WPAD + XEL;
-    constexpr int REDF = STATS ? 4 * (CO_T / WCO) * 2 : 0;
+    constexpr int REDF = (STATS || GAP) ? 4 * (CO_T / WCO) * 2 : 0;
     static_assert(REDF <= IMG, "stat scratch aliases image 0");
     static_assert(NST >= 2 + DPW + XLOADS, "not enough steps to spread the staging over");
 
@@ -215,7 +216,7 @@ __global__ __launch_bounds__(256, 2) void conv1d_mfma_fwd_kernel(
             const int col = wco + 32 * i + acc_row(r, half);    // channel inside the CO_T tile
             const float bv = bias ? bias[co0 + col] : 0.f;
             float s = 0.f, q = 0.f;
-            if (EPI == EPI_EVAL) {
+            if (EPI == EPI_EVAL || GAP) {
                 // p[j] = max(0, max(a[2j], a[2j+1])), a = (v - mean) * (invstd * gamma) + beta.  The two
                 // samples of a pooling pair sit on adjacent lanes: one DPP quad_perm fetches the partner.
                 const int ch = co0 + col;
@@ -228,7 +229,9 @@ __global__ __launch_bounds__(256, 2) void conv1d_mfma_fwd_kernel(
                     const float a = bn_apply1(acc[i][j][r] + bv, mu, sc, be);
                     const float o = dpp_move<0xB1>(a);                 // lane ^ 1
                     const float m = fmaxf(fmaxf(a, o), 0.f);
-                    if (!(l31 & 1) && (t >> 1) < Lp) y[((size_t)n * Cout + ch) * Lp + (t >> 1)] = m;
+                    const bool owner = !(l31 & 1) && (t >> 1) < Lp;
+                    if (GAP) s += owner ? m : 0.f;
+                    else if (owner) y[((size_t)n * Cout + ch) * Lp + (t >> 1)] = m;
                 }
             } else {
 #pragma unroll
@@ -241,7 +244,7 @@ __global__ __launch_bounds__(256, 2) void conv1d_mfma_fwd_kernel(
                     }
                 }
             }
-            if (STATS) {
+            if (STATS || GAP) {
                 s = half32_sum(s);       // 4 DPP adds + 1 bpermute, stays inside the 32-lane half
                 q = half32_sum(q);
                 if (l31 == 0) {
@@ -250,6 +253,17 @@ __global__ __launch_bounds__(256, 2) void conv1d_mfma_fwd_kernel(
                     red[(wave * (CO_T / WCO) + lc) * 2 + 1] = q;
                 }
             }
+        }
+    }
+    if (GAP) {
+        __syncthreads();
+        // global average pool: combine the WT waves of each channel row, divide by the pooled length
+        for (int col = tid; col < CO_T; col += 256) {
+            const int wrow = col / (CO_T / WCO), lc = col - wrow * (CO_T / WCO);
+            float g = 0.f;
+#pragma unroll
+            for (int j = 0; j < WT; ++j) g += red[((wrow * WT + j) * (CO_T / WCO) + lc) * 2];
+            y[(size_t)n * Cout + co0 + col] = g / (float)(Lo >> 1);
         }
     }
     if (STATS) {
@@ -295,11 +309,12 @@ static void launch_fwd(const float *x, const float *wp, const float *bias, float
     const int tiles_t = cdiv(Lo, T_T);
     dim3 grid((unsigned)((size_t)tiles_t * (Cout / CO_T) * N)), block(256);
     const int P = N * tiles_t;
-    const EvalEpi none{nullptr, nullptr, nullptr, nullptr, 0.f};
+    const EvalEpi none{nullptr, nullptr, nullptr, nullptr, 0.f, 0};
 #define ECG_FWD(MODE, EV) \
     hipLaunchKernelGGL((conv1d_mfma_fwd_kernel<CO_T, T_T, WCO, WT, MODE>), grid, block, 0, st, x, wp, \
                        bias, y, partials, Cin, Cout, L, ldx, Lo, pad, P, tiles_t, EV)
-    if (ev) ECG_FWD(EPI_EVAL, *ev);
+    if (ev && ev->gap) ECG_FWD(EPI_EVAL_GAP, *ev);
+    else if (ev) ECG_FWD(EPI_EVAL, *ev);
     else if (partials) ECG_FWD(EPI_STATS, none);
     else ECG_FWD(EPI_PLAIN, none);
 #undef ECG_FWD
@@ -324,11 +339,18 @@ int mfma_fwd(const float *x, int ldx, const float *wp, const float *bias, float 
 }
 
 // eval-mode ConvBlock in one launch: p = MaxPool2(ReLU(BN_running(conv(x))))
+// gap != 0: the global average pool is folded in too (p is then g [N][C_out]); needs the whole row in one
+// t tile — mfma_fwd_eval_gap_supported
 int mfma_fwd_eval_pool(const float *x, const float *wp, const float *bias, const float *gamma,
                        const float *beta, const float *mean, const float *var, float eps, float *p,
-                       int N, int Cin, int Cout, int L, int K, int pad, hipStream_t st) {
-    const EvalEpi ev{gamma, beta, mean, var, eps};
+                       int N, int Cin, int Cout, int L, int K, int pad, hipStream_t st, int gap) {
+    const EvalEpi ev{gamma, beta, mean, var, eps, gap};
     return mfma_fwd_any(x, wp, bias, p, nullptr, &ev, N, Cin, Cout, L, L, K, pad, st);
+}
+
+bool mfma_fwd_eval_gap_supported(int Cin, int Cout, int L, int K, int pad) {
+    const int Lo = L + 2 * pad - K + 1;
+    return mfma_fwd_supported(Cin, Cout, K, pad) && Lo >= 2 && Lo <= fwd_cfg(1, Cout, Lo).t_t;
 }
 
 // =======================================================================================

@@ -49,6 +49,8 @@ SIGNATURES = {
     "ecg_bn_relu_pool_bwd_ld": (_i, [_vp] * 7 + [_i] + [_vp] * 3 + [_i, _i, _i, _i, _vp]),
     "ecg_conv1d_bn_relu_pool_eval_supported": (_i, [_i, _i, _i, _i]),
     "ecg_conv1d_bn_relu_pool_eval_fwd": (_i, [_vp] * 7 + [_f, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "ecg_conv1d_bn_relu_pool_gap_eval_supported": (_i, [_i] * 5),
+    "ecg_conv1d_bn_relu_pool_gap_eval_fwd": (_i, [_vp] * 7 + [_f, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "ecg_bn_relu_pool_gap_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "ecg_bn_relu_pool_gap_bwd": (_i, [_vp] * 10 + [_i, _i, _i, _i, _vp]),
     "ecg_bn_relu_pool_gap_bwd_ld": (_i, [_vp] * 7 + [_i] + [_vp] * 3 + [_i, _i, _i, _i, _vp]),

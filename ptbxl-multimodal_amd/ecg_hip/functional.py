@@ -326,16 +326,22 @@ class ConvBlockFn(torch.autograd.Function):
             w_fwd, w_bwd = packed                        # packed by WeightPacker for the whole model
         else:
             w_fwd, w_bwd = conv1d_pack(w, need_bwd=need_grad and ctx.needs_input_grad[0])
-        if (not use_batch and not gap and not need_grad and not bf16
-                and _query("ecg_conv1d_bn_relu_pool_eval_supported", x.shape[1], Co, K, pad)):
-            # pure inference: conv + folded BN + ReLU + pool in one launch, y is never written
+        if not use_batch and not need_grad and not bf16:
+            # pure inference: conv + folded BN + ReLU + pool (+ global average pool) in ONE launch, y never written
             N, Ci, Lin = x.shape
             Lo = Lin + 2 * pad - K + 1
-            p = _empty(x, N, Co, Lo // 2)
-            _call("ecg_conv1d_bn_relu_pool_eval_fwd", _f32(x), _f32(w_fwd), _f32(b), _f32(gamma),
-                  _f32(beta), _f32(running_mean), _f32(running_var), float(eps), _f32(p),
-                  N, Ci, Co, Lin, K, pad, _st())
-            return p
+            if not gap and _query("ecg_conv1d_bn_relu_pool_eval_supported", Ci, Co, K, pad):
+                p = _empty(x, N, Co, Lo // 2)
+                _call("ecg_conv1d_bn_relu_pool_eval_fwd", _f32(x), _f32(w_fwd), _f32(b), _f32(gamma),
+                      _f32(beta), _f32(running_mean), _f32(running_var), float(eps), _f32(p),
+                      N, Ci, Co, Lin, K, pad, _st())
+                return p
+            if gap and _query("ecg_conv1d_bn_relu_pool_gap_eval_supported", Ci, Co, Lin, K, pad):
+                g = _empty(x, N, Co)
+                _call("ecg_conv1d_bn_relu_pool_gap_eval_fwd", _f32(x), _f32(w_fwd), _f32(b), _f32(gamma),
+                      _f32(beta), _f32(running_mean), _f32(running_var), float(eps), _f32(g),
+                      N, Ci, Co, Lin, K, pad, _st())
+                return g
         if bf16:
             y, partials, P = conv1d_forward_bf16_raw(x, w_fwd, b, Co, K, pad, want_stats=use_batch)
         else:

@@ -269,10 +269,11 @@ def test_inference_takes_the_one_launch_conv_blocks():
         out = m(x.to(DEV), xd.to(DEV))
     names = [k[0] for k in kt.result]
     assert names.count("ecg_conv1d_bn_relu_pool_eval_fwd") == 3, names
-    assert "ecg_bn_finalize" not in names
+    assert names.count("ecg_conv1d_bn_relu_pool_gap_eval_fwd") == 1, names      # last block: the average pool too
+    assert "ecg_bn_finalize" not in names and "ecg_conv1d_fwd" not in names
     with _lib.kernel_timing() as kt2:
         out_g = m(x.to(DEV), xd.to(DEV))        # grad mode on: parameters need gradients
-    assert "ecg_conv1d_bn_relu_pool_eval_fwd" not in [k[0] for k in kt2.result]
+    assert not any("eval_fwd" in k[0] for k in kt2.result)
     with torch.no_grad():
         want = ref(x, xd)
     assert (out.cpu() - want).abs().max() <= 1e-4

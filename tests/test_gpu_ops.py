@@ -470,6 +470,37 @@ def test_eval_fused_conv_bn_relu_pool(hip, oracle, shape):
     assert L.query("ecg_conv1d_bn_relu_pool_eval_supported", 7, 5, 3, 1) == 0
 
 
+@pytest.mark.parametrize("shape", [(3, 128, 256, 125), (2, 64, 128, 128), (5, 32, 64, 33), (2, 12, 32, 256), (1, 128, 256, 2)])
+def test_eval_fused_conv_bn_relu_pool_gap(hip, oracle, shape):
+    """Last block at inference: conv + running-stat BN + ReLU + MaxPool + global average pool in ONE launch."""
+    from ecg_hip import _lib as L
+    N, Ci, Co, Lin = shape
+    rng = np.random.default_rng(Ci + Lin)
+    x = rng.standard_normal((N, Ci, Lin)).astype(np.float32)
+    w = (rng.standard_normal((Co, Ci, 15)) / np.sqrt(Ci * 15)).astype(np.float32)
+    b = rng.standard_normal(Co).astype(np.float32)
+    gamma = (1 + 0.2 * rng.standard_normal(Co)).astype(np.float32)
+    beta = (0.2 * rng.standard_normal(Co)).astype(np.float32)
+    rmean = (0.3 * rng.standard_normal(Co)).astype(np.float32)
+    rvar = rng.uniform(0.5, 2.0, Co).astype(np.float32)
+    assert L.query("ecg_conv1d_bn_relu_pool_gap_eval_supported", Ci, Co, Lin, 15, 7) == 1
+    w_fwd, _ = hip.conv1d_pack(dev(w), need_bwd=False)
+    g = torch.full((N, Co), float("nan"), device="cuda")
+    args = [dev(a) for a in (x, b, gamma, beta, rmean, rvar)]
+    L.call("ecg_conv1d_bn_relu_pool_gap_eval_fwd", L.f32(args[0]), L.f32(w_fwd), *map(L.f32, args[1:]), 1e-5, L.f32(g),
+           N, Ci, Co, Lin, 15, 7, L.stream())
+    y = oracle.conv1d_fwd(x, w, b, 7)
+    invstd = (1.0 / np.sqrt(rvar.astype(np.float64) + 1e-5)).astype(np.float32)
+    rp = oracle.bn_relu_pool_fwd(y, gamma, beta, rmean, invstd)
+    np.testing.assert_allclose(host(g), rp.astype(np.float64).mean(axis=2), atol=3e-5)
+    # rows longer than one time tile are not covered: callers fall back to conv + gap kernel
+    assert L.query("ecg_conv1d_bn_relu_pool_gap_eval_supported", 128, 256, 625, 15, 7) == 0
+    assert L.query("ecg_conv1d_bn_relu_pool_gap_eval_supported", 12, 32, 257, 15, 7) == 0
+    with pytest.raises(L.EcgHipError, match="not covered"):
+        L.call("ecg_conv1d_bn_relu_pool_gap_eval_fwd", L.f32(args[0]), L.f32(w_fwd), *map(L.f32, args[1:]), 1e-5, L.f32(g),
+               N, Ci, Co, 1000, 15, 7, L.stream())
+
+
 def _bf16_round(a):
     return torch.from_numpy(np.ascontiguousarray(a)).to(torch.bfloat16).to(torch.float32).numpy()
 
