@@ -163,22 +163,41 @@ __global__ __launch_bounds__(kBlock) void bn_bwd_reduce_kernel(
     // row is shorter than the workgroup (Lp = 62 for the last block)
     const int per = FUSED ? Lp : L;
     const int total = (n1 - n0) * per;
-    for (int idx = tl; idx < total; idx += kBlock) {
-        const int nl = idx / per, j = idx - nl * per;
-        const size_t row = (size_t)(n0 + nl) * C + c;
-        const float *r = y + row * L;
-        if (FUSED) {
-            const float y0 = r[2 * j], y1 = r[2 * j + 1];
-            int am;
-            if (pool_route(y0, y1, mu, sc, be, am)) {
-                const float d = bcast != 0.f ? g[row] * bcast : g[row * Lp + j];
-                a += d;
-                q = __fmaf_rn(d, ((am ? y1 : y0) - mu) * is, q);
+    // Loads are unconditional (a load under the routing branch gets a vmcnt(0) of its own) and four
+    // iterations are in flight at once; the per-thread accumulation order is unchanged.
+    constexpr int U = 4;
+    for (int base = tl; base < total; base += U * kBlock) {
+        float y0[U], y1[U], d[U];
+        bool live[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int idx = base + u * kBlock;
+            live[u] = idx < total;
+            const int ic = live[u] ? idx : tl;                     // clamp to this thread's first (valid) element
+            const int nl = ic / per, j = ic - nl * per;
+            const size_t row = (size_t)(n0 + nl) * C + c;
+            const float *r = y + row * L;
+            if (FUSED) {
+                y0[u] = r[2 * j]; y1[u] = r[2 * j + 1];
+                d[u] = bcast != 0.f ? g[row] * bcast : g[row * Lp + j];
+            } else {
+                y0[u] = r[j]; y1[u] = 0.f;
+                d[u] = g[row * L + j];
             }
-        } else {
-            const float d = g[row * L + j];
-            a += d;
-            q = __fmaf_rn(d, (r[j] - mu) * is, q);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (!live[u]) continue;
+            if (FUSED) {
+                int am;
+                if (pool_route(y0[u], y1[u], mu, sc, be, am)) {
+                    a += d[u];
+                    q = __fmaf_rn(d[u], ((am ? y1[u] : y0[u]) - mu) * is, q);
+                }
+            } else {
+                a += d[u];
+                q = __fmaf_rn(d[u], (y0[u] - mu) * is, q);
+            }
         }
     }
     a = wave_sum(a); q = wave_sum(q);
