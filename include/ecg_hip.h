@@ -93,7 +93,7 @@ int ecg_conv1d_bwd_data(const float *dy, const float *w_bwd, float *dx,
  * weight gradient streams it global -> LDS by DMA instead of through registers.  The _ld entry
  * points accept any ldy >= Lo where the MFMA kernels apply and require ldy == Lo elsewhere; the
  * plain entry points are the ldy == Lo case. */
-int ecg_conv1d_dy_row_stride(int N, int C_in, int C_out, int L, int K, int pad);
+int ecg_conv1d_dy_row_stride(int N, int C_in, int C_out, int L, int K, int pad, int need_dx);
 int ecg_conv1d_bwd_data_ld(const float *dy, int ldy, const float *w_bwd, float *dx,
                            int N, int C_in, int C_out, int L, int K, int pad, ecg_stream_t stream);
 int ecg_conv1d_bwd_weight_bias_ld(const float *dy, int ldy, const float *x, float *dw, float *db,

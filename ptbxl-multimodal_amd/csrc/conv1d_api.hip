@@ -24,7 +24,7 @@ int mfma_fwd_eval_pool(const float *x, const float *wp, const float *bias, const
                        int N, int Cin, int Cout, int L, int K, int pad, hipStream_t st, int gap);
 bool mfma_fwd_eval_gap_supported(int Cin, int Cout, int L, int K, int pad);
 bool mfma_wgrad_supported(int Cin, int Cout, int K, int pad);
-size_t mfma_wgrad_ws_floats(int N, int Cin, int Cout, int L, int K);
+size_t mfma_wgrad_ws_floats(int N, int Cin, int Cout, int L, int K, int pad);
 bool mfma_wgrad_dma_supported(int Cin, int Cout, int K);
 int mfma_wgrad(const float *dy, int ldy, const float *x, float *dw, float *db, float *ws, int N,
                int Cin, int Cout, int L, int K, int pad, hipStream_t st);
@@ -82,11 +82,12 @@ ECG_API int ecg_conv1d_fwd(const float *x, const float *w_fwd, const float *bias
 // Row stride the fused BatchNorm backward should give dY for this layer: rows padded to a
 // multiple of 64 floats (pad zero-filled) let the weight-gradient kernel stream dY by LDS-DMA.
 // Returns Lo (dense rows) when the shape is not served by the MFMA kernels that understand it.
-ECG_API int ecg_conv1d_dy_row_stride(int N, int C_in, int C_out, int L, int K, int pad) {
+ECG_API int ecg_conv1d_dy_row_stride(int N, int C_in, int C_out, int L, int K, int pad, int need_dx) {
     (void)N;
     const int Lo = L + 2 * pad - K + 1;
     if (Lo <= 0) return Lo;
-    if (mfma_wgrad_dma_supported(C_in, C_out, K) && mfma_fwd_supported(C_out, C_in, K, K - 1 - pad))
+    // the input gradient (when it is wanted at all: not for the first layer) must understand the stride too
+    if (mfma_wgrad_dma_supported(C_in, C_out, K) && (!need_dx || mfma_fwd_supported(C_out, C_in, K, K - 1 - pad)))
         return cdiv(Lo, 64) * 64;
     return Lo;
 }
@@ -113,7 +114,7 @@ ECG_API int ecg_conv1d_bwd_data(const float *dy, const float *w_bwd, float *dx, 
 }
 
 ECG_API size_t ecg_conv1d_bwd_weight_ws_floats(int N, int C_in, int C_out, int L, int K, int pad) {
-    if (mfma_wgrad_supported(C_in, C_out, K, pad)) return mfma_wgrad_ws_floats(N, C_in, C_out, L, K);
+    if (mfma_wgrad_supported(C_in, C_out, K, pad)) return mfma_wgrad_ws_floats(N, C_in, C_out, L, K, pad);
     return direct_wgrad_ws_floats(N, C_in, C_out, K);
 }
 

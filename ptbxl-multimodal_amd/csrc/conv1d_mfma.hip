@@ -627,14 +627,16 @@ __global__ __launch_bounds__(256, 2) void conv1d_mfma_wgrad_kernel(
 //   read per lane feeds four MFMA steps.  The x tile (B operand) is register-staged as in the
 //   kernel above and read at +4h+j.
 // grid = (ceil(R/R_T), Cout/M_T, S); T_T = 64; slab layout as above.
-template <int M_T, int R_T, int WM, int WR, int KK>
+template <int M_T, int R_T, int WM, int WR, int WK, int KK>
 __global__ __launch_bounds__(256, 2) void conv1d_mfma_wgrad_dma_kernel(
     const float *__restrict__ dy, const float *__restrict__ x, float *__restrict__ slab, int N,
     int Cin, int Cout, int L, int Lo, int ldy, int pad, int S) {
-    static_assert(WM * WR == 4, "4 waves per workgroup");
+    static_assert(WM * WR * WK == 4, "4 waves per workgroup");
     constexpr int T_T = 64;
     constexpr int MC = M_T / WM / 32, MR = R_T / WR / 32;
-    constexpr int NST = T_T / 2, NGRP = NST / 4;        // 32 reduction steps = 8 groups of 4
+    constexpr int TW = T_T / WK;                        // WK > 1: the waves split the stage's t range (32-channel layer)
+    constexpr int NST = TW / 2, NGRP = NST / 4;         // reduction steps per stage, in groups of 4
+    static_assert(NST % 4 == 0, "whole groups of four steps");
     constexpr int XSPAN = T_T + KK - 1;
     constexpr int XS = ((XSPAN - KK + 31) / 32) * 32 + KK;   // >= XSPAN and == KK (mod 32)
     constexpr int NCI = (R_T + KK - 2) / KK + 1;
@@ -643,6 +645,8 @@ __global__ __launch_bounds__(256, 2) void conv1d_mfma_wgrad_dma_kernel(
     constexpr int NDMA = AEL / 256;                     // 1 KB pieces (4 rows each)
     constexpr int DPW = NDMA / 4;                       // pieces per wave per stage
     constexpr int IMG = ((AEL + XEL + 63) / 64) * 64;   // keeps image 1 16-byte aligned
+    constexpr int ACCF = MC * MR * 16 * 64;             // floats of one wave's accumulators (WK > 1 exchange)
+    static_assert(WK == 1 || WM * WR * ACCF + 4 * 32 <= 2 * IMG, "accumulator exchange must fit the dead images");
     static_assert(XS >= XSPAN, "x row stride too small");
     static_assert(NDMA % 4 == 0, "dY image must split evenly over the four waves");
     static_assert(XLOADS <= 32, "mask bits");
@@ -658,10 +662,13 @@ __global__ __launch_bounds__(256, 2) void conv1d_mfma_wgrad_dma_kernel(
     const int tile = xcd_chunked(blockIdx.x, gridDim.x);
     const int tile_r = tile % RT, tile_cs = tile / RT;
     const int r0 = tile_r * R_T, co0 = (tile_cs % CT) * M_T, s = tile_cs / CT;
-    const int wr = wave % WR, wm = wave / WR;
-    const int wm0 = wm * (M_T / WM), wr0 = wr * (R_T / WR);
+    const int wk = wave % WK, wr = (wave / WK) % WR, wm = wave / (WK * WR);
+    const int wm0 = wm * (M_T / WM), wr0 = wr * (R_T / WR), wt0 = wk * TW;
     const int ci_base = r0 / KK;
-    const int n_begin = (int)((long long)N * s / S), n_end = (int)((long long)N * (s + 1) / S);
+    const int ntt = (Lo + T_T - 1) / T_T;
+    // the split runs over stages (n, t tile), not whole samples: finer balance, and enough workgroups for
+    // layers with a single output tile
+    const int it_begin = (int)((long long)N * ntt * s / S), it_end = (int)((long long)N * ntt * (s + 1) / S);
 
     int xcol[MR];
 #pragma unroll
@@ -700,21 +707,20 @@ __global__ __launch_bounds__(256, 2) void conv1d_mfma_wgrad_dma_kernel(
     }
     float xreg[XLOADS];
     unsigned xmask = 0, cxmask = 0;
-    const int ntt = (Lo + T_T - 1) / T_T;
-    const int total = (n_end - n_begin) * ntt;
+    const int total = it_end - it_begin;
 
     // stage coordinates advance incrementally (uniform, no division in the loop)
-    int sn = n_begin, stt = 0;          // stage whose x tile is loaded next
-    int dn = n_begin, dtt = 0;          // stage whose dY tile is DMA'd next
+    int sn = it_begin / ntt, stt = it_begin - sn * ntt;     // stage whose x tile is loaded next
+    int dn = sn, dtt = stt;                                 // stage whose dY tile is DMA'd next
     auto advance = [&]() { if (++stt == ntt) { stt = 0; ++sn; } };
     auto dma_a = [&](int j, float *img) {               // one 1 KB piece of stage (dn, dtt)'s dY tile
-        const float *base = dy + ((size_t)min(dn, n_end - 1) * Cout + co0) * ldy + dtt * T_T;
+        const float *base = dy + ((size_t)min(dn, N - 1) * Cout + co0) * ldy + dtt * T_T;
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(base + doff[j]),
                                          (__attribute__((address_space(3))) void *)(img + (j * 4 + wave) * 256),
                                          16, 0, 0);
     };
     auto load_x = [&](int j) {                          // x tile element of stage (sn, stt)
-        const float *xn = x + (size_t)min(sn, n_end - 1) * Cin * L;
+        const float *xn = x + (size_t)min(sn, N - 1) * Cin * L;
         const int sidx = stt * T_T + xpos[j];
         xreg[j] = xn[xci[j] + min(max(sidx, 0), L - 1)];
         const unsigned bit = ((sidx >= 0) && (sidx < L)) ? (1u << j) : 0u;
@@ -751,11 +757,11 @@ __global__ __launch_bounds__(256, 2) void conv1d_mfma_wgrad_dma_kernel(
         cxmask = xmask;                                    // mask of stage it+1 (now in registers)
 
         const float *arow = dys + aoff;
-        const float *brow = xs + 4 * half;
+        const float *brow = xs + 4 * half + wt0;
         auto lda = [&](int g, f32x4 *a) {                  // group g: chunk 2g+half, swizzled
 #pragma unroll
             for (int i = 0; i < MC; ++i)
-                a[i] = *reinterpret_cast<const f32x4 *>(arow + 32 * i * T_T + ((((2 * g) << 2) + (half << 2)) ^ swz));
+                a[i] = *reinterpret_cast<const f32x4 *>(arow + 32 * i * T_T + ((((2 * g) << 2) + (half << 2) + wt0) ^ swz));
         };
         auto ldb = [&](int st, float *b) {
             const int tp = 8 * (st >> 2) + (st & 3);
@@ -801,6 +807,34 @@ __global__ __launch_bounds__(256, 2) void conv1d_mfma_wgrad_dma_kernel(
 #pragma unroll
         for (int i = 0; i < MC; ++i) bsum[i] += __shfl_xor(bsum[i], 32, 64);
     }
+    if (WK > 1) {
+        // sum the WK waves that share an output tile through LDS, in wave order (the images are dead)
+        float *ex = lds + (wr + WR * wm) * ACCF, *bex = lds + WM * WR * ACCF;
+        for (int w = 1; w < WK; ++w) {
+            __syncthreads();
+            if (wk == w) {
+#pragma unroll
+                for (int i = 0; i < MC; ++i)
+#pragma unroll
+                    for (int j = 0; j < MR; ++j)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) ex[((i * MR + j) * 16 + r) * 64 + lane] = acc[i][j][r];
+                if (want_bias && half == 0 && MC == 1) bex[(wr + WR * wm) * 32 + l31] = bsum[0];
+            }
+            __syncthreads();
+            if (wk == 0) {
+#pragma unroll
+                for (int i = 0; i < MC; ++i)
+#pragma unroll
+                    for (int j = 0; j < MR; ++j)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) acc[i][j][r] += ex[((i * MR + j) * 16 + r) * 64 + lane];
+                if (want_bias && half == 0 && MC == 1) bsum[0] += bex[(wr + WR * wm) * 32 + l31];
+            }
+        }
+        static_assert(WK == 1 || MC == 1, "the bias exchange above assumes one 32-channel row per wave");
+        if (wk != 0) return;
+    }
     const size_t wslab = (size_t)Cout * R;
     float *out = slab + (size_t)s * wslab;
 #pragma unroll
@@ -829,7 +863,7 @@ int wgrad_reduce(const float *ws, float *dw, float *db, size_t wslab, int Cout, 
 
 struct WgCfg { int m_t, r_t, splits; };
 
-static WgCfg wgrad_cfg(int N, int Cin, int Cout) {
+static WgCfg wgrad_cfg(int N, int Cin, int Cout, int Lo, bool dma) {
     const int R = Cin * kKM;
     WgCfg c;
     if (Cout % 128 == 0) c = {128, 128, 0};
@@ -840,7 +874,9 @@ static WgCfg wgrad_cfg(int N, int Cin, int Cout) {
                                        // one workgroup over and the launch takes two rounds.
                                        // (64-channel tiles at 4 workgroups per CU measured no better here; nor did
                                        // 128 x 256 column tiles for block 3: 273 vs 271 us, 236 VGPRs.)
-    if (s > N) s = N;
+    // the DMA kernel splits over stages (n, 64-wide t tile), the register-staged one over samples
+    const long long cap = dma ? (long long)N * cdiv(Lo, 64) : N;
+    if (s > cap) s = (int)cap;
     if (s < 1) s = 1;
     c.splits = s;
     return c;
@@ -851,30 +887,31 @@ bool mfma_wgrad_supported(int Cin, int Cout, int K, int pad) {
     return K == kKM && Cout % 32 == 0;
 }
 
-size_t mfma_wgrad_ws_floats(int N, int Cin, int Cout, int L, int K) {
-    (void)L;
-    const WgCfg c = wgrad_cfg(N, Cin, Cout);
-    return (size_t)c.splits * ((size_t)Cout * Cin * K + Cout);
+size_t mfma_wgrad_ws_floats(int N, int Cin, int Cout, int L, int K, int pad) {
+    const int Lo = L + 2 * pad - K + 1;
+    const WgCfg a = wgrad_cfg(N, Cin, Cout, Lo, false), b = wgrad_cfg(N, Cin, Cout, Lo, true);
+    return (size_t)(a.splits > b.splits ? a.splits : b.splits) * ((size_t)Cout * Cin * K + Cout);
 }
 
 // dY rows that the DMA kernel can stream: 64-float multiples with a zero pad (see the kernel)
 bool mfma_wgrad_dma_supported(int Cin, int Cout, int K) {
     (void)Cin;
-    return K == kKM && Cout % 64 == 0;
+    return K == kKM && Cout % 32 == 0;
 }
 
 int mfma_wgrad(const float *dy, int ldy, const float *x, float *dw, float *db, float *ws, int N,
                int Cin, int Cout, int L, int K, int pad, hipStream_t st) {
     const int Lo = L + 2 * pad - K + 1;
     const int R = Cin * K;
-    const WgCfg c = wgrad_cfg(N, Cin, Cout);
-    dim3 grid((unsigned)(cdiv(R, c.r_t) * (Cout / c.m_t) * c.splits)), block(256);
     const bool dma = mfma_wgrad_dma_supported(Cin, Cout, K) && ldy % 64 == 0 && ldy >= cdiv(Lo, 64) * 64 &&
                      (reinterpret_cast<uintptr_t>(dy) & 15) == 0;
+    const WgCfg c = wgrad_cfg(N, Cin, Cout, Lo, dma);
+    dim3 grid((unsigned)(cdiv(R, c.r_t) * (Cout / c.m_t) * c.splits)), block(256);
 #define ECG_WG(KERNEL) \
     hipLaunchKernelGGL(KERNEL, grid, block, 0, st, dy, x, ws, N, Cin, Cout, L, Lo, ldy, pad, c.splits)
-    if (dma && c.m_t == 128) ECG_WG((conv1d_mfma_wgrad_dma_kernel<128, 128, 2, 2, kKM>));
-    else if (dma) ECG_WG((conv1d_mfma_wgrad_dma_kernel<64, 128, 2, 2, kKM>));
+    if (dma && c.m_t == 128) ECG_WG((conv1d_mfma_wgrad_dma_kernel<128, 128, 2, 2, 1, kKM>));
+    else if (dma && c.m_t == 64) ECG_WG((conv1d_mfma_wgrad_dma_kernel<64, 128, 2, 2, 1, kKM>));
+    else if (dma) ECG_WG((conv1d_mfma_wgrad_dma_kernel<32, 192, 1, 2, 2, kKM>));
     else if (c.m_t == 128) ECG_WG((conv1d_mfma_wgrad_kernel<128, 128, 2, 2, 1, 64, kKM>));
     else if (c.m_t == 64) ECG_WG((conv1d_mfma_wgrad_kernel<64, 128, 2, 2, 1, 64, kKM>));
     else ECG_WG((conv1d_mfma_wgrad_kernel<32, 192, 1, 1, 4, 128, kKM>));

@@ -374,7 +374,7 @@ class ConvBlockFn(torch.autograd.Function):
         # (rows padded to 64 floats, zero pad -> LDS-DMA in the weight gradient)
         need_dx = ctx.needs_input_grad[0]
         ldy = Lo if (ctx.bf16 and need_dx) else _query("ecg_conv1d_dy_row_stride", N, x.shape[1], Co,
-                                                       x.shape[2], w.shape[2], ctx.pad)
+                                                       x.shape[2], w.shape[2], ctx.pad, int(bool(need_dx)))
         dy = _empty(y, N, Co, ldy)
         kw, kb, kg, kbe = ctx.sink_keys
         dgamma, dbeta = _grad_out(kg, y, Co), _grad_out(kbe, y, Co)

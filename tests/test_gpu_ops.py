@@ -141,7 +141,7 @@ def test_bn_relu_pool_fwd_bwd(hip, oracle, shape, train):
 # (N, Ci, Co, L): row-padded dY (ldy = 64-multiple, zero pad) through the _ld entry points — the
 # layout ConvBlockFn.backward uses so that the weight gradient streams dY by LDS-DMA
 @pytest.mark.parametrize("case", [(3, 32, 64, 250), (2, 64, 128, 125), (5, 128, 256, 62), (2, 64, 128, 64),
-                                  (1, 32, 64, 1), (4, 128, 256, 129), (37, 64, 128, 70)])
+                                  (1, 32, 64, 1), (4, 128, 256, 129), (37, 64, 128, 70), (3, 32, 96, 100)])
 def test_row_padded_dy_entry_points(hip, oracle, case):
     from ecg_hip import _lib as L
     N, Ci, Co, Lin = case
@@ -150,7 +150,7 @@ def test_row_padded_dy_entry_points(hip, oracle, case):
     x = rng.standard_normal((N, Ci, Lin)).astype(np.float32)
     w = (rng.standard_normal((Co, Ci, K)) / np.sqrt(Ci * K)).astype(np.float32)
     dy = rng.standard_normal((N, Co, Lin)).astype(np.float32)
-    ldy = L.query("ecg_conv1d_dy_row_stride", N, Ci, Co, Lin, K, pad)
+    ldy = L.query("ecg_conv1d_dy_row_stride", N, Ci, Co, Lin, K, pad, 1)
     assert ldy % 64 == 0 and Lin <= ldy < Lin + 64
     dyp = np.zeros((N, Co, ldy), np.float32)
     dyp[:, :, :Lin] = dy
@@ -168,10 +168,32 @@ def test_row_padded_dy_entry_points(hip, oracle, case):
     np.testing.assert_allclose(host(dw), host(dw0), atol=2e-6 * scale + 2e-5)
 
 
+@pytest.mark.parametrize("case", [(5, 12, 32, 300), (2, 12, 32, 1000), (3, 12, 32, 64), (1, 12, 32, 7), (37, 12, 32, 130)])
+def test_row_padded_dy_first_layer_weight_grad(hip, oracle, case):
+    """Block-0 geometry (C_out = 32, no input-grad): the weight gradient streams a row-padded dY too —
+    32-channel tile, the two wave pairs split each stage's time range and are summed through LDS."""
+    from ecg_hip import _lib as L
+    N, Ci, Co, Lin = case
+    rng = np.random.default_rng(sum(case))
+    x = rng.standard_normal((N, Ci, Lin)).astype(np.float32)
+    dy = rng.standard_normal((N, Co, Lin)).astype(np.float32)
+    ldy = L.query("ecg_conv1d_dy_row_stride", N, Ci, Co, Lin, 15, 7, 0)
+    assert ldy % 64 == 0 and Lin <= ldy < Lin + 64
+    dyp = np.zeros((N, Co, ldy), np.float32)
+    dyp[:, :, :Lin] = dy
+    xd, dyd = dev(x), dev(dyp)
+    _, dw, db = hip.conv1d_backward_raw(xd, dyd, (Co, Ci, 15), None, 7, need_dx=False, ldy=ldy)
+    rdw, rdb = oracle.conv1d_bwd_weight(dy, x, 15, 7)
+    scale = np.sqrt(N * Lin)
+    np.testing.assert_allclose(host(dw), rdw, atol=2e-6 * scale + 2e-5)
+    np.testing.assert_allclose(host(db), rdb, atol=2e-6 * scale + 2e-5)
+
+
 def test_row_padded_dy_is_refused_where_unsupported(hip):
     from ecg_hip import _lib as L
-    assert L.query("ecg_conv1d_dy_row_stride", 4, 12, 32, 100, 15, 7) == 100     # block 0: dense rows
-    assert L.query("ecg_conv1d_dy_row_stride", 4, 7, 12, 50, 3, 1) == 50
+    assert L.query("ecg_conv1d_dy_row_stride", 4, 12, 32, 100, 15, 7, 1) == 100  # an input-grad that cannot read strided rows
+    assert L.query("ecg_conv1d_dy_row_stride", 4, 12, 32, 100, 15, 7, 0) == 128  # block 0: no input-grad -> padded
+    assert L.query("ecg_conv1d_dy_row_stride", 4, 7, 12, 50, 3, 1, 0) == 50
     x, dy = torch.zeros(2, 7, 50, device="cuda"), torch.zeros(2, 12, 64, device="cuda")
     w_bwd = torch.zeros(3, 12, 7, device="cuda")
     with pytest.raises(L.EcgHipError, match="dense dY rows"):
