@@ -92,7 +92,8 @@ int ecg_conv1d_bwd_data(const float *dy, const float *w_bwd, float *dx,
  * ([N][C_out][ldy], zeros in [Lo, ldy) — ecg_bn_relu_pool_bwd_ld / _gap_bwd_ld write them) and the
  * weight gradient streams it global -> LDS by DMA instead of through registers.  The _ld entry
  * points accept any ldy >= Lo where the MFMA kernels apply and require ldy == Lo elsewhere; the
- * plain entry points are the ldy == Lo case. */
+ * plain entry points are the ldy == Lo case.  need_dx: whether ecg_conv1d_bwd_data_ld will be called on
+ * this dY too (not for the first layer) — the stride must then be one the input-gradient kernel reads. */
 int ecg_conv1d_dy_row_stride(int N, int C_in, int C_out, int L, int K, int pad, int need_dx);
 int ecg_conv1d_bwd_data_ld(const float *dy, int ldy, const float *w_bwd, float *dx,
                            int N, int C_in, int C_out, int L, int K, int pad, ecg_stream_t stream);
