@@ -157,9 +157,10 @@ def test_g6_gradcam_hooks_and_demo_gradient():
         np.testing.assert_allclose(l2.cpu().numpy(), logits.detach().cpu().numpy(), atol=2e-5)
 
 
-@pytest.mark.parametrize("name", ["cnn5", "mm"])
-def test_full_size_train_step_vs_cpu_oracle(name):
-    """BASELINE.json size (B=256, 12x1000): one train step vs the stock-torch CPU restatement."""
+@pytest.mark.parametrize("name,B,T", [("cnn5", 256, 1000), ("mm", 256, 1000), ("cnn1", 64, 5000)])
+def test_full_size_train_step_vs_cpu_oracle(name, B, T):
+    """BASELINE.json sizes (B=256, 12x1000; the AF-binary 12x5000 window of config 5 at B=64): one train
+    step vs the stock-torch CPU restatement."""
     from ecg_hip.optim import FlatAdamW
     from src.utils.seed import set_seed
     from ecg_hip import functional as hipF
@@ -168,7 +169,7 @@ def test_full_size_train_step_vs_cpu_oracle(name):
     model = ctor().to(DEV).train()
     R.seed_all(42)
     ref = rctor().train()
-    batch = R.synthetic_batch(256, 1000, C, demo=demo)
+    batch = R.synthetic_batch(B, T, C, demo=demo)
     opt = FlatAdamW(model.parameters(), lr=1e-4, weight_decay=1e-4)
     ropt = R.make_adamw(ref, 1e-4, 1e-4)
     opt.zero_grad()
