@@ -76,6 +76,50 @@ def test_conv_vs_oracle(hip, oracle, case):
     np.testing.assert_allclose(db, rdb, atol=2e-6 * scale + 2e-5)
 
 
+def _random_conv_cases(n, seed):
+    rng = np.random.default_rng(seed)
+    out = []
+    for _ in range(n):
+        out.append((int(rng.integers(1, 41)), int(rng.choice([4, 8, 12, 20, 32, 64, 128])),
+                    int(rng.choice([32, 64, 96, 128, 256])), int(rng.integers(1, 700))))
+    return out
+
+
+@pytest.mark.parametrize("case", _random_conv_cases(36, 2024))
+def test_conv_random_shapes_vs_oracle(hip, oracle, case):
+    """Seeded sweep over MFMA-path shapes: odd grid sizes for the XCD-chunked tile order (it must stay a
+    bijection for any workgroup count), ragged time tiles, stage-level splits of the weight gradient with
+    both dY layouts (dense rows: register-staged kernel; row-padded: DMA kernel)."""
+    from ecg_hip import _lib as L
+    N, Ci, Co, Lin = case
+    rng = np.random.default_rng(sum(case) * 7919 + Lin)
+    x = rng.standard_normal((N, Ci, Lin)).astype(np.float32)
+    w = (rng.standard_normal((Co, Ci, 15)) / np.sqrt(Ci * 15)).astype(np.float32)
+    b = rng.standard_normal(Co).astype(np.float32)
+    dy = rng.standard_normal((N, Co, Lin)).astype(np.float32)
+    xd, wd, bd, dyd = dev(x), dev(w), dev(b), dev(dy)
+    w_fwd, w_bwd = hip.conv1d_pack(wd)
+    y, _, _ = hip.conv1d_forward_raw(xd, w_fwd, bd, Co, 15, 7, want_stats=False)
+    np.testing.assert_allclose(host(y), oracle.conv1d_fwd(x, w, b, 7), rtol=2e-5, atol=3e-5)
+    need_dx = Ci % 32 == 0                      # the MFMA input-grad needs C_in % 32 == 0; otherwise the direct kernel
+    dx, dw, db = hip.conv1d_backward_raw(xd, dyd, w.shape, w_bwd, 7, need_dx=True)
+    np.testing.assert_allclose(host(dx), oracle.conv1d_bwd_data(dy, w, Lin, 7), rtol=2e-5, atol=6e-5)   # fp32 sums of up to 3840 terms
+    rdw, rdb = oracle.conv1d_bwd_weight(dy, x, 15, 7)
+    tol = 2e-6 * np.sqrt(N * Lin) + 3e-5
+    np.testing.assert_allclose(host(dw), rdw, rtol=2e-5, atol=tol)
+    np.testing.assert_allclose(host(db), rdb, rtol=2e-5, atol=tol)
+    ldy = L.query("ecg_conv1d_dy_row_stride", N, Ci, Co, Lin, 15, 7, int(need_dx))
+    if ldy != Lin:
+        dyp = np.zeros((N, Co, ldy), np.float32)
+        dyp[:, :, :Lin] = dy
+        dypd = dev(dyp)
+        dx2, dw2, db2 = hip.conv1d_backward_raw(xd, dypd, w.shape, w_bwd, 7, need_dx=need_dx, ldy=ldy)
+        np.testing.assert_allclose(host(dw2), rdw, rtol=2e-5, atol=tol)
+        np.testing.assert_allclose(host(db2), rdb, rtol=2e-5, atol=tol)
+        if need_dx:
+            np.testing.assert_array_equal(host(dx2), host(dx))
+
+
 def test_conv_stats_epilogue_and_finalize(hip, oracle):
     from ecg_hip import _lib as L
     rng = np.random.default_rng(3)
