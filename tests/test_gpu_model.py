@@ -325,6 +325,36 @@ def test_gradients_land_in_the_flat_buffer_and_still_accumulate():
     assert all(not (lo <= p.grad.data_ptr() < hi) for p in m.parameters())
 
 
+def test_hooked_block_trains_like_the_fused_path_with_flat_optimizer():
+    """A forward hook on an inner module switches that block to the unfused leaves, whose gradients are ordinary
+    tensors while the other blocks write into FlatAdamW's flat buffer: the optimizer must repair the mix
+    (no gather may read what it overwrites) and land on the same parameters as the all-fused step."""
+    from ecg_hip.optim import FlatAdamW
+    from src.models.ecg_cnn import ECGCNN
+    from src.training.loop import train_one_epoch
+    from src.utils.seed import set_seed
+    x, y = R.synthetic_batch(8, 1000, 5)
+    states = []
+    for hooked in (False, True):
+        set_seed(42)
+        m = ECGCNN(num_labels=5).to(DEV)
+        seen = []
+        if hooked:
+            m.backbone[2].net[0].register_forward_hook(lambda mod, inp, out: seen.append(tuple(out.shape)))
+        opt = FlatAdamW(m.parameters(), lr=1e-3, weight_decay=1e-4)
+        for _ in range(2):
+            train_one_epoch(m, torch.utils.data.DataLoader(_DS(x, y), batch_size=8), opt, DEV)
+        assert (len(seen) == 2 and seen[0] == (8, 128, 250)) if hooked else not seen
+        states.append({k: v.detach().cpu() for k, v in m.state_dict().items()})
+    for k in states[0]:
+        if k.endswith("num_batches_tracked"):
+            assert int(states[0][k]) == int(states[1][k]) == 2
+        else:
+            # two AdamW steps at lr 1e-3: noise-level gradients may move by +-lr per step on either path
+            assert (states[0][k] - states[1][k]).abs().max() <= 2.02 * 1e-3 * 2, k
+            assert ((states[0][k] - states[1][k]).abs() > 0.3 * 1e-3 * 2).float().mean() <= 0.03 or states[0][k].numel() < 70, k
+
+
 def test_legacy_concat_fusion_model_vs_stock_torch():
     """§8(f)-4: the reconstructed concat-fusion model on the HIP leaves against the same module
     tree built from stock torch layers (no reference output exists for it)."""
