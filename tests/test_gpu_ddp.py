@@ -84,3 +84,26 @@ def test_two_ranks_share_one_gpu(tmp_path, overlap):
         assert np.mean(np.abs(r0[k] - w) > 0.3 * lr * 2) <= 0.03 or r0[k].size < 70, k
     np.testing.assert_allclose(r0["losses"], want_losses[:, 0], atol=2e-4)
     np.testing.assert_allclose(r1["losses"], want_losses[:, 1], atol=2e-4)
+
+
+def test_bench_two_rank_line(tmp_path):
+    """bench.py exactly as the driver launches it for N > 1 (torch.distributed.run, one rank per process),
+    rehearsed with both ranks on one device: one JSON line from rank 0 with the contract's fields."""
+    import json
+    env = dict(os.environ, ECG_HIP_REHEARSE_ON_ONE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2", "--batch", "32"]
+    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, res.stderr[-3000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, res.stdout[-2000:]
+    d = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline"):
+        assert key in d, key
+    assert d["n_gpus"] == 2 and d["steps"] == 4 and d["scaling"] == "weak" and d["unit"] == "windows/s"
+    assert d["config"]["global_batch"] == 64 and d["config"]["parallelism"] == "dp2"
+    assert "cpu_baseline" not in d                      # rank 0 at N = 1 only
+    assert abs(d["value"] - 64 * 4 / (d["ms_per_step"] * 4 * 1e-3)) / d["value"] < 1e-3
+    assert d["also"]["value"] > 0
