@@ -13,7 +13,8 @@ for p in (ROOT, os.path.join(ROOT, "ptbxl-multimodal_amd")):
 
 
 def main():
-    out_dir, overlap = sys.argv[1], sys.argv[2] == "1"
+    out_dir, mode = sys.argv[1], sys.argv[2]          # mode: "1"/"0" = FlatAdamW with/without overlap, "wrap" = FlatGradDDP
+    overlap = mode == "1"
     from ecg_hip import ddp
     from ecg_hip.optim import FlatAdamW
     from oracle import ref_models as R
@@ -26,10 +27,15 @@ def main():
     set_seed(42 + rank)                                   # different replicas: rank 0 must win
     model = ECGMultimodal().to(dev)
     ddp.broadcast_module_state(model, 0)
-    opt = FlatAdamW(model.parameters(), lr=1e-4, weight_decay=1e-4, overlap=overlap)
+    step_model = model
+    if mode == "wrap":                                    # stock optimizer + the gradient-averaging wrapper
+        step_model = ddp.FlatGradDDP(model)
+        opt = torch.optim.AdamW(model.parameters(), lr=1e-4, weight_decay=1e-4)
+    else:
+        opt = FlatAdamW(model.parameters(), lr=1e-4, weight_decay=1e-4, overlap=overlap)
     batch = R.synthetic_batch(16, 1000, 5, demo=True)     # global batch 16 -> 8 windows per rank
     shard = tuple(t.to(dev) for t in ddp.shard_batch(batch, rank, world))
-    losses = [train_one_epoch_demo(model, [shard], opt, dev) for _ in range(2)]      # two steps
+    losses = [train_one_epoch_demo(step_model, [shard], opt, dev) for _ in range(2)]      # two steps
     torch.cuda.synchronize()
     np.savez(os.path.join(out_dir, f"rank{rank}.npz"), losses=np.array(losses),
              **{k: v.detach().cpu().numpy() for k, v in model.state_dict().items()})

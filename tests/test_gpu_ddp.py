@@ -58,12 +58,13 @@ def _oracle_two_shards(steps=2):
     return model.state_dict(), np.array(losses)
 
 
-@pytest.mark.parametrize("overlap", [True, False])
+@pytest.mark.parametrize("overlap", [True, False, "wrap"])
 def test_two_ranks_share_one_gpu(tmp_path, overlap):
     env = dict(os.environ, ECG_HIP_REHEARSE_ON_ONE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
            "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
-           os.path.join(ROOT, "tests", "ddp_gpu_worker.py"), str(tmp_path), "1" if overlap else "0"]
+           os.path.join(ROOT, "tests", "ddp_gpu_worker.py"), str(tmp_path),
+           "wrap" if overlap == "wrap" else ("1" if overlap else "0")]
     res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
     assert res.returncode == 0, res.stderr[-3000:]
     r0, r1 = (dict(np.load(tmp_path / f"rank{r}.npz")) for r in range(2))
