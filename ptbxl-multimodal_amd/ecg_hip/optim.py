@@ -82,11 +82,18 @@ class FlatAdamW(torch.optim.Optimizer):
         self._split = sum(p.numel() for p in self._params[:self._n_early])      # flat offset of the late bucket
         self._late_pending = 0
         self._late_work = None
+        self._early_pending = 0
+        self._early_work = None
         self._overlap = bool(overlap) and world_size > 1 and 0 < self._n_early < len(self._params)
         if self._overlap:
             self._late_total = len(self._params) - self._n_early
             for p in self._params[self._n_early:]:
                 p.register_post_accumulate_grad_hook(self._on_late_grad)
+            # the early bucket cannot hide under backward (its gradients are the last to arrive), but its
+            # all-reduce can at least be issued from the hook of its last gradient instead of waiting for
+            # Python to come back from backward() and reach step()
+            for p in self._params[:self._n_early]:
+                p.register_post_accumulate_grad_hook(self._on_early_grad)
 
     def __del__(self):
         try:
@@ -132,6 +139,16 @@ class FlatAdamW(torch.optim.Optimizer):
             late = self.flat_grad[self._split:]
             self._late_work = torch.distributed.all_reduce(late, group=self.process_group, async_op=True)
 
+    def _on_early_grad(self, _param):
+        self._early_pending += 1
+        if self._early_pending < self._n_early:
+            return
+        self._early_pending = 0
+        with torch.no_grad():
+            self._gather(0, self._n_early)
+            self._early_work = torch.distributed.all_reduce(self.flat_grad[:self._split], group=self.process_group,
+                                                            async_op=True)
+
     @torch.no_grad()
     def reduce_gradients(self):
         """Flat gradient of this step, summed over ranks; returns (flat, scale) where
@@ -139,13 +156,26 @@ class FlatAdamW(torch.optim.Optimizer):
         late bucket was already launched from the backward hooks."""
         if self._late_work is not None:                       # late bucket is in flight / done
             g = self.flat_grad
-            early = g[:self._split]
-            self._gather(0, self._n_early)
-            torch.distributed.all_reduce(early, group=self.process_group)
+            if self._early_work is not None:                  # issued from the hook of its last gradient
+                self._early_work.wait()
+                self._early_work = None
+            else:                                             # some early gradient never arrived (unused parameter)
+                self._early_pending = 0
+                self._gather(0, self._n_early)
+                torch.distributed.all_reduce(g[:self._split], group=self.process_group)
             self._late_work.wait()
             self._late_work = None
             return g, 1.0 / self.world_size
         self._late_pending = 0
+        self._early_pending = 0
+        if self._early_work is not None:                      # early bucket went out but the late one did not: finish it,
+            self._early_work.wait()                           # then fall through to one all-reduce of everything else
+            self._early_work = None
+            g = self.flat_grad
+            self._gather(self._n_early, len(self._params))
+            if self.world_size > 1:
+                torch.distributed.all_reduce(g[self._split:], group=self.process_group)
+            return g, 1.0 / self.world_size
         g = self.flat_grad
         self._gather(0, len(self._params))
         if self.world_size > 1:
