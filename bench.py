@@ -1,21 +1,33 @@
 #!/usr/bin/env python3
 """bench.py — ECG windows/s of the full train step (fwd + BCE + bwd + AdamW) on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W            (N > 1: starts its own N rank processes)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
-Workload (BASELINE.json configs[2]/[3]): ECGMultimodal, 12x1000 fp32 synthetic
-windows, batch 256 PER GPU (weak scaling), inputs resident in HBM, driven through the
-reference's own loop API (src.training.loop_demo.train_one_epoch_demo) with the flat AdamW;
-with N > 1 the gradient exchange is one RCCL all-reduce of the flat 3 MB gradient per step.
-Rank 0 prints ONE JSON line.  After the timed region a second, event-instrumented pass gives
-live per-kernel durations for the `roofline` object; at N=1 the CPU oracle ("port") is timed
-on the host cores for `cpu_baseline`.
+Primary workload (BASELINE.json configs[1], the configuration the metric is quoted on):
+ECGCNN(5), 12x1000 fp32 synthetic windows, batch 256 PER GPU (weak scaling), inputs resident in HBM,
+driven through the reference's own loop API (src.training.loop.train_one_epoch) with the flat AdamW;
+with N > 1 the gradient exchange is one RCCL all-reduce of the flat 2.9 MB gradient per step (two
+buckets issued from backward hooks).  Rank 0 prints ONE JSON line.
+
+Protocol per leg: `--priming` untimed steps (allocator, lazy module loading, clock ramp), W untimed
+warm-up steps, then EXACTLY K steps between barrier + synchronize (max over ranks) -> `value`,
+`ms_per_step`; one HIP event per step boundary on the launch stream -> `step_ms` median / p10 / p90.
+A second, event-instrumented pass (events around every ABI launch) prices every conv entry point of
+every layer against its roof -> `roofline` (the dominant entry point) and `layers`.
+
+`also` carries the other configurations of BASELINE.json, each measured the same way with its own
+roofline: ECGMultimodal (configs[2]/[3]), the headline with the stock torch.optim.AdamW the reference
+scripts construct (scripts/03_train_ecg_baseline.py:130-133), and configs[4] (ECGCNN(1), 12x5000,
+batch 256) in fp32 and with bf16 conv operands.  The CPU baseline (oracle/ref_models.py, stock torch
+CPU ops: "port") runs LAST so that its thread pool cannot disturb a GPU leg.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -24,30 +36,102 @@ for p in (ROOT, os.path.join(ROOT, "ptbxl-multimodal_amd")):
     if p not in sys.path:
         sys.path.insert(0, p)
 
-import torch  # noqa: E402
-
 PEAK_F32_TFLOPS = 157.3      # MI355X_MICROARCH.md: fp32 vector == fp32 MFMA peak
+PEAK_BF16_TFLOPS = 2500.0    # dense bf16 MFMA
 PEAK_HBM_GBS = 8000.0
 CONV_GEOM = [(12, 32), (32, 64), (64, 128), (128, 256)]
+FWD, DGRAD, WGRAD = "fwd", "dgrad", "wgrad"
+CONV_ENTRY = {"ecg_conv1d_fwd": (FWD, "f32"), "ecg_conv1d_fwd_bf16": (FWD, "bf16"),
+              "ecg_conv1d_bwd_data": (DGRAD, "f32"), "ecg_conv1d_bwd_data_ld": (DGRAD, "f32"),
+              "ecg_conv1d_bwd_data_bf16": (DGRAD, "bf16"),
+              "ecg_conv1d_bwd_weight_bias": (WGRAD, "f32"), "ecg_conv1d_bwd_weight_bias_ld": (WGRAD, "f32"),
+              "ecg_conv1d_bwd_weight_bias_bf16": (WGRAD, "bf16")}
 
 
+# ------------------------------------------------------------------------------------------------
+# N > 1 without a launcher: start the ranks ourselves (fresh children, before anything touches the GPU)
+# ------------------------------------------------------------------------------------------------
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def self_launch(n):
+    """`python bench.py --gpus N` with WORLD_SIZE unset: one child process per rank (never an exec of this
+    process), rank 0's JSON line forwarded, exit code = the worst child's."""
+    port = _free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ)
+        env.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or n) // n)))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out0, _ = procs[0].communicate()
+    rcs = [procs[0].returncode]
+    deadline = time.time() + 120
+    for p in procs[1:]:
+        try:
+            rcs.append(p.wait(timeout=max(1.0, deadline - time.time())))
+        except subprocess.TimeoutExpired:
+            p.kill()                               # the exact child we started, by handle
+            rcs.append(p.wait())
+    sys.stdout.write(out0.decode("utf-8", "replace"))
+    sys.stdout.flush()
+    worst = max((abs(rc) for rc in rcs), default=0)
+    if worst:
+        sys.stderr.write(f"bench.py: rank exit codes {rcs}\n")
+    return worst
+
+
+# ------------------------------------------------------------------------------------------------
+# helpers
+# ------------------------------------------------------------------------------------------------
 class ListLoader:
-    """The loop API only needs iteration and len(loader.dataset)."""
+    """The loop API only needs iteration and len(loader.dataset).  Records one HIP event on the current
+    stream at every step boundary (the GPU is the bottleneck, so event intervals are per-step GPU time)."""
 
-    def __init__(self, batch, steps):
-        self.batch, self.steps = batch, steps
+    def __init__(self, batch, steps, record=False):
+        self.batch, self.steps, self.record = batch, steps, record
         self.dataset = range(batch[0].shape[0] * steps)
+        self.events = []
 
     def __iter__(self):
-        return iter([self.batch] * self.steps)
+        import torch
+        for _ in range(self.steps):
+            if self.record:
+                e = torch.cuda.Event(enable_timing=True)
+                e.record()
+                self.events.append(e)
+            yield self.batch
+        if self.record:
+            e = torch.cuda.Event(enable_timing=True)
+            e.record()
+            self.events.append(e)
 
     def __len__(self):
         return self.steps
 
+    def step_ms(self):
+        return [a.elapsed_time(b) for a, b in zip(self.events, self.events[1:])]
+
+
+def percentiles(v):
+    import numpy as np
+    a = np.asarray(v, dtype=np.float64)
+    return {"median": round(float(np.median(a)), 4), "p10": round(float(np.percentile(a, 10)), 4),
+            "p90": round(float(np.percentile(a, 90)), 4), "min": round(float(a.min()), 4),
+            "max": round(float(a.max()), 4), "n": int(a.size)}
+
 
 def conv_flops_per_window(T):
-    """Algorithmic conv flops of one window: fwd, and the train step (fwd + wgrad + dgrad
-    without block 0's dgrad) — SURVEY §8(d)."""
+    """Algorithmic conv flops of one window: fwd, and the train step (fwd + wgrad + dgrad without block 0's
+    dgrad) — SURVEY §8(d)."""
     L, fwd, step = T, 0.0, 0.0
     for i, (ci, co) in enumerate(CONV_GEOM):
         f = 2.0 * co * ci * 15 * L
@@ -57,68 +141,142 @@ def conv_flops_per_window(T):
     return fwd, step
 
 
-SINGLE_LAUNCH = ("ecg_conv1d_fwd", "ecg_conv1d_bwd_data", "ecg_conv1d_bwd_data_ld",   # entry points that are exactly one kernel
-                 "ecg_conv1d_fwd_bf16", "ecg_conv1d_bwd_data_bf16")
+def csrc_digest():
+    """sha256 over the kernel sources: counter traffic collected for other kernels is stale."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "ptbxl-multimodal_amd", "csrc")
+    for f in sorted(glob.glob(os.path.join(d, "*.hip")) + glob.glob(os.path.join(d, "*.h")) + glob.glob(os.path.join(d, "*.cpp"))):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
 
 
-def load_pmc_traffic():
-    """HBM bytes per launch measured with rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes,
-    committed under profiles/); keyed like the kernel names below.  None when not collected."""
-    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    try:
-        return json.load(open(path))
-    except (OSError, ValueError):
-        return {}
+_PMC = None
 
 
-def kernel_roofline(timings, B):
-    """Price the dominant single-kernel entry point of the instrumented pass against its roof.
-    (ecg_conv1d_bwd_weight_bias is two launches — MFMA kernel + slab reduce — so it is listed in
-    the breakdown but not used for the per-kernel roofline.)"""
-    total_ms = 0.0
-    per = {}
+def pmc_traffic(key):
+    """(HBM bytes per launch, provenance) from the committed rocprofv3 --pmc passes (profiles/pmc_traffic.json:
+    2*FETCH_SIZE + WRITE_SIZE per the guide's gfx950 correction), or (None, reason) when the file is missing, has
+    no entry, or was collected for different kernel sources."""
+    global _PMC
+    if _PMC is None:
+        try:
+            _PMC = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+        except (OSError, ValueError):
+            _PMC = {}
+    meta = _PMC.get("_meta", {})
+    if key not in _PMC.get("entries", {}):
+        return None, "not collected"
+    if meta.get("csrc_digest") != csrc_digest():
+        return None, f"stale: collected for csrc {meta.get('csrc_digest')} at {meta.get('commit')}"
+    return _PMC["entries"][key], f"profiles/pmc_traffic.json ({meta.get('source')}, commit {meta.get('commit')})"
+
+
+def layer_table(timings):
+    """Instrumented pass -> one row per (conv entry point, layer): live µs per call (all launches of the entry
+    point, e.g. weight-gradient MFMA kernel + slab reduce), TFLOP/s, fraction of the MFMA peak for its operand
+    type, algorithmic bytes and, when a matching counter collection is committed, HBM traffic / algorithmic."""
+    rows, other_ms, n_steps = [], 0.0, None
     for (name, sig), ms in timings.items():
-        per[(name, sig)] = (sum(ms) / len(ms), len(ms))
-        total_ms += sum(ms)
-    agg = sorted(per.items(), key=lambda kv: -kv[1][0] * kv[1][1])
-    (name, sig), (avg_ms, cnt) = next(kv for kv in agg if kv[0][0] in SINGLE_LAUNCH)
-    key = f"{name}{list(sig)}"
-    N, ci, co, Lc, K, pad = sig[-6:]
-    flops = 2.0 * N * co * ci * K * (Lc + 2 * pad - K + 1)
-    bytes_ = 4.0 * N * Lc * (ci + co) + 4.0 * co * ci * K
-    ach = flops / (avg_ms * 1e-3) / 1e12
-    peak = 2500.0 if name.endswith("_bf16") else PEAK_F32_TFLOPS        # dense bf16 MFMA peak ~2.5 PFLOP/s
-    out = {"kernel": key, "avg_ms": round(avg_ms, 4), "bound": "mfma", "achieved": round(ach, 3),
-           "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
-           "traffic": load_pmc_traffic().get(key),
-           "algorithmic_flops": flops, "algorithmic_bytes": bytes_,
-           "hbm_frac_of_algorithmic_bytes": round(bytes_ / (avg_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 5),
-           "note": "fp32 conv: arithmetic intensity 65-615 flop/B vs ridge 20 -> the fp32 MFMA peak binds, "
-                   "not HBM; peak = 157.3 TFLOP/s (v_mfma_f32_32x32x2_f32 == fp32 vector rate)"}
-    breakdown = [{"kernel": f"{n}{list(s)}", "avg_ms": round(a, 4), "calls": c} for (n, s), (a, c) in agg[:14]]
-    return out, breakdown, total_ms
+        if name not in CONV_ENTRY:
+            other_ms += sum(ms)
+            continue
+        op, dt = CONV_ENTRY[name]
+        N, ci, co, Lc, K, pad = sig[-6:]
+        Lo = Lc + 2 * pad - K + 1
+        flops = 2.0 * N * co * ci * K * Lo
+        abytes = 4.0 * N * (Lc * ci + Lo * co) + 4.0 * co * ci * K
+        avg = sum(ms) / len(ms)
+        peak = PEAK_BF16_TFLOPS if dt == "bf16" else PEAK_F32_TFLOPS
+        ach = flops / (avg * 1e-3) / 1e12
+        key = f"{name}{list(sig)}"
+        tr, prov = pmc_traffic(key)
+        rows.append({"entry": key, "op": op, "operands": dt, "c_in": ci, "c_out": co, "L": Lc, "calls": len(ms),
+                     "avg_us": round(avg * 1e3, 2), "tflops": round(ach, 2), "peak": peak, "frac": round(ach / peak, 4),
+                     "algorithmic_flops": flops, "algorithmic_bytes": abytes,
+                     "traffic_bytes_from_profile": tr, "traffic_over_algorithmic": (round(tr / abytes, 3) if tr else None),
+                     "traffic_source": prov})
+    rows.sort(key=lambda r: (-r["avg_us"] * r["calls"]))
+    return rows, other_ms
 
 
-def cpu_baseline(B, T, seconds, demo, labels):
-    """The oracle (stock-torch CPU restatement of the reference loop body) on the host cores."""
+def roofline_of(rows):
+    """The dominant conv entry point (largest total time; multi-launch entry points included)."""
+    if not rows:
+        return None
+    r = rows[0]
+    return {"kernel": r["entry"], "op": r["op"], "avg_ms": round(r["avg_us"] / 1e3, 4), "bound": "mfma",
+            "achieved": r["tflops"], "peak": r["peak"], "unit": "TFLOP/s", "frac": r["frac"],
+            "traffic": r["traffic_bytes_from_profile"], "traffic_source": r["traffic_source"],
+            "algorithmic_flops": r["algorithmic_flops"], "algorithmic_bytes": r["algorithmic_bytes"],
+            "algorithmic_hbm_bw_frac_of_peak": round(r["algorithmic_bytes"] / (r["avg_us"] * 1e-6) / 1e9 / PEAK_HBM_GBS, 5),
+            "note": ("fp32 conv: arithmetic intensity 65-615 flop/B vs a ridge of 20 -> the fp32 MFMA peak binds, not HBM; "
+                     "peak = 157.3 TFLOP/s (v_mfma_f32_32x32x2_f32 == fp32 vector rate)") if r["operands"] == "f32" else
+                    "bf16 operands, fp32 accumulate: priced against the dense bf16 MFMA peak (2.5 PFLOP/s)"}
+
+
+def host_info():
+    import torch
+    model, cores = "unknown", set()
+    try:
+        phys = core = None
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name") and model == "unknown":
+                model = line.split(":", 1)[1].strip()
+            elif line.startswith("physical id"):
+                phys = line.split(":", 1)[1].strip()
+            elif line.startswith("core id"):
+                core = line.split(":", 1)[1].strip()
+            elif not line.strip():
+                if phys is not None and core is not None:
+                    cores.add((phys, core))
+                phys = core = None
+    except OSError:
+        pass
+    return {"cpu_model": model, "physical_cores": len(cores) or None, "logical_cpus": os.cpu_count(),
+            "torch_threads": torch.get_num_threads(), "torch": torch.__version__}
+
+
+def cpu_baseline(seconds):
+    """The oracle (oracle/ref_models.py: stock-torch CPU restatement of the reference loop body, kind "port") on
+    the host cores.  Primary figure = BASELINE.json configs[0] / BASELINE.md §3: ECGCNN(5), batch 32, 12x1000;
+    median of >= 30 steps.  The same model at batch 256 (the GPU leg's batch) rides along."""
+    import numpy as np
     from oracle import ref_models as R
-    R.seed_all(42)
-    model = (R.RefECGMultimodal(num_labels=labels) if demo else R.RefECGCNN(num_labels=labels)).train()
-    opt = R.make_adamw(model, 1e-4, 1e-4)
-    batch = R.synthetic_batch(B, T, labels, demo=demo)
-    R.train_step(model, opt, batch)                     # warm-up
-    n, t0 = 0, time.perf_counter()
-    while True:
-        R.train_step(model, opt, batch)
-        n += 1
-        dt = time.perf_counter() - t0
-        if dt >= seconds or n >= 200:
-            break
-    return {"value": round(B * n / dt, 1), "unit": "windows/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"oracle/ref_models.py train_step (stock torch CPU ops), {'ECGMultimodal' if demo else f'ECGCNN({labels})'} "
-                      f"B={B} 12x{T}, {n} steps in {dt:.1f}s"}
+    info = host_info()
+
+    def run(B, T, labels, demo, budget, min_steps):
+        R.seed_all(42)
+        model = (R.RefECGMultimodal(num_labels=labels) if demo else R.RefECGCNN(num_labels=labels)).train()
+        opt = R.make_adamw(model, 1e-4, 1e-4)
+        batch = R.synthetic_batch(B, T, labels, demo=demo)
+        for _ in range(2):
+            R.train_step(model, opt, batch)
+        ts, t_all = [], time.perf_counter()
+        while len(ts) < min_steps or (time.perf_counter() - t_all < budget and len(ts) < 400):
+            t0 = time.perf_counter()
+            R.train_step(model, opt, batch)
+            ts.append(time.perf_counter() - t0)
+            if time.perf_counter() - t_all > 3 * budget:
+                break
+        med = float(np.median(ts))
+        return {"windows_per_s": round(B / med, 1), "median_ms": round(med * 1e3, 3), "steps": len(ts),
+                "p10_ms": round(float(np.percentile(ts, 10)) * 1e3, 3), "p90_ms": round(float(np.percentile(ts, 90)) * 1e3, 3)}
+
+    c1 = run(32, 1000, 5, False, 0.45 * seconds, 30)
+    c256 = run(256, 1000, 5, False, 0.45 * seconds, 5)
+    return {"value": c1["windows_per_s"], "unit": "windows/s", "cores": info["torch_threads"], "kind": "port",
+            "sample": f"oracle/ref_models.py train_step (stock torch CPU ops), ECGCNN(5) B=32 12x1000 (BASELINE configs[0]), "
+                      f"median of {c1['steps']} steps ({c1['median_ms']} ms, p10 {c1['p10_ms']}, p90 {c1['p90_ms']})",
+            "batch256": {"value": c256["windows_per_s"], "median_ms": c256["median_ms"], "steps": c256["steps"]},
+            **info}
 
 
+# ------------------------------------------------------------------------------------------------
+# input-pipeline workload (unchanged protocol; one GPU)
+# ------------------------------------------------------------------------------------------------
 def input_pipeline_bench(B0, lengths, iters, cpu_seconds):
     """--workload input: the step before the model, WFDB int16 samples resident in
     HBM -> z-scored fp32 windows.  One JSON line per window length: windows/s of ecg_wfdb16_zscore, its time
@@ -126,6 +284,7 @@ def input_pipeline_bench(B0, lengths, iters, cpu_seconds):
     baseline (oracle/input_oracle.py = the reference's numpy arithmetic) on a bounded sample."""
     import tempfile
     import numpy as np
+    import torch
     from ecg_hip import _lib, functional as F, pack
     _lib.call("ecg_check_device")
     B = B0
@@ -155,11 +314,13 @@ def input_pipeline_bench(B0, lengths, iters, cpu_seconds):
         # algorithmic HBM bytes: 2 B/sample in (int16) + 4 B/sample out (fp32), whatever the launch plan
         alg = 6.0 * samples
         t = per["ecg_wfdb16_zscore"]
-        out["roofline"] = {"kernel": "ecg_wfdb16_zscore", "bound": "hbm", "achieved": round(alg / (t * 1e-3) / 1e9, 1),
+        out["roofline"] = {"kernel": "ecg_wfdb16_zscore", "bound": "latency (sequential fp32 chain)",
+                           "achieved": round(alg / (t * 1e-3) / 1e9, 1),
                            "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(alg / (t * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
                            "algorithmic_bytes": alg, "traffic": None,
-                           "note": "bound by the left-to-right float32 chains (one lane per (window, lead) row) that "
-                                   "make the result bit-identical to the reference's numpy arithmetic, not by HBM"}
+                           "note": "priced against the HBM roof for its 6 B/sample, but bound by the left-to-right float32 "
+                                   "chains (one lane per (window, lead) row) that make the result bit-identical to the "
+                                   "reference's numpy arithmetic"}
         # packed loader, PCIe inclusive
         with tempfile.TemporaryDirectory() as tmp:
             path = os.path.join(tmp, "b.ecgpack")
@@ -189,6 +350,9 @@ def input_pipeline_bench(B0, lengths, iters, cpu_seconds):
         print(json.dumps(out))
 
 
+# ------------------------------------------------------------------------------------------------
+# train workload
+# ------------------------------------------------------------------------------------------------
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--workload", choices=["train", "input"], default="train",
@@ -196,32 +360,44 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--priming", type=int, default=30,
+                    help="untimed steps BEFORE the warm-up of every leg (allocator, lazy code-object loading, clock "
+                         "ramp after idle); makes short --steps/--warmup runs reproduce long ones")
     ap.add_argument("--batch", type=int, default=256, help="windows per GPU")
     ap.add_argument("--length", type=int, default=1000)
     ap.add_argument("--model", choices=["multimodal", "cnn"], default="cnn",
                     help="cnn = ECGCNN (BASELINE.json configs[1], the configuration the metric is quoted on); "
-                         "multimodal = ECGMultimodal with the FiLM fusion (configs[2]/[3]); the other one is timed too "
-                         "and reported under 'also'")
-    ap.add_argument("--no-also", action="store_true", help="skip the secondary measurement of the other model")
+                         "multimodal = ECGMultimodal with the FiLM fusion (configs[2]/[3])")
+    ap.add_argument("--optim", choices=["flat", "torch"], default="flat",
+                    help="flat = ecg_hip.optim.FlatAdamW (one launch); torch = the stock torch.optim.AdamW the reference "
+                         "scripts construct")
+    ap.add_argument("--no-also", action="store_true", help="skip the secondary legs")
     ap.add_argument("--labels", type=int, default=5, help="output labels (1 = the AF-binary shape of BASELINE config 5)")
     ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32",
                     help="f32 (default, the parity path) or bf16 = opt-in mixed precision of BASELINE config 5: "
                          "bf16 conv operands in forward/input-grad/weight-grad, fp32 accumulate, fp32 everything else")
     ap.add_argument("--graph", action="store_true",
-                    help="replay the whole step as one captured hipGraph (ecg_hip.graph.GraphedTrainStep); "
-                         "single GPU only; pays off when the step is host-bound (small batches)")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+                    help="replay the whole step as one captured hipGraph (ecg_hip.graph.GraphedTrainStep); single GPU only")
+    ap.add_argument("--cpu-seconds", type=float, default=14.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--n1-value", type=float, default=None,
+                    help="windows/s of the N=1 run: adds efficiency_vs_n1 = value / (N * n1-value) to an N>1 line")
     args = ap.parse_args()
+
+    # ---- before ANY GPU call: a bare `--gpus N` starts its own ranks --------------------------------------
+    if args.workload == "train" and args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args.gpus))
+
+    import numpy as np
+    import torch
+
     if args.workload == "input":
-        sys.path[:0] = [ROOT, os.path.join(ROOT, "ptbxl-multimodal_amd")]
         lengths = [args.length] if "--length" in sys.argv else [1000, 5000]
         return input_pipeline_bench(args.batch, lengths, args.steps, min(args.cpu_seconds, 10.0))
 
     from ecg_hip import _lib, ddp
     from ecg_hip import functional as hipF
     from ecg_hip.optim import FlatAdamW
-    hipF.set_conv_precision("bf16" if args.dtype == "bf16" else "fp32")
     from src.models.ecg_cnn import ECGCNN
     from src.models.ecg_multimodal import ECGMultimodal
     from src.training.loop import train_one_epoch
@@ -230,38 +406,46 @@ def main():
 
     rank, world, local = ddp.init_distributed("nccl")
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    rehearsal = os.environ.get("ECG_HIP_REHEARSE_ON_ONE_GPU") == "1"
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     _lib.load()
     _lib.call("ecg_check_device")
-
-    B, T = args.batch, args.length
+    dist = torch.distributed
+    backend = dist.get_backend() if world > 1 else None
 
     def barrier():
         torch.cuda.synchronize()
         if world > 1:
-            torch.distributed.barrier()
+            dist.barrier(device_ids=[local]) if backend == "nccl" else dist.barrier()
         torch.cuda.synchronize()
 
-    def build(demo):
+    def run_leg(spec):
+        """One configuration, measured by the protocol in the module docstring.  Every rank takes part."""
+        B, T, labels, demo = spec["batch"], spec["length"], spec["labels"], spec["model"] == "multimodal"
+        bf16, graph, stock = spec["dtype"] == "bf16", spec.get("graph", False), spec.get("optim", "flat") == "torch"
+        hipF.set_conv_precision("bf16" if bf16 else "fp32")
         set_seed(42)
-        model = (ECGMultimodal(num_labels=args.labels) if demo else ECGCNN(num_labels=args.labels)).to(dev)
+        model = (ECGMultimodal(num_labels=labels) if demo else ECGCNN(num_labels=labels)).to(dev)
         if world > 1:
             ddp.broadcast_module_state(model, 0)
-        opt = FlatAdamW(model.parameters(), lr=1e-4, weight_decay=1e-4)
+        wrapped = model
+        if stock:
+            if world > 1:
+                wrapped = ddp.FlatGradDDP(model)
+            opt = torch.optim.AdamW(model.parameters(), lr=1e-4, weight_decay=1e-4)
+        else:
+            opt = FlatAdamW(model.parameters(), lr=1e-4, weight_decay=1e-4)
         g = torch.Generator().manual_seed(1234 + rank)            # each rank its own shard of the global batch
         x = torch.randn(B, 12, T, generator=g).to(dev)
-        y = (torch.rand(B, args.labels, generator=g) < 0.3).float().to(dev)
+        y = (torch.rand(B, labels, generator=g) < 0.3).float().to(dev)
         batch = (x, torch.rand(B, 5, generator=g).to(dev), y) if demo else (x, y)
-        return model, opt, batch
-
-    def timed(demo, model, opt, batch, steps, warmup):
-        """W untimed steps, then exactly K steps between barrier+synchronize; max over ranks."""
-        run = train_one_epoch_demo if demo else train_one_epoch
-        if args.graph:
-            if world > 1:
-                raise SystemExit("--graph is single-GPU only")
+        run_eager = train_one_epoch_demo if demo else train_one_epoch
+        run = run_eager
+        if graph:
+            if world > 1 or stock:
+                raise SystemExit("--graph is single-GPU, FlatAdamW only")
             from ecg_hip.graph import GraphedTrainStep
             gstep = GraphedTrainStep(model, opt, batch)
 
@@ -270,69 +454,142 @@ def main():
                     gstep(*b)
                 return gstep.mean_loss_and_reset(len(loader))
 
-        run(model, ListLoader(batch, warmup), opt, dev)
+        if spec["priming"] > 0:
+            run(wrapped, ListLoader(batch, spec["priming"]), opt, dev)
+        run(wrapped, ListLoader(batch, spec["warmup"]), opt, dev)
+        loader = ListLoader(batch, spec["steps"], record=True)
         barrier()
         t0 = time.perf_counter()
-        last_loss = run(model, ListLoader(batch, steps), opt, dev)
+        last_loss = run(wrapped, loader, opt, dev)
         barrier()
         elapsed = time.perf_counter() - t0
         if world > 1:
             t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = t.item()
-        return elapsed, last_loss
+        step_ms = percentiles(loader.step_ms())
 
-    def workload_name(demo):
-        return (f"{'ECGMultimodal (FiLM)' if demo else f'ECGCNN({args.labels})'} train step fwd+BCE+bwd+AdamW, "
-                f"12x{T} fp32, batch {B}/GPU, global batch {B * world}")
+        # instrumented pass (HIP events around every ABI launch on the launch stream); always eager
+        n_instr = 5
+        exch = []
+        if world > 1 and not stock:           # exposed exchange time: how long the compute stream waits in reduce_gradients
+            inner = opt.reduce_gradients
 
-    demo = args.model == "multimodal"
-    model, opt, batch = build(demo)
-    elapsed, last_loss = timed(demo, model, opt, batch, args.steps, args.warmup)
+            def timed_reduce():
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record()
+                out = inner()
+                b.record()
+                exch.append((a, b))
+                return out
+            opt.reduce_gradients = timed_reduce
+        with _lib.kernel_timing() as kt:
+            run_eager(wrapped, ListLoader(batch, n_instr), opt, dev)
+        if exch:
+            opt.reduce_gradients = inner
+        rows, other_ms = layer_table(kt.result)
+        conv_ms = sum(r["avg_us"] * r["calls"] for r in rows) / 1e3
 
-    # instrumented pass (HIP events around every ABI launch on the launch stream); always eager
-    run_eager = train_one_epoch_demo if demo else train_one_epoch
-    with _lib.kernel_timing() as kt:
-        run_eager(model, ListLoader(batch, min(args.steps, 10)), opt, dev)
-    roof, breakdown, instr_ms = kernel_roofline(kt.result, B)
-
-    if rank == 0:
-        value = world * B * args.steps / elapsed
+        value = world * B * spec["steps"] / elapsed
         fwd_f, step_f = conv_flops_per_window(T)
-        line = {
-            "metric": f"ECG windows/s (train step) at 12x{T}, batch {B}", "value": round(value, 1), "unit": "windows/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None,
-            "dtype": "f32" if args.dtype == "f32" else "bf16 conv operands (fwd, input-grad, weight-grad) / f32 accumulate, activations, BN, tail, optimizer",
-            "data": "synthetic",
-            "config": {"workload": workload_name(demo),
-                       "global_batch": B * world, "parallelism": f"dp{world}",
-                       "loop": "hipGraph replay of the whole step (GraphedTrainStep)" if args.graph else "src.training API + FlatAdamW",
-                       "final_loss": round(float(last_loss), 6)},
+        peak = PEAK_BF16_TFLOPS if bf16 else PEAK_F32_TFLOPS
+        res = {
+            "workload": (f"{'ECGMultimodal (FiLM)' if demo else f'ECGCNN({labels})'} train step fwd+BCE+bwd+AdamW, 12x{T}, "
+                         f"{'bf16 conv operands' if bf16 else 'fp32'}, batch {B}/GPU, global batch {B * world}"),
+            "value": round(value, 1), "unit": "windows/s", "ms_per_step": round(1e3 * elapsed / spec["steps"], 4),
+            "step_ms": step_ms, "value_at_median_step": round(world * B / (step_ms["median"] * 1e-3), 1),
+            "dtype": "f32" if not bf16 else "bf16 conv operands (fwd, input-grad, weight-grad) / f32 accumulate, activations, BN, tail, optimizer",
+            "optimizer": "torch.optim.AdamW (stock, foreach)" if stock else "ecg_hip.optim.FlatAdamW (one launch)",
+            "loop": "hipGraph replay of the whole step (GraphedTrainStep)" if graph else "src.training loop API, eager",
+            "final_loss": round(float(last_loss), 6),
             "step_conv_tflops": round(value * step_f / 1e12, 2),
-            "step_frac_of_fp32_peak": round(value * step_f / 1e12 / (PEAK_F32_TFLOPS * world), 4),
-            "roofline": roof, "kernel_breakdown": breakdown,
-            "instrumented_ms_per_step": round(instr_ms / min(args.steps, 10), 4),
+            "step_frac_of_mfma_peak": round(value * step_f / 1e12 / (peak * world), 4),
+            "roofline": roofline_of(rows), "layers": rows,
+            "instrumented_ms_per_step": {"conv_entry_points": round(conv_ms / n_instr, 4),
+                                         "everything_else": round(other_ms / n_instr, 4)},
         }
-        if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(B, T, args.cpu_seconds, demo, args.labels)
+        if exch:
+            torch.cuda.synchronize()
+            res["exchange_exposed_ms_per_step"] = percentiles([a.elapsed_time(b) for a, b in exch])
+        extra = None
+        if world > 1 and not stock:
+            # RCCL sanity on real gradients: exchange once by hand and compare checksums
+            opt.zero_grad()
+            with opt.no_sync():
+                out = wrapped(*batch[:-1])
+                hipF.backward_from_loss(hipF.binary_cross_entropy_with_logits(out, batch[-1]))
+            opt._gather(0, len(opt._params))
+            local_sum = opt.flat_grad.double().sum()
+            total = local_sum.clone()
+            dist.all_reduce(total)
+            flat, _scale = opt.reduce_gradients()
+            after = flat.double().sum().item()
+            opt.zero_grad()
+            extra = {"grad_checksum_sum_of_ranks": total.item(), "grad_checksum_after_allreduce": after,
+                     "rel_diff": abs(after - total.item()) / max(abs(total.item()), 1e-30),
+                     "flat_gradient_bytes": int(opt.flat_grad.numel() * 4)}
+        del model, opt, wrapped, batch, x, y
+        torch.cuda.empty_cache()
+        return res, extra
 
-    # secondary line item: the other model of the path on the same shape (all ranks take part)
-    also = None
-    if not args.no_also and not args.graph:
-        del model, opt, batch
-        m2, o2, b2 = build(not demo)
-        e2, _ = timed(not demo, m2, o2, b2, args.steps, min(args.warmup, 5))
-        also = {"workload": workload_name(not demo), "value": round(world * B * args.steps / e2, 1),
-                "unit": "windows/s", "ms_per_step": round(1e3 * e2 / args.steps, 4)}
+    base = {"batch": args.batch, "length": args.length, "labels": args.labels, "model": args.model,
+            "dtype": args.dtype, "optim": args.optim, "graph": args.graph,
+            "steps": args.steps, "warmup": args.warmup, "priming": args.priming}
+    primary, rccl_extra = run_leg(base)
+
+    also = []
+    if not args.no_also:
+        legs = []
+        if args.model == "cnn":
+            legs.append(dict(base, model="multimodal", graph=False))
+        else:
+            legs.append(dict(base, model="cnn", graph=False))
+        if world == 1 and args.dtype == "f32" and args.length == 1000 and not args.graph:
+            if args.optim == "flat":
+                legs.append(dict(base, optim="torch"))
+            # BASELINE.json configs[4]: ECGCNN(1), 12x5000, batch 256 — fp32 and with bf16 conv operands
+            k5 = max(10, args.steps // 2)
+            legs.append(dict(base, model="cnn", labels=1, length=5000, optim="flat", steps=k5, priming=10))
+            legs.append(dict(base, model="cnn", labels=1, length=5000, optim="flat", dtype="bf16", steps=k5, priming=10))
+        for spec in legs:
+            res, _ = run_leg(spec)
+            also.append(res)
+
+    line = None
+    if rank == 0:
+        T, B = args.length, args.batch
+        line = {
+            "metric": f"ECG windows/s (train step) at 12x{T}, batch {B}", "value": primary["value"], "unit": "windows/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": primary["ms_per_step"], "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": primary["dtype"], "data": "synthetic",
+            "config": {"workload": primary["workload"], "global_batch": B * world, "parallelism": f"dp{world}",
+                       "loop": primary["loop"], "optimizer": primary["optimizer"], "priming_steps": args.priming,
+                       "final_loss": primary["final_loss"]},
+            "step_ms": primary["step_ms"], "value_at_median_step": primary["value_at_median_step"],
+            "step_conv_tflops": primary["step_conv_tflops"], "step_frac_of_mfma_peak": primary["step_frac_of_mfma_peak"],
+            "roofline": primary["roofline"], "layers": primary["layers"],
+            "instrumented_ms_per_step": primary["instrumented_ms_per_step"],
+        }
+    if world > 1:
+        ones = torch.ones(1, device=dev)
+        dist.all_reduce(ones)
+        if rank == 0:
+            line["rccl"] = {"backend": backend + (" (one-GPU rehearsal: every rank on device 0)" if rehearsal else ""),
+                            "ranks_seen_by_allreduce": int(ones.item()), **(rccl_extra or {})}
+            if "exchange_exposed_ms_per_step" in primary:
+                line["rccl"]["exchange_exposed_ms_per_step"] = primary["exchange_exposed_ms_per_step"]
+            if args.n1_value:
+                line["efficiency_vs_n1"] = round(primary["value"] / (world * args.n1_value), 4)
     if rank == 0:
         if also:
             line["also"] = also
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(args.cpu_seconds)       # LAST: its thread pool must not disturb a GPU leg
         print(json.dumps(line), flush=True)
     if world > 1:
-        torch.distributed.barrier()
-        torch.distributed.destroy_process_group()
+        barrier()
+        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -1,8 +1,9 @@
 """ctypes binding of libecg_hip.so (include/ecg_hip.h).
 
-The product path has no CPU fallback: if the shared library is missing, or a tensor is not
-a contiguous float32 CUDA tensor, the call raises.  Every wrapper launches on torch's
-current HIP stream and never synchronises.
+There is no CPU fallback at this level: if the shared library is missing, or a tensor handed to a
+kernel wrapper is not a contiguous float32 CUDA tensor, the call raises.  (CPU tensors are routed to
+stock torch one level up, in ecg_hip/nn.py and the model classes — never to oracle/.)  Every wrapper
+launches on torch's current HIP stream and never synchronises.
 """
 import ctypes
 import functools
@@ -99,7 +100,7 @@ def load():
             if not os.path.exists(LIB_PATH):
                 raise EcgHipError(
                     f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
-                    "(or `make -C ptbxl-multimodal_amd/csrc`). There is no CPU fallback.")
+                    "(or `make -C ptbxl-multimodal_amd/csrc`). CUDA tensors have no fallback path.")
             lib = ctypes.CDLL(LIB_PATH)
             for name, (res, args) in SIGNATURES.items():
                 fn = getattr(lib, name)          # AttributeError if the .so lacks a declared symbol
@@ -131,8 +132,8 @@ def ptr(t):
     if t.is_cuda and t.is_contiguous():
         return t.data_ptr()
     if not t.is_cuda:
-        raise EcgHipError("ecg_hip kernels need CUDA(HIP) tensors; got a CPU tensor "
-                          "(move the model and inputs to 'cuda' — there is no CPU fallback)")
+        raise EcgHipError("a CPU tensor reached a HIP kernel wrapper: ecg_hip.functional's Functions take CUDA(HIP) "
+                          "tensors only (the nn modules route CPU inputs to stock torch before getting here)")
     raise EcgHipError("ecg_hip kernels need contiguous tensors")
 
 

@@ -38,13 +38,29 @@ def unregister_grad_sinks(keys):
         _grad_sinks.pop(k, None)
 
 
+_sinks_handed = set()     # sinks already given to a kernel in the backward pass that is running now
+
+
+def _forget_handed_sinks():
+    _sinks_handed.clear()
+
+
 def _grad_out(key, ref, *shape):
     """Destination of a parameter gradient: a FRESH view of the registered sink (AccumulateGrad only adopts
-    a tensor nobody else holds) or a new tensor."""
+    a tensor nobody else holds) or a new tensor.  A sink is handed out AT MOST ONCE per backward pass: a
+    parameter used twice in one graph (model called twice before backward(), shared weights) gets a private
+    tensor for its second gradient, which autograd then adds to the first — two kernels writing the same
+    sink would leave 2*dw2 instead of dw1 + dw2.  The set is cleared by an engine callback when the pass ends."""
     ent = _grad_sinks.get(key) if key is not None else None
-    if ent is not None:
+    if ent is not None and key not in _sinks_handed:
         p, v = ent[0](), ent[1]
         if p is not None and p.grad is None and v.device == ref.device and v.numel() == _numel(shape):
+            try:
+                if not _sinks_handed:
+                    torch.autograd.Variable._execution_engine.queue_callback(_forget_handed_sinks)
+                _sinks_handed.add(key)
+            except RuntimeError:         # not inside a backward pass (direct call of a backward formula): no tracking
+                return torch.empty(shape, dtype=torch.float32, device=ref.device)
             return v.view(shape)
     return torch.empty(shape, dtype=torch.float32, device=ref.device)
 
@@ -683,14 +699,30 @@ def tail(g, x_demo, proj, head, mlp0=None, mlp2=None, film_gen=None, transposed=
                         mlp2.bias, film_gen.weight, film_gen.bias, head.weight, head.bias, WpT, WfT)
 
 
+def film(z, film_raw):
+    """(1 + tanh(gamma)) * z + beta with [gamma | beta] = film_raw (reference src/models/ecg_multimodal.py:92-96)."""
+    if not z.is_cuda:
+        gamma, beta = film_raw.chunk(2, dim=-1)
+        return (1.0 + torch.tanh(gamma)) * z + beta
+    return FilmFn.apply(z, film_raw)
+
+
 def binary_cross_entropy_with_logits(logits, target, running=None, weight=1.0):
     """Drop-in for F.binary_cross_entropy_with_logits(logits, y) (mean reduction only).
     `running` (optional float64 scalar on the device) receives `+= loss * weight` inside the same
-    launch: the loops' epoch-loss bookkeeping without a host sync or extra kernels."""
+    launch: the loops' epoch-loss bookkeeping without a host sync or extra kernels.
+    CPU tensors take stock torch (the reference's own call, src/training/loop.py:32)."""
+    if not logits.is_cuda:
+        loss = torch.nn.functional.binary_cross_entropy_with_logits(logits, target)
+        if running is not None:
+            running += loss.detach().double() * weight
+        return loss
     return BceWithLogitsFn.apply(logits, target, running, weight)
 
 
 def sigmoid(x):
+    if not x.is_cuda:
+        return torch.sigmoid(x.detach())
     x = _contig(x.detach())
     out = torch.empty_like(x)
     _call("ecg_sigmoid_fwd", _f32(x), _f32(out), x.numel(), _st())

@@ -29,13 +29,22 @@ class GraphedTrainStep:
         self.running = torch.zeros((), dtype=torch.float64, device=self.static[0].device)
         self.loss = None
         model.train()
+        # the warm-up iterations below are REAL optimizer steps on the example batch: snapshot everything they
+        # advance (parameters, AdamW moments, step counter, BatchNorm running statistics and counters) and put
+        # it back before capture, so that building the graphed step on a loaded checkpoint leaves it untouched
+        opt = self.optimizer
+        snap = [(t, t.detach().clone()) for t in (opt.flat_param, opt.flat_m, opt.flat_v, opt._step_dev)]
+        snap += [(b, b.detach().clone()) for b in model.buffers()]
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):                 # warm-up outside capture (allocator, pack caches)
             for _ in range(warmup):
                 self._step_body()
+            with torch.no_grad():
+                for t, saved in snap:
+                    t.copy_(saved)
+            self.running.zero_()
         torch.cuda.current_stream().wait_stream(side)
-        self.running.zero_()
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
             self._step_body()
@@ -45,7 +54,7 @@ class GraphedTrainStep:
         out = self.model(*self.static[:-1])
         logits = out[0] if isinstance(out, tuple) else out
         self.loss = hipF.binary_cross_entropy_with_logits(logits, self.static[-1], self.running, 1.0)
-        self.loss.backward()
+        hipF.backward_from_loss(self.loss)
         self.optimizer.step()
 
     def __call__(self, *batch):

@@ -5,7 +5,13 @@ Every class subclasses the stock torch.nn layer the reference constructs, so
     the reference load with strict=True; `set_seed(42)` gives the same initial weights),
   * `isinstance(m, torch.nn.Conv1d)` discovery and module hooks used by the Grad-CAM scripts
     keep working (reference scripts/00_demo_inference.py:64-71, 36-37),
-but `forward` dispatches to the HIP kernels.  CPU tensors raise (no fallback).
+but `forward` dispatches to the HIP kernels whenever the input lives on a HIP device.
+
+CPU tensors take the stock torch layer each class inherits from (`super().forward`): every
+reference script selects `"cuda" if torch.cuda.is_available() else "cpu"`
+(scripts/03_train_ecg_baseline.py:120), so on a GPU-less box the drop-in modules behave exactly
+like the reference's.  That is stock ATen, not `oracle/`; a CUDA tensor with a missing
+libecg_hip.so still fails loudly (ecg_hip/_lib.py).
 """
 import torch
 import torch.nn as nn
@@ -23,12 +29,16 @@ def _check_conv(m):
 
 class HipConv1d(nn.Conv1d):
     def forward(self, x):
+        if not x.is_cuda:
+            return super().forward(x)
         _check_conv(self)
         return F_.Conv1dFn.apply(x, self.weight, self.bias, self.padding[0])
 
 
 class HipBatchNorm1d(nn.BatchNorm1d):
     def forward(self, x):
+        if not x.is_cuda:
+            return super().forward(x)
         if not self.affine:
             raise EcgHipError("HipBatchNorm1d requires affine=True")
         if x.dim() != 3:
@@ -41,11 +51,15 @@ class HipReLU(nn.ReLU):
     """ReLU(inplace=True) in the reference; the HIP leaf writes a new tensor (same values)."""
 
     def forward(self, x):
+        if not x.is_cuda:
+            return super().forward(x)
         return F_.ReLUFn.apply(x)
 
 
 class HipMaxPool1d(nn.MaxPool1d):
     def forward(self, x):
+        if not x.is_cuda:
+            return super().forward(x)
         k = self.kernel_size if isinstance(self.kernel_size, int) else self.kernel_size[0]
         s = self.stride if isinstance(self.stride, int) else self.stride[0]
         if k != 2 or s != 2 or self.padding not in (0, (0,)) or self.dilation not in (1, (1,)) \
@@ -56,6 +70,8 @@ class HipMaxPool1d(nn.MaxPool1d):
 
 class HipAdaptiveAvgPool1d(nn.AdaptiveAvgPool1d):
     def forward(self, x):
+        if not x.is_cuda:
+            return super().forward(x)
         if self.output_size not in (1, (1,)):
             raise EcgHipError("HipAdaptiveAvgPool1d supports output_size=1 only (src/models/ecg_cnn.py:46)")
         return F_.GapFn.apply(x)
@@ -67,6 +83,9 @@ class HipLinear(nn.Linear):
     fuse_relu = False
 
     def forward(self, x):
+        if not x.is_cuda:
+            y = super().forward(x)
+            return torch.relu(y) if self.fuse_relu else y
         return F_.LinearFn.apply(x, self.weight, self.bias, self.fuse_relu)
 
 

@@ -85,6 +85,7 @@ class FlatAdamW(torch.optim.Optimizer):
         self._early_pending = 0
         self._early_work = None
         self._overlap = bool(overlap) and world_size > 1 and 0 < self._n_early < len(self._params)
+        self._sync = True                 # False inside no_sync(): gradients accumulate locally, nothing is exchanged
         if self._overlap:
             self._late_total = len(self._params) - self._n_early
             for p in self._params[self._n_early:]:
@@ -127,9 +128,36 @@ class FlatAdamW(torch.optim.Optimizer):
             else:
                 dst.copy_(p.grad.reshape(-1))
 
+    def no_sync(self):
+        """Context manager for gradient accumulation over several backward passes per step (as
+        DistributedDataParallel.no_sync): inside it the hooked exchange is off and gradients only accumulate
+        locally; the first backward outside it (or step() itself) exchanges the accumulated gradient once."""
+        opt = self
+
+        class _NoSync:
+            def __enter__(self):
+                self.prev, opt._sync = opt._sync, False
+
+            def __exit__(self, *exc):
+                opt._sync = self.prev
+                return False
+
+        return _NoSync()
+
+    def _refuse_second_exchange(self):
+        raise RuntimeError(
+            "FlatAdamW: a second backward pass completed a gradient bucket whose all-reduce from the previous pass "
+            "has not been consumed by step(): the bucket already holds the sum over ranks, so adding local "
+            "gradients to it and reducing again would give world*g1 + g2.  Wrap all but the last backward of a "
+            "step in `optimizer.no_sync()` (gradient accumulation), or call step() between the passes.")
+
     def _on_late_grad(self, _param):
         """Autograd hook: when the last gradient of the late bucket lands, gather that bucket into
         the flat gradient and start its all-reduce; backward of the early blocks keeps running."""
+        if not self._sync:
+            return
+        if self._late_work is not None:
+            self._refuse_second_exchange()
         self._late_pending += 1
         if self._late_pending < self._late_total:
             return
@@ -140,6 +168,10 @@ class FlatAdamW(torch.optim.Optimizer):
             self._late_work = torch.distributed.all_reduce(late, group=self.process_group, async_op=True)
 
     def _on_early_grad(self, _param):
+        if not self._sync:
+            return
+        if self._early_work is not None:
+            self._refuse_second_exchange()
         self._early_pending += 1
         if self._early_pending < self._n_early:
             return
@@ -203,8 +235,23 @@ class FlatAdamW(torch.optim.Optimizer):
                    L.f32(self.flat_v), g.numel(), self._step, float(grp["lr"]), float(b1), float(b2),
                    float(grp["eps"]), float(grp["weight_decay"]), scale, L.stream())
         else:
-            raise L.EcgHipError("FlatAdamW: parameters must live on the GPU (no CPU fallback)")
+            self._step_cpu(g, grp, scale)
         return loss
+
+    def _step_cpu(self, g, grp, scale):
+        """CPU parameters (a GPU-less box): the same update with stock torch ops on the flat buffers —
+        torch.optim.AdamW's single-tensor formula (decoupled decay, bias-corrected moments)."""
+        b1, b2 = grp["betas"]
+        lr, eps, wd, t = float(grp["lr"]), float(grp["eps"]), float(grp["weight_decay"]), self._step
+        if scale != 1.0:
+            g = g * scale
+        p, m, v = self.flat_param, self.flat_m, self.flat_v
+        p.mul_(1.0 - lr * wd)
+        m.lerp_(g, 1.0 - b1)
+        v.mul_(b2).addcmul_(g, g, value=1.0 - b2)
+        bc1, bc2 = 1.0 - b1 ** t, 1.0 - b2 ** t
+        denom = (v.sqrt() / (bc2 ** 0.5)).add_(eps)
+        p.addcdiv_(m, denom, value=-lr / bc1)
 
     def make_capturable(self):
         """Move the step counter to the device so `step()` can be captured in a HIP graph."""

@@ -191,6 +191,25 @@ def epoch_indices(n, shuffle, seed, epoch, rank=0, world_size=1, drop_last=False
     return order
 
 
+class _IteratedWindows:
+    """`loader.dataset` of a PackedBatchLoader: what `len(loader.dataset)` must be for the loops' epoch-loss
+    normalisation (src/training/loop.py:38,73 divide by it) — the number of windows THIS rank iterates in the
+    current epoch (after sharding, wrap-padding and drop_last), re-evaluated on every len()."""
+
+    def __init__(self, loader):
+        self._loader = loader
+
+    def __len__(self):
+        return len(self._loader.indices())
+
+    def __getitem__(self, i):
+        ld = self._loader
+        rec = int(ld.indices()[i])
+        p = ld.pack
+        out = (p.samples[rec], p.labels[rec])
+        return out if not ld.with_demo else (p.samples[rec], p.demo[rec], p.labels[rec])
+
+
 class PackedBatchLoader:
     """Iterable of device batches, shaped like the reference's DataLoader output so that
     `train_one_epoch(model, loader, optimizer, device)` (src/training/loop.py:14) and
@@ -212,11 +231,12 @@ class PackedBatchLoader:
         self.device = torch.device(device)
         self.epoch = 0
         if self.device.type != "cuda" or not torch.cuda.is_available():
-            raise L.EcgHipError("PackedBatchLoader prepares batches on the GPU (there is no CPU fallback); "
+            raise L.EcgHipError("PackedBatchLoader prepares batches on the GPU; "
                                 "pass device='cuda' on a machine with an MI355X")
         L.load()
         self._stream = torch.cuda.Stream(device=self.device)
         self._slots = None
+        self.dataset = _IteratedWindows(self)      # train_one_epoch / eval_one_epoch end with len(loader.dataset)
 
     def set_epoch(self, epoch):
         self.epoch = int(epoch)

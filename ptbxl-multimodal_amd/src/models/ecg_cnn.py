@@ -34,7 +34,8 @@ class ConvBlock(nn.Module):
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         conv, bn, relu, pool = self.net[0], self.net[1], self.net[2], self.net[3]
-        if self._fusable and not hipnn.has_hooks(self.net, conv, bn, relu, pool):
+        # CPU tensors: the stock torch layers the leaves inherit from (no GPU on this box)
+        if x.is_cuda and self._fusable and not hipnn.has_hooks(self.net, conv, bn, relu, pool):
             return hipF.conv_block(x, conv, bn)
         return self.net(x)
 
@@ -73,7 +74,7 @@ def backbone_features(backbone: nn.Sequential, gap: nn.Module, x: torch.Tensor) 
     last pooled activation is never written to HBM."""
     blocks = list(backbone)
     last = blocks[-1]
-    if (isinstance(last, ConvBlock) and last._fusable and x.dim() == 3
+    if (x.is_cuda and isinstance(last, ConvBlock) and last._fusable and x.dim() == 3
             and not hipnn.has_hooks(backbone, gap, *blocks, last.net, *last.net)):
         for blk in blocks[:-1]:
             x = blk(x)
@@ -97,11 +98,11 @@ class ECGCNN(nn.Module):
 
     def forward(self, x: torch.Tensor, return_features: bool = False):
         """x: [B, in_leads, T] -> logits [B, num_labels] (or (logits, z) if return_features)."""
-        if x.dim() == 3 and fully_fusable(self.backbone, self.gap, self.proj, self.head):
+        if x.is_cuda and x.dim() == 3 and fully_fusable(self.backbone, self.gap, self.proj, self.head):
             logits, z = fused_forward(self._packer, self.backbone, self.gap, x, None, self.proj, self.head)
             return (logits, z) if return_features else logits
         pooled = backbone_features(self.backbone, self.gap, x)
-        if not hipnn.has_hooks(self.proj, self.head):
+        if pooled.is_cuda and not hipnn.has_hooks(self.proj, self.head):
             logits, z = hipF.tail(pooled, None, self.proj, self.head)       # one fused launch
         else:
             z = self.proj(pooled)

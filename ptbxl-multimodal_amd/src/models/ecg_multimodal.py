@@ -60,17 +60,17 @@ class ECGMultimodal(nn.Module):
 
     def forward(self, x_ecg: torch.Tensor, x_demo: torch.Tensor) -> torch.Tensor:
         enc, bb = self.demo_encoder, self.ecg_backbone
-        if x_ecg.dim() == 3 and fully_fusable(bb.backbone, bb.gap, bb, bb.proj, enc, enc.mlp, *enc.mlp,
+        if x_ecg.is_cuda and x_ecg.dim() == 3 and fully_fusable(bb.backbone, bb.gap, bb, bb.proj, enc, enc.mlp, *enc.mlp,
                                               self.film_gen, self.head):
             # 4 fused blocks + fused tail, one weight-repack launch for the whole model
             logits, _ = fused_forward(self._packer, bb.backbone, bb.gap, x_ecg, x_demo, bb.proj, self.head,
                                       enc.mlp[0], enc.mlp[2], self.film_gen)
             return logits
-        if not hipnn.has_hooks(bb, bb.proj, enc, enc.mlp, *enc.mlp, self.film_gen, self.head):
+        if x_ecg.is_cuda and not hipnn.has_hooks(bb, bb.proj, enc, enc.mlp, *enc.mlp, self.film_gen, self.head):
             # proj + demographic MLP + film_gen + FiLM + head: one fused launch
             logits, _ = hipF.tail(bb.features(x_ecg), x_demo, bb.proj, self.head, enc.mlp[0], enc.mlp[2],
                                   self.film_gen)
             return logits
         z = bb(x_ecg)
         film = self.film_gen(enc(x_demo))      # [B, 2F]: gamma-raw | beta
-        return self.head(hipF.FilmFn.apply(z, film))
+        return self.head(hipF.film(z, film))

@@ -53,15 +53,17 @@ def test_size_helpers_are_pure(lib):
     assert lib.ecg_bn_stat_partials_count(4, 32, 100) >= 1
 
 
-def test_product_path_refuses_cpu_tensors():
+def test_kernel_wrappers_refuse_cpu_tensors_but_modules_route_them_to_stock_torch():
+    """The ABI wrappers never see a CPU tensor: the nn modules send those to the stock torch layer they inherit
+    from (tests/test_cpu_path.py checks the numbers); a CPU tensor handed to a Function directly still raises."""
     import torch
-    from ecg_hip import EcgHipError
+    from ecg_hip import EcgHipError, functional as hipF
     from src.models.ecg_cnn import ECGCNN
-    from src.training.loop_demo import bce_loss_fn
-    with pytest.raises(EcgHipError, match="no CPU fallback"):
-        ECGCNN(num_labels=5)(torch.randn(2, 12, 64))
-    with pytest.raises(EcgHipError):
-        bce_loss_fn(torch.zeros(2, 5), torch.zeros(2, 5))
+    assert ECGCNN(num_labels=5)(torch.randn(2, 12, 64)).shape == (2, 5)
+    with pytest.raises(EcgHipError, match="CPU tensor"):
+        hipF.ReLUFn.apply(torch.zeros(4))
+    with pytest.raises(EcgHipError, match="CPU tensor"):
+        hipF.BceWithLogitsFn.apply(torch.zeros(2, 5), torch.zeros(2, 5), None, 1.0)
 
 
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):

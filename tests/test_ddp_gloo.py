@@ -110,8 +110,18 @@ def _worker_flat(rank, world, port, out_dir):
     both = [torch.empty_like(local) for _ in range(world)]
     dist.all_gather(both, local)
     assert torch.allclose(flat, both[0] + both[1])                     # SUM; 1/world is applied in the kernel
-    with pytest.raises(Exception, match="no CPU fallback"):
-        opt.step()                                                     # the update itself is HIP-only
+    # the update on CPU parameters is stock torch math: one step == torch.optim.AdamW on the averaged gradient
+    ref = torch.nn.Sequential(torch.nn.Linear(7, 5), torch.nn.Linear(5, 3))
+    ref.load_state_dict({k: v.clone() for k, v in lin.state_dict().items()})
+    ropt = torch.optim.AdamW(ref.parameters(), lr=1e-3, weight_decay=1e-4)
+    off = 0
+    for q in ref.parameters():
+        q.grad = (0.5 * (both[0] + both[1]))[off:off + q.numel()].view_as(q).clone()
+        off += q.numel()
+    ropt.step()
+    opt.step()
+    for a, b in zip(lin.parameters(), ref.parameters()):
+        assert torch.allclose(a, b, rtol=0, atol=1e-7)
     # hook-based wrapper: uneven shards are rejected, equal shards are contiguous
     with pytest.raises(ValueError):
         ddp.shard_batch((torch.zeros(5, 2),), rank, world)
@@ -148,6 +158,94 @@ def _worker_overlap(rank, world, port, out_dir):
     assert not opt2._overlap
     dist.barrier()
     dist.destroy_process_group()
+
+
+def _worker_product_g5(rank, world, port, name, out_dir):
+    """G5 through the PRODUCT modules (src.models on CPU tensors = stock torch layers) and the product
+    optimizer: FlatAdamW(process_group) with the bucketed exchange issued from backward hooks."""
+    ddp = _setup(rank, world, port)
+    from ecg_hip.optim import FlatAdamW
+    from oracle import ref_models as R
+    from src.models.ecg_cnn import ECGCNN
+    from src.models.ecg_multimodal import ECGMultimodal
+    from src.training.loop import train_one_epoch
+    from src.training.loop_demo import train_one_epoch_demo
+    from src.utils.seed import set_seed
+    ctor, C, demo, lr = {"cnn5": (lambda: ECGCNN(num_labels=5), 5, False, 1.5e-3),
+                         "mm": (lambda: ECGMultimodal(), 5, True, 1e-4)}[name]
+    set_seed(42 + rank)                   # deliberately different replicas: rank 0 must win
+    model = ctor().train()
+    ddp.broadcast_module_state(model, 0)
+    opt = FlatAdamW(model.parameters(), lr=lr, weight_decay=1e-4)
+    assert opt.world_size == world and opt._overlap
+    batch = R.synthetic_batch(32, 1000, C, demo=demo)
+    shard = ddp.shard_batch(batch, rank, world)
+
+    class OneBatch:
+        dataset = range(shard[0].shape[0])
+
+        def __iter__(self):
+            return iter([shard])
+
+    (train_one_epoch_demo if demo else train_one_epoch)(model, OneBatch(), opt, "cpu")
+    if rank == 0:
+        torch.save({"sd": model.state_dict(), "flat_grad": opt.flat_grad.clone() / world}, os.path.join(out_dir, f"p_{name}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("name", ["cnn5", "mm"])
+def test_g5_through_product_modules_and_flat_optimizer_world8(tmp_path, name):
+    world, port = 8, _free_port()
+    mp.spawn(_worker_product_g5, args=(world, port, name, str(tmp_path)), nprocs=world, join=True)
+    got = torch.load(os.path.join(tmp_path, f"p_{name}.pt"))
+    g = golden("g5_ddp")
+    lr = float(g[f"{name}_lr"])
+    for k, v in got["sd"].items():
+        if k.endswith("num_batches_tracked"):
+            assert int(v) == int(g[f"{name}_post_sd_{k}"]) == 1
+        else:
+            check_put(g, f"{name}_post_sd_{k}", v, atol=2.02 * lr if ".net.0.bias" in k else 2e-5)
+
+
+def _worker_accum(rank, world, port, out_dir):
+    """Gradient accumulation: two backward passes per step.  Without no_sync() the second pass would add local
+    gradients to an already rank-summed bucket — FlatAdamW refuses; with no_sync() the accumulated gradient is
+    exchanged once."""
+    _setup(rank, world, port)
+    from ecg_hip.optim import FlatAdamW
+    torch.manual_seed(0)
+    lin = torch.nn.Sequential(*[torch.nn.Linear(6, 6) for _ in range(6)])          # 12 tensors: early bucket = 8
+    opt = FlatAdamW(lin.parameters(), lr=1e-3, weight_decay=0.0)
+    assert opt._overlap
+    xs = [torch.full((3, 6), float(rank + 1 + i)) for i in range(2)]
+    lin(xs[0]).sum().backward()
+    with pytest.raises(RuntimeError, match="no_sync"):
+        lin(xs[1]).sum().backward()
+    opt.reduce_gradients()                                  # drain the in-flight work of the first pass
+    opt.zero_grad()
+    with opt.no_sync():
+        lin(xs[0]).sum().backward()
+        assert opt._late_work is None and opt._early_work is None
+    lin(xs[1]).sum().backward()                             # exchanges g(x0) + g(x1)
+    local = []
+    for i in range(2):
+        ref = torch.nn.Sequential(*[torch.nn.Linear(6, 6) for _ in range(6)])
+        ref.load_state_dict(lin.state_dict())
+        ref(xs[i]).sum().backward()
+        local.append(torch.cat([p.grad.reshape(-1) for p in ref.parameters()]))
+    mine = local[0] + local[1]
+    both = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(both, mine)
+    flat, scale = opt.reduce_gradients()
+    assert scale == 0.5 and torch.allclose(flat, both[0] + both[1], rtol=1e-6, atol=1e-6)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gradient_accumulation_needs_no_sync_world2(tmp_path):
+    world, port = 2, _free_port()
+    mp.spawn(_worker_accum, args=(world, port, str(tmp_path)), nprocs=world, join=True)
 
 
 def test_bucketed_overlap_exchange_world2(tmp_path):

@@ -87,24 +87,36 @@ def test_two_ranks_share_one_gpu(tmp_path, overlap):
     np.testing.assert_allclose(r1["losses"], want_losses[:, 1], atol=2e-4)
 
 
-def test_bench_two_rank_line(tmp_path):
-    """bench.py exactly as the driver launches it for N > 1 (torch.distributed.run, one rank per process),
-    rehearsed with both ranks on one device: one JSON line from rank 0 with the contract's fields."""
+@pytest.mark.parametrize("launcher", ["self", "torchrun"])
+def test_bench_two_rank_line(tmp_path, launcher):
+    """bench.py for N > 1 in both launch forms — the plain `python bench.py --gpus 2` (bench starts its own
+    rank processes before touching the GPU) and the driver's torch.distributed.run form — rehearsed with both
+    ranks on one device (gloo): one JSON line from rank 0 with the contract's fields and the exchange checks."""
     import json
     env = dict(os.environ, ECG_HIP_REHEARSE_ON_ONE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
-           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2", "--batch", "32"]
-    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+    env.pop("WORLD_SIZE", None), env.pop("RANK", None), env.pop("LOCAL_RANK", None)
+    tail = [os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2", "--priming", "2",
+            "--batch", "32", "--n1-value", "1000"]
+    if launcher == "self":
+        cmd = [sys.executable] + tail
+    else:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+               "--master-addr", "127.0.0.1", "--master-port", str(_free_port())] + tail
+    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=400)
     assert res.returncode == 0, res.stderr[-3000:]
     lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, res.stdout[-2000:]
     d = json.loads(lines[0])
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
-                "vs_baseline", "dtype", "data", "config", "roofline"):
+                "vs_baseline", "dtype", "data", "config", "roofline", "step_ms", "layers", "rccl", "efficiency_vs_n1"):
         assert key in d, key
     assert d["n_gpus"] == 2 and d["steps"] == 4 and d["scaling"] == "weak" and d["unit"] == "windows/s"
     assert d["config"]["global_batch"] == 64 and d["config"]["parallelism"] == "dp2"
     assert "cpu_baseline" not in d                      # rank 0 at N = 1 only
     assert abs(d["value"] - 64 * 4 / (d["ms_per_step"] * 4 * 1e-3)) / d["value"] < 1e-3
-    assert d["also"]["value"] > 0
+    assert d["step_ms"]["n"] == 4 and d["step_ms"]["p10"] <= d["step_ms"]["median"] <= d["step_ms"]["p90"]
+    r = d["rccl"]
+    assert r["ranks_seen_by_allreduce"] == 2 and r["rel_diff"] < 1e-6 and r["flat_gradient_bytes"] == 719397 * 4
+    assert r["exchange_exposed_ms_per_step"]["n"] == 5
+    assert [a["value"] > 0 for a in d["also"]] == [True]          # N > 1: the multimodal leg only
+    assert {row["op"] for row in d["layers"]} == {"fwd", "dgrad", "wgrad"} and len(d["layers"]) == 11

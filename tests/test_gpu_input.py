@@ -190,3 +190,34 @@ def test_loader_feeds_the_training_loop(hip, tmp_path):
     losses = [train_one_epoch_demo(model, pack.PackedBatchLoader(path, 8, shuffle=True, seed=1), opt, "cuda")
               for _ in range(3)]
     assert all(np.isfinite(losses)) and losses[-1] < losses[0]
+
+
+def test_packed_loader_has_a_dataset_for_the_single_input_loops(hip, tmp_path):
+    """train_one_epoch / eval_one_epoch end with len(loader.dataset) (src/training/loop.py:38,73): the packed
+    loader without demographics must give the same epoch loss as a DataLoader over the same windows."""
+    from ecg_hip import pack
+    from src.models.ecg_cnn import ECGCNN
+    from src.training.loop import eval_one_epoch, train_one_epoch
+    from src.utils.seed import set_seed
+    rng = np.random.default_rng(11)
+    n, T = 21, 1000                                   # ragged last batch: 8 + 8 + 5
+    d = rng.integers(-2500, 2500, size=(n, T, 12)).astype(np.int16)
+    gain, base = np.full((n, 12), 1000.0), np.zeros((n, 12), np.int32)
+    y = (rng.random((n, 5)) < 0.3).astype(np.float32)
+    path = str(tmp_path / "s.ecgpack")
+    pack.write_pack(path, d, gain, base, y, None)
+    ld = pack.PackedBatchLoader(path, 8)
+    assert len(ld.dataset) == n and len(ld) == 3
+    ld2 = pack.PackedBatchLoader(path, 8, rank=1, world_size=2, drop_last=True)
+    assert len(ld2.dataset) == 8 and len(ld2) == 1      # 21 -> wrap-padded to 22 -> 11 per rank -> one full batch
+    xw = torch.from_numpy(io_ref.windows_from_wfdb16(d, gain, base))
+    ds = torch.utils.data.TensorDataset(xw, torch.from_numpy(y))
+    losses = []
+    for loader in (ld, torch.utils.data.DataLoader(ds, batch_size=8, shuffle=False)):
+        set_seed(42)
+        model = ECGCNN(num_labels=5).cuda()
+        opt = torch.optim.AdamW(model.parameters(), lr=1e-3, weight_decay=1e-4)
+        tr = train_one_epoch(model, loader, opt, "cuda")
+        ev = eval_one_epoch(model, loader, "cuda")
+        losses.append((tr, ev["bce_loss"]))
+    assert abs(losses[0][0] - losses[1][0]) < 1e-6 and abs(losses[0][1] - losses[1][1]) < 1e-6, losses

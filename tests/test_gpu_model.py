@@ -151,6 +151,19 @@ def test_g6_gradcam_hooks_and_demo_gradient():
         np.testing.assert_allclose(up.cpu().numpy(), g[name + "_cam_up"], atol=1e-5)
         if name == "multimodal":
             np.testing.assert_allclose(demo.grad.cpu().numpy(), g["multimodal_dlogit_ddemo"], atol=1e-5)
+        # the deprecated NON-full hook, registered exactly as src/interpretability/grad_cam_1d.py:30-36 does
+        # (forward hook stores output.detach(), register_backward_hook stores grad_output[0].detach())
+        legacy = {}
+        h3 = last.register_forward_hook(lambda mod, i, o: legacy.__setitem__("act", o.detach()))
+        with pytest.warns(Warning):
+            h4 = last.register_backward_hook(lambda mod, gi, go: legacy.__setitem__("grad", go[0].detach()))
+            m.zero_grad()
+            lg = m(x, demo.detach()) if name == "multimodal" else m(x)
+            lg[:, 0].sum().backward()
+        h3.remove(), h4.remove()
+        check_put(g, name + "_act", legacy["act"][0], atol=1e-4)
+        check_put(g, name + "_grad", legacy["grad"][0], atol=1e-6)
+        assert torch.equal(legacy["act"], store["act"]) and torch.equal(legacy["grad"], store["grad"])
         # and the fused path (no hooks) gives the same logits
         with torch.no_grad():
             l2 = m(x, demo.detach()) if name == "multimodal" else m(x)
@@ -466,9 +479,10 @@ def test_graphed_train_step_matches_eager():
     gopt = FlatAdamW(graphed.parameters(), lr=1e-3, weight_decay=1e-4)
     sd0 = {k: v.clone() for k, v in graphed.state_dict().items()}
     step = GraphedTrainStep(graphed, gopt, batch, warmup=2)
-    # the constructor's warm-up/capture iterations advanced the model: rewind it completely
-    graphed.load_state_dict(sd0)
-    gopt.flat_m.zero_(), gopt.flat_v.zero_(), gopt._step_dev.zero_()
+    # the constructor's warm-up iterations are real steps, but it puts back everything they advanced
+    for k, v in graphed.state_dict().items():
+        assert torch.equal(v, sd0[k]), k
+    assert gopt.steps_taken == 0 and float(gopt.flat_m.abs().max()) == 0.0 and float(gopt.flat_v.abs().max()) == 0.0
     losses = []
     for _ in range(4):
         eopt.zero_grad()
@@ -485,3 +499,61 @@ def test_graphed_train_step_matches_eager():
             assert int(a.item()) == int(b.item()) == 4
         else:
             np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), atol=1e-6, err_msg=k)
+
+
+def test_parameter_used_twice_in_one_backward_matches_stock_torch():
+    """Model called twice before backward() (shared weights): each parameter gets TWO gradients in one pass.
+    Only the first may land in the flat-buffer sink; autograd must end with dw1 + dw2 (not 2*dw2)."""
+    from ecg_hip import functional as hipF
+    from ecg_hip.optim import FlatAdamW
+    from src.models.ecg_multimodal import ECGMultimodal
+    from src.utils.seed import set_seed
+    set_seed(42)
+    model = ECGMultimodal().to(DEV).train()
+    R.seed_all(42)
+    ref = R.RefECGMultimodal().train()
+    opt = FlatAdamW(model.parameters(), lr=1e-4, weight_decay=1e-4)      # registers the gradient sinks
+    b1 = R.synthetic_batch(6, 500, 5, demo=True)
+    b2 = R.synthetic_batch(6, 500, 5, gen_seed=77, demo=True)
+    for rep in range(2):                     # second repetition: the handed-out set was cleared by the engine callback
+        opt.zero_grad()
+        loss = (hipF.binary_cross_entropy_with_logits(model(b1[0].to(DEV), b1[1].to(DEV)), b1[2].to(DEV))
+                + hipF.binary_cross_entropy_with_logits(model(b2[0].to(DEV), b2[1].to(DEV)), b2[2].to(DEV)))
+        loss.backward()
+        ref.zero_grad()
+        rl = (torch.nn.functional.binary_cross_entropy_with_logits(ref(b1[0], b1[1]), b1[2])
+              + torch.nn.functional.binary_cross_entropy_with_logits(ref(b2[0], b2[1]), b2[2]))
+        rl.backward()
+        assert abs(loss.item() - rl.item()) < 1e-5
+        for (k, a), (_, b) in zip(model.named_parameters(), ref.named_parameters()):
+            tol = 1e-6 if ".net.0.bias" in k else 1e-4
+            np.testing.assert_allclose(a.grad.cpu().numpy(), b.grad.numpy(), atol=tol, err_msg=f"{k} rep {rep}")
+        # undo the BN running-stat drift between the two models for the second repetition
+        ref.load_state_dict({k: v.detach().cpu() for k, v in model.state_dict().items()})
+
+
+@pytest.mark.parametrize("name", ["cnn5", "mm"])
+def test_train_step_is_bitwise_reproducible(name):
+    """Two identical B=256 train steps from the same state: bit-identical flat gradient, BN buffers and
+    parameters (fixed-order weight-gradient slabs, ordered statistics partials, no atomics)."""
+    from ecg_hip import functional as hipF
+    from ecg_hip.optim import FlatAdamW
+    from src.utils.seed import set_seed
+    ctor, _, C, demo = _ctors()[name]
+    batch = tuple(t.to(DEV) for t in R.synthetic_batch(256, 1000, C, demo=demo))
+    outs = []
+    for rep in range(2):
+        set_seed(42)
+        model = ctor().to(DEV).train()
+        opt = FlatAdamW(model.parameters(), lr=1e-4, weight_decay=1e-4)
+        for _ in range(2):
+            opt.zero_grad()
+            loss = hipF.binary_cross_entropy_with_logits(model(*batch[:-1]), batch[-1])
+            loss.backward()
+            opt.step()
+        outs.append((opt.flat_grad.clone(), loss.detach().clone(), {k: v.clone() for k, v in model.state_dict().items()}))
+        del model, opt
+    assert torch.equal(outs[0][0], outs[1][0]), "flat gradient differs between identical runs"
+    assert torch.equal(outs[0][1], outs[1][1])
+    for k in outs[0][2]:
+        assert torch.equal(outs[0][2][k], outs[1][2][k]), k

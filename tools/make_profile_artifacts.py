@@ -1,17 +1,20 @@
 #!/usr/bin/env python3
 """Turn gpurun_out/ of tools/collect_profiles.sh into the artefacts committed under profiles/.
 
-    python tools/make_profile_artifacts.py r01
+    python tools/make_profile_artifacts.py r02
 
 profiles/<tag>_bench*.json            the bench lines as printed
 profiles/<tag>_kernel_stats.csv       rocprofv3 --stats table of the bench command
 profiles/<tag>_kernel_stats_summary.txt   the same per training step (tools/prof_summary.py)
-profiles/<tag>_pmc_summary.txt        per-kernel averages of the three counter passes
-profiles/pmc_traffic.json             HBM bytes per launch for the conv entry points bench.py prices:
+profiles/<tag>_pmc_summary.txt        per ENTRY POINT (same keys as bench.py's `layers`): launches, µs, FETCH_SIZE,
+                                      WRITE_SIZE, HBM bytes, MFMA-pipe busy fraction and clock
+profiles/pmc_traffic.json             {"_meta": {commit, csrc_digest, source}, "entries": {key: HBM bytes per call}}
         traffic = 2 * FETCH_SIZE + WRITE_SIZE   (rocprofv3 reports both in KiB; on gfx950 FETCH_SIZE counts
-        half the bytes of wide coalesced reads — MI355X_MICROARCH.md, HBM section — hence the factor 2),
-    plus MFMA-pipe utilisation of the longest dispatch of every MFMA kernel:
-        busy = SQ_VALU_MFMA_BUSY_CYCLES / (4 SIMDs * 256 CUs * GRBM_GUI_ACTIVE), clock = GRBM_GUI_ACTIVE / duration
+        half the bytes of wide coalesced reads — MI355X_MICROARCH.md, HBM section — hence the factor 2);
+        busy = SQ_VALU_MFMA_BUSY_CYCLES / (4 SIMDs * 256 CUs * GRBM_GUI_ACTIVE / 8), clock = GRBM_GUI_ACTIVE / 8 / duration
+
+The counter passes run tools/pmc_step.py, which launches a marker kernel in front of every ABI call and logs the
+order of the entry points: the dispatches between two markers ARE that entry point's launches.
 """
 import collections
 import csv
@@ -23,8 +26,10 @@ import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-TAG = sys.argv[1] if len(sys.argv) > 1 else "r01"
+sys.path.insert(0, ROOT)
+TAG = sys.argv[1] if len(sys.argv) > 1 else "r02"
 OUT, PROF = os.path.join(ROOT, "gpurun_out"), os.path.join(ROOT, "profiles")
+MARKER = "relu_fwd_kernel"
 
 
 def newest(pattern):
@@ -34,24 +39,32 @@ def newest(pattern):
     return files[-1]
 
 
-def counters(d):
-    """One --pmc pass -> {(kernel name, grid): [per-dispatch {counter: value, "_ns": duration}]}.
-    Several layers share a (kernel, grid) pair; callers pick the dispatches they mean by duration."""
-    per = collections.defaultdict(dict)
-    for r in csv.DictReader(open(newest(os.path.join(d, "**", "*counter_collection.csv")))):
-        e = per[(r["Kernel_Name"], int(r["Grid_Size"]), int(r["Dispatch_Id"]))]
-        e[r["Counter_Name"]] = float(r["Counter_Value"])
-        e["_ns"] = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
-    agg = collections.defaultdict(list)
-    for (name, grid, _), e in per.items():
-        agg[(name, grid)].append(e)
-    return agg
-
-
-def longest(dispatches):
-    """The dispatches of the longest-running layer among those sharing a (kernel, grid) pair."""
-    top = max(e["_ns"] for e in dispatches)
-    return [e for e in dispatches if e["_ns"] >= 0.85 * top]
+def per_entry(tag_dir):
+    """One --pmc pass of tools/pmc_step.py -> {entry key: [per-call {counter: sum over its launches, "_ns", "_n"}]}."""
+    order = json.load(open(tag_dir + ".order.json"))["order"]
+    disp = collections.OrderedDict()
+    rows = list(csv.DictReader(open(newest(os.path.join(tag_dir, "**", "*counter_collection.csv")))))
+    rows.sort(key=lambda r: int(r["Dispatch_Id"]))
+    for r in rows:
+        e = disp.setdefault(int(r["Dispatch_Id"]), {"name": r["Kernel_Name"], "c": {}})
+        e["c"][r["Counter_Name"]] = float(r["Counter_Value"])
+        e["ns"] = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+    segs, cur = [], None
+    for e in disp.values():
+        if MARKER in e["name"]:
+            cur = {"_ns": 0, "_n": 0}
+            segs.append(cur)
+        elif cur is not None and "ecg::" in e["name"]:
+            for k, v in e["c"].items():
+                cur[k] = cur.get(k, 0.0) + v
+            cur["_ns"] += e["ns"]
+            cur["_n"] += 1
+    if len(segs) != len(order):
+        raise SystemExit(f"{tag_dir}: {len(segs)} marked segments but {len(order)} logged entry points")
+    out = collections.defaultdict(list)
+    for key, s in zip(order, segs):
+        out[key].append(s)
+    return out
 
 
 def mean(v):
@@ -64,58 +77,45 @@ def main():
         shutil.copy(f, os.path.join(PROF, os.path.basename(f)))
     stats = newest(os.path.join(OUT, f"prof_{TAG}", "**", "*_kernel_stats.csv"))
     shutil.copy(stats, os.path.join(PROF, f"{TAG}_kernel_stats.csv"))
-    steps = 20 + 5 + 10          # timed + warm-up + the instrumented pass of bench.py
+    steps = 20 + 5 + 5          # timed + warm-up + the instrumented pass of bench.py (--priming 0)
     summ = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "prof_summary.py"),
                            os.path.dirname(stats), str(steps), "40"], capture_output=True, text=True).stdout
     open(os.path.join(PROF, f"{TAG}_kernel_stats_summary.txt"), "w").write(
-        f"# rocprofv3 --kernel-trace --stats -- python3 bench.py --no-cpu-baseline --no-also --steps 20 --warmup 5  ({steps} steps incl. warm-up and the instrumented pass)\n" + summ)
+        f"# rocprofv3 --kernel-trace --stats -- python3 bench.py --no-cpu-baseline --no-also --steps 20 --warmup 5 --priming 0  ({steps} steps incl. warm-up and the instrumented pass)\n" + summ)
 
-    fetch = counters(os.path.join(OUT, f"pmc_fetch_{TAG}"))
-    write = counters(os.path.join(OUT, f"pmc_write_{TAG}"))
-    sq = counters(os.path.join(OUT, f"pmc_sq_{TAG}"))
-    short = lambda name: name.replace("void ecg::", "").replace("ecg::", "")[:56]
-    lines = ["# per (kernel, grid), LONGEST layer sharing that pair (mean over its launches); FETCH_SIZE / WRITE_SIZE in KiB as",
-             "# reported by rocprofv3 (separate passes); hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024 (gfx950 FETCH_SIZE correction)"]
-    hbm = {}
-    for key in sorted(fetch):
-        name, grid = key
-        fl = longest(fetch[key])
-        f = mean([e["FETCH_SIZE"] for e in fl])
-        w = mean([e["WRITE_SIZE"] for e in longest(write[key])]) if key in write else float("nan")
-        hbm[key] = (2 * f + w) * 1024
-        lines.append(f"{short(name):56s} grid={grid:>8d} us={mean([e['_ns'] for e in fl]) / 1e3:8.1f} FETCH_SIZE={f:10.1f} "
-                     f"WRITE_SIZE={w:10.1f} hbm_bytes={hbm[key]:14.0f}")
-    lines.append("# MFMA pipe of the same dispatches: busy = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs * cycles), cycles = GRBM_GUI_ACTIVE / 8")
-    lines.append("# (GRBM_GUI_ACTIVE is summed over the 8 XCDs); clock = cycles / duration")
-    util = {}
-    for key in sorted(sq):
-        name, grid = key
-        if "mfma" not in name:
-            continue
-        sl = longest(sq[key])
-        cyc = mean([e["GRBM_GUI_ACTIVE"] for e in sl]) / 8.0
-        busy = mean([e["SQ_VALU_MFMA_BUSY_CYCLES"] for e in sl])
-        d_us = mean([e["_ns"] for e in sl]) / 1e3
-        util[f"{short(name)} grid={grid}"] = {"mfma_busy_frac": round(busy / (1024 * cyc), 3), "clock_GHz": round(cyc / (d_us * 1e3), 3),
-                                             "dur_us": round(d_us, 1)}
-        lines.append(f"{short(name):56s} grid={grid:>8d} us={d_us:8.1f} mfma_busy={busy / (1024 * cyc):.3f} clock_GHz={cyc / (d_us * 1e3):.3f}")
+    fetch = per_entry(os.path.join(OUT, f"pmc_fetch_{TAG}"))
+    write = per_entry(os.path.join(OUT, f"pmc_write_{TAG}"))
+    sq = per_entry(os.path.join(OUT, f"pmc_sq_{TAG}"))
+    lines = ["# per entry point of one ECGCNN(5) B=256 12x1000 train step (tools/pmc_step.py; same keys as bench.py `layers`):",
+             "# launches per call, µs per call (under the counter pass), FETCH_SIZE / WRITE_SIZE in KiB as rocprofv3 reports them",
+             "# (separate passes), hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024 (gfx950 FETCH_SIZE correction),",
+             "# mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs * GRBM_GUI_ACTIVE / 8), clock = GRBM_GUI_ACTIVE / 8 / duration"]
+    entries = {}
+    for key in fetch:
+        f = mean([s.get("FETCH_SIZE", 0.0) for s in fetch[key]])
+        w = mean([s.get("WRITE_SIZE", 0.0) for s in write[key]]) if key in write else float("nan")
+        hb = (2 * f + w) * 1024
+        entries[key] = int(hb)
+        us = mean([s["_ns"] for s in fetch[key]]) / 1e3
+        extra = ""
+        if key in sq and "mfma" in "".join(k for k in [key]) or ("conv1d" in key and key in sq):
+            cyc = mean([s.get("GRBM_GUI_ACTIVE", 0.0) for s in sq[key]]) / 8.0
+            busy = mean([s.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) for s in sq[key]])
+            d_us = mean([s["_ns"] for s in sq[key]]) / 1e3
+            if cyc > 0 and busy > 0:
+                extra = f" mfma_busy={busy / (1024 * cyc):.3f} clock_GHz={cyc / (d_us * 1e3):.3f}"
+        lines.append(f"{key:64s} launches={fetch[key][0]['_n']:2d} us={us:8.1f} FETCH_SIZE={f:10.1f} WRITE_SIZE={w:10.1f} "
+                     f"hbm_bytes={hb:12.0f}{extra}")
     open(os.path.join(PROF, f"{TAG}_pmc_summary.txt"), "w").write("\n".join(lines) + "\n")
 
-    # entry point -> (kernel substring, grid) for B=256, 12x1000: block-3 forward (stats epilogue) and block-3 input-grad
-    # are the longest layers of their (kernel, grid) pairs
-    def traffic(sub, grid):
-        for (name, g) in fetch:
-            if sub in name and g == grid:
-                return int(hbm[(name, g)])
-        return None
-    tr = {"ecg_conv1d_fwd[256, 128, 256, 125, 15, 7]": traffic("conv1d_mfma_fwd_kernel<64, 128, 2, 2, 1>", 1 * 4 * 256 * 256),
-          "ecg_conv1d_bwd_data_ld[128, 256, 128, 256, 125, 15, 7]": traffic("conv1d_mfma_fwd_kernel<64, 128, 2, 2, 0>", 1 * 2 * 256 * 256),
-          "_formula": "hbm bytes per launch = (2 * FETCH_SIZE + WRITE_SIZE) KiB, separate rocprofv3 --pmc passes; "
-                      "gfx950 FETCH_SIZE correction per MI355X_MICROARCH.md",
-          "_mfma_utilisation": util}
-    json.dump(tr, open(os.path.join(PROF, "pmc_traffic.json"), "w"), indent=1)
+    import bench
+    commit = subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip()
+    meta = {"commit": commit, "csrc_digest": bench.csrc_digest(), "source": f"profiles/{TAG}_pmc_summary.txt",
+            "formula": "hbm bytes per call = (2 * FETCH_SIZE + WRITE_SIZE) KiB summed over the entry point's launches, separate "
+                       "rocprofv3 --pmc passes of tools/pmc_step.py; gfx950 FETCH_SIZE correction per MI355X_MICROARCH.md"}
+    json.dump({"_meta": meta, "entries": entries}, open(os.path.join(PROF, "pmc_traffic.json"), "w"), indent=1)
     print(summ[:1500])
-    print({k: v for k, v in tr.items() if k.startswith("ecg_")})
+    print("\n".join(lines[:40]))
 
 
 if __name__ == "__main__":
