@@ -189,7 +189,7 @@ def test_loader_refuses_cpu(tmp_path):
     from ecg_hip import EcgHipError
     path = _toy_pack(tmp_path)[0]
     if not torch.cuda.is_available():
-        with pytest.raises(EcgHipError, match="no CPU fallback"):
+        with pytest.raises(EcgHipError, match="prepares batches on the GPU"):
             pack.PackedBatchLoader(path, 4, device="cuda")
-    with pytest.raises(EcgHipError, match="no CPU fallback"):
+    with pytest.raises(EcgHipError, match="prepares batches on the GPU"):
         pack.PackedBatchLoader(path, 4, device="cpu")
