@@ -244,6 +244,7 @@ def cpu_baseline(seconds):
     the host cores.  Primary figure = BASELINE.json configs[0] / BASELINE.md §3: ECGCNN(5), batch 32, 12x1000;
     median of >= 30 steps.  The same model at batch 256 (the GPU leg's batch) rides along."""
     import numpy as np
+    import torch
     from oracle import ref_models as R
     info = host_info()
 
@@ -265,12 +266,26 @@ def cpu_baseline(seconds):
         return {"windows_per_s": round(B / med, 1), "median_ms": round(med * 1e3, 3), "steps": len(ts),
                 "p10_ms": round(float(np.percentile(ts, 10)) * 1e3, 3), "p90_ms": round(float(np.percentile(ts, 90)) * 1e3, 3)}
 
-    c1 = run(32, 1000, 5, False, 0.45 * seconds, 30)
-    c256 = run(256, 1000, 5, False, 0.45 * seconds, 5)
-    return {"value": c1["windows_per_s"], "unit": "windows/s", "cores": info["torch_threads"], "kind": "port",
+    # torch's default is one thread per logical core pair (128 here); on 12x1000 windows at batch 32 that
+    # oversubscribes oneDNN, so the baseline is the BEST of a short thread-count sweep (stated in the line)
+    default_threads = torch.get_num_threads()
+    sweep = {}
+    for th in sorted({default_threads, 32, 16, 8}):
+        if th > default_threads:
+            continue
+        torch.set_num_threads(th)
+        sweep[th] = run(32, 1000, 5, False, 0.12 * seconds, 30 if th == default_threads else 12)
+    best = max(sweep, key=lambda t: sweep[t]["windows_per_s"])
+    torch.set_num_threads(best)
+    c1 = run(32, 1000, 5, False, 0.2 * seconds, 30)
+    c256 = run(256, 1000, 5, False, 0.25 * seconds, 5)
+    torch.set_num_threads(default_threads)
+    return {"value": c1["windows_per_s"], "unit": "windows/s", "cores": best, "kind": "port",
             "sample": f"oracle/ref_models.py train_step (stock torch CPU ops), ECGCNN(5) B=32 12x1000 (BASELINE configs[0]), "
-                      f"median of {c1['steps']} steps ({c1['median_ms']} ms, p10 {c1['p10_ms']}, p90 {c1['p90_ms']})",
-            "batch256": {"value": c256["windows_per_s"], "median_ms": c256["median_ms"], "steps": c256["steps"]},
+                      f"median of {c1['steps']} steps ({c1['median_ms']} ms, p10 {c1['p10_ms']}, p90 {c1['p90_ms']}) at the best "
+                      f"thread count of the sweep",
+            "thread_sweep_windows_per_s": {str(t): v["windows_per_s"] for t, v in sweep.items()},
+            "batch256": {"value": c256["windows_per_s"], "median_ms": c256["median_ms"], "steps": c256["steps"], "threads": best},
             **info}
 
 

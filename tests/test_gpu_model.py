@@ -154,13 +154,17 @@ def test_g6_gradcam_hooks_and_demo_gradient():
         # the deprecated NON-full hook, registered exactly as src/interpretability/grad_cam_1d.py:30-36 does
         # (forward hook stores output.detach(), register_backward_hook stores grad_output[0].detach())
         legacy = {}
-        h3 = last.register_forward_hook(lambda mod, i, o: legacy.__setitem__("act", o.detach()))
-        with pytest.warns(Warning):
-            h4 = last.register_backward_hook(lambda mod, gi, go: legacy.__setitem__("grad", go[0].detach()))
-            m.zero_grad()
-            lg = m(x, demo.detach()) if name == "multimodal" else m(x)
+        m_l = ctor()                     # a fresh module: torch refuses to mix full and non-full hooks on one
+        m_l.load_state_dict(sd_from_npz(golden("g3_ckpt_" + name)))
+        m_l.to(DEV).eval()
+        last_l = [c for c in m_l.modules() if isinstance(c, torch.nn.Conv1d)][-1]
+        last_l.register_forward_hook(lambda mod, i, o: legacy.__setitem__("act", o.detach()))
+        import warnings
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")          # torch deprecates the non-full hook; the reference uses it
+            last_l.register_backward_hook(lambda mod, gi, go: legacy.__setitem__("grad", go[0].detach()))
+            lg = m_l(x, demo.detach()) if name == "multimodal" else m_l(x)
             lg[:, 0].sum().backward()
-        h3.remove(), h4.remove()
         check_put(g, name + "_act", legacy["act"][0], atol=1e-4)
         check_put(g, name + "_grad", legacy["grad"][0], atol=1e-6)
         assert torch.equal(legacy["act"], store["act"]) and torch.equal(legacy["grad"], store["grad"])
