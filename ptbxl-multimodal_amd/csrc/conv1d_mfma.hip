@@ -27,6 +27,18 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));   // native vector: sta
 
 constexpr int kKM = 15;   // largest kernel size the MFMA path stages (the reference uses 15)
 
+// In-kernel stamps (diagnostic build only: make STAMP=1 -> lib/libecg_hip_stamp.so; the product library has none).
+// Wave 0 of every workgroup writes s_memtime at a few points into a buffer no other code reads.
+#ifdef ECG_STAMP
+__device__ unsigned long long *g_stamps = nullptr;
+#define ECG_STAMP_AT(slot) do { if (g_stamps && threadIdx.x == 0) { \
+    g_stamps[(size_t)blockIdx.x * 8 + (slot)] = __builtin_amdgcn_s_memtime(); \
+    if ((slot) == 0) g_stamps[(size_t)blockIdx.x * 8 + 7] = __builtin_amdgcn_s_memrealtime(); \
+    if ((slot) == 4) g_stamps[(size_t)blockIdx.x * 8 + 6] = __builtin_amdgcn_s_memrealtime(); } } while (0)
+#else
+#define ECG_STAMP_AT(slot) do { } while (0)
+#endif
+
 __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
 }
@@ -97,6 +109,7 @@ __global__ __launch_bounds__(256, 2) void conv1d_mfma_fwd_kernel(
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int half = lane >> 5, l31 = lane & 31;
+    ECG_STAMP_AT(0);
     // logical tile order: the C_out tiles of one (n, t tile) are adjacent — they read the same x panel
     const int CT = Cout / CO_T;
     const int tile = xcd_chunked(blockIdx.x, gridDim.x);
@@ -113,6 +126,23 @@ __global__ __launch_bounds__(256, 2) void conv1d_mfma_fwd_kernel(
         for (int b = 0; b < MT; ++b)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    // ---- per-channel epilogue parameters, lane-indexed: lane (r + 32*half), r < 16, holds those of accumulator
+    // row (r, half) of each 32-channel group.  They are loaded HERE, before the main loop: vmcnt is in-order, so
+    // a global load issued between the epilogue's stores has to wait for the round trip of every store before it
+    // (16 rows x ~1 us per workgroup when the bias was fetched row by row).
+    constexpr bool EVALM = (EPI == EPI_EVAL || EPI == EPI_EVAL_GAP);
+    float p_b[MC], p_mu[MC], p_sc[MC], p_be[MC];
+#pragma unroll
+    for (int i = 0; i < MC; ++i) {
+        const int ch = co0 + wco + 32 * i + acc_row(l31 & 15, half);
+        p_b[i] = bias ? bias[ch] : 0.f;
+        p_mu[i] = p_sc[i] = p_be[i] = 0.f;
+        if (EVALM) {
+            const float is = (float)(1.0 / sqrt((double)ev.var[ch] + (double)ev.eps));
+            p_sc[i] = is * ev.gamma[ch]; p_mu[i] = ev.mean[ch]; p_be[i] = ev.beta[ch];
+        }
+    }
 
     // ---- loop-invariant per-thread staging offsets -------------------------------------------
     int woff[DPW];          // weight piece j of this wave: element offset inside wp (chunk 0)
@@ -162,6 +192,7 @@ __global__ __launch_bounds__(256, 2) void conv1d_mfma_fwd_kernel(
         for (int j = 0; j < XLOADS; ++j) load_x(j, CI_C);
     }
     __syncthreads();
+    ECG_STAMP_AT(1);
 
     for (int c = 0; c < nchunks; ++c) {
         const float *ws = lds + (c & 1) * IMG, *xs = ws + WPAD;
@@ -205,24 +236,43 @@ __global__ __launch_bounds__(256, 2) void conv1d_mfma_fwd_kernel(
             for (int i = 0; i < MT; ++i) b_c[i] = b_n[i];
         }
         __syncthreads();      // image c&1 free again; image (c+1)&1 complete (vmcnt(0) + barrier)
+        if (c == 0) ECG_STAMP_AT(2);
     }
+    ECG_STAMP_AT(3);
     float *red = lds;         // all images are dead: reuse image 0 for the statistics scratch
 
     // ---- epilogue: bias, store, per-channel (sum, sum^2) partials --------------------------
+    // Nothing is in flight here (the last chunk's barrier drained vmcnt), but the compiler cannot prove it for the
+    // staging registers of a loop it thinks may run zero times: without this explicit (free) wait it protects their
+    // reuse below with `s_waitcnt vmcnt(2..0)` in the MIDDLE of the stores, i.e. a wait for the stores themselves.
+    __builtin_amdgcn_s_waitcnt(0x0F70);        // vmcnt(0), expcnt/lgkmcnt untouched
+    // No global load and no LDS-crossbar permute between the stores.  Row r of the two halves: parameters come out
+    // of the lane-indexed registers by v_readlane; per-row sums are reduced over each 16-lane DPP row only and
+    // accumulated in lanes r / r+16 of ONE register per 32 channels, the two 16-lane sums meet once at the end.
+    auto pick = [&](float v, int r) {
+        const int vi = __float_as_int(v);
+        const float lo = __int_as_float(__builtin_amdgcn_readlane(vi, r));
+        const float hi = __int_as_float(__builtin_amdgcn_readlane(vi, r + 32));
+        return half ? hi : lo;
+    };
+    float st_s[MC], st_q[MC];
+#pragma unroll
+    for (int i = 0; i < MC; ++i) { st_s[i] = 0.f; st_q[i] = 0.f; }
+    const int Lp = Lo >> 1;
+    // element offset of (row 0 of this lane's half, first column of this lane) inside the output of sample n
+    float *yw = EVALM ? y + ((size_t)n * Cout + co0 + wco + 4 * half) * Lp + ((t0 + wt + l31) >> 1)
+                      : y + ((size_t)n * Cout + co0 + wco + 4 * half) * Lo + t0 + wt + l31;
 #pragma unroll
     for (int i = 0; i < MC; ++i) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int col = wco + 32 * i + acc_row(r, half);    // channel inside the CO_T tile
-            const float bv = bias ? bias[co0 + col] : 0.f;
+            const int rowk = 32 * i + (r & 3) + 8 * (r >> 2);          // channel row inside the wave tile, minus 4*half
+            const float bv = pick(p_b[i], r);
             float s = 0.f, q = 0.f;
-            if (EPI == EPI_EVAL || GAP) {
+            if (EVALM) {
                 // p[j] = max(0, max(a[2j], a[2j+1])), a = (v - mean) * (invstd * gamma) + beta.  The two
                 // samples of a pooling pair sit on adjacent lanes: one DPP quad_perm fetches the partner.
-                const int ch = co0 + col;
-                const float is = (float)(1.0 / sqrt((double)ev.var[ch] + (double)ev.eps));
-                const float sc = is * ev.gamma[ch], mu = ev.mean[ch], be = ev.beta[ch];
-                const int Lp = Lo >> 1;
+                const float mu = pick(p_mu[i], r), sc = pick(p_sc[i], r), be = pick(p_be[i], r);
 #pragma unroll
                 for (int j = 0; j < MT; ++j) {
                     const int t = t0 + wt + 32 * j + l31;
@@ -231,27 +281,35 @@ __global__ __launch_bounds__(256, 2) void conv1d_mfma_fwd_kernel(
                     const float m = fmaxf(fmaxf(a, o), 0.f);
                     const bool owner = !(l31 & 1) && (t >> 1) < Lp;
                     if (GAP) s += owner ? m : 0.f;
-                    else if (owner) y[((size_t)n * Cout + ch) * Lp + (t >> 1)] = m;
+                    else if (owner) yw[rowk * Lp + 16 * j] = m;
                 }
             } else {
 #pragma unroll
                 for (int j = 0; j < MT; ++j) {
-                    const int t = t0 + wt + 32 * j + l31;
                     const float v = acc[i][j][r] + bv;
-                    if (t < Lo) {
-                        y[((size_t)n * Cout + co0 + col) * Lo + t] = v;
+                    if (t0 + wt + 32 * j + l31 < Lo) {
+                        yw[rowk * Lo + 32 * j] = v;
                         if (STATS) { s += v; q = __fmaf_rn(v, v, q); }
                     }
                 }
             }
             if (STATS || GAP) {
-                s = half32_sum(s);       // 4 DPP adds + 1 bpermute, stays inside the 32-lane half
-                q = half32_sum(q);
-                if (l31 == 0) {
-                    const int lc = 32 * i + acc_row(r, half);   // channel inside the wave tile
-                    red[(wave * (CO_T / WCO) + lc) * 2] = s;
-                    red[(wave * (CO_T / WCO) + lc) * 2 + 1] = q;
-                }
+                const bool mine = (l31 & 15) == r;       // lanes r and r+16 of each half keep row (r, half)
+                s = row16_sum(s);                        // 4 DPP adds: every lane holds the sum of its 16-lane row
+                st_s[i] += mine ? s : 0.f;
+                if (STATS) { q = row16_sum(q); st_q[i] += mine ? q : 0.f; }
+            }
+        }
+    }
+    if (STATS || GAP) {
+#pragma unroll
+        for (int i = 0; i < MC; ++i) {
+            const float s = st_s[i] + __shfl_xor(st_s[i], 16, 64);
+            const float q = st_q[i] + __shfl_xor(st_q[i], 16, 64);
+            if (l31 < 16) {
+                const int lc = 32 * i + acc_row(l31, half);   // channel inside the wave tile
+                red[(wave * (CO_T / WCO) + lc) * 2] = s;
+                red[(wave * (CO_T / WCO) + lc) * 2 + 1] = q;
             }
         }
     }
@@ -279,13 +337,17 @@ __global__ __launch_bounds__(256, 2) void conv1d_mfma_fwd_kernel(
             partials[((size_t)(co0 + col) * P + pidx) * 2 + w] = s;
         }
     }
+#ifdef ECG_STAMP
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the stores of the epilogue have left the wave
+#endif
+    ECG_STAMP_AT(4);
 }
 
 struct FwdCfg { int co_t, t_t; };
 
-// Tile choice.  Measured on MI355X (B=256): 64x128 tiles at 4 resident workgroups per CU beat
-// 128x128 at 2 per CU by 6-8 % (more independent waves per SIMD to cover each other's prologue,
-// epilogue and staging waits), so the 64-channel tile is used whenever C_out allows it.
+// Tile choice of the one-tile-per-workgroup kernel (inference epilogues).  Measured on MI355X (B=256): 64x128
+// tiles at 4 resident workgroups per CU beat 128x128 at 2 per CU by 6-8 % (more independent waves per SIMD to
+// cover each other's prologue, epilogue and staging waits), so the 64-channel tile is used whenever C_out allows it.
 static FwdCfg fwd_cfg(int N, int Cout, int Lo) {
     (void)N; (void)Lo;
     if (Cout % 64 == 0) return {64, 128};
@@ -922,3 +984,9 @@ int mfma_wgrad(const float *dy, int ldy, const float *x, float *dw, float *db, f
 }
 
 }  // namespace ecg
+
+#ifdef ECG_STAMP
+extern "C" __attribute__((visibility("default"))) int ecg_debug_set_stamp_buffer(unsigned long long *buf) {
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(ecg::g_stamps), &buf, sizeof(buf));
+}
+#endif

@@ -13,7 +13,8 @@ import threading
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libecg_hip.so")
+# ECG_HIP_LIB: load another build of the same ABI instead (the diagnostic `make STAMP=1` library of the profiling tools)
+LIB_PATH = os.environ.get("ECG_HIP_LIB") or os.path.join(os.path.dirname(_HERE), "lib", "libecg_hip.so")
 
 _vp, _i, _f, _sz, _ll = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_size_t, ctypes.c_longlong
 

@@ -1,0 +1,62 @@
+#!/usr/bin/env python3
+"""Where does a forward-conv workgroup spend its time?  Runs each block geometry through the diagnostic build
+(make -C ptbxl-multimodal_amd/csrc STAMP=1; ECG_HIP_LIB=.../libecg_hip_stamp.so) whose kernel stamps s_memtime at
+start / end of prologue / end of first chunk / end of main loop / end of epilogue, and prints per-phase medians
+in microseconds (s_memtime ticks at 100 MHz... no: at the shader clock; s_memrealtime at 100 MHz anchors it)."""
+import ctypes
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "ptbxl-multimodal_amd")):
+    sys.path.insert(0, p)
+os.environ.setdefault("ECG_HIP_LIB", os.path.join(ROOT, "ptbxl-multimodal_amd", "lib", "libecg_hip_stamp.so"))
+os.environ["ECG_HIP_FWD_PERSISTENT"] = "0"
+
+
+def main():
+    import numpy as np
+    import torch
+    from ecg_hip import _lib as L, functional as F
+    lib = L.load()
+    lib.ecg_debug_set_stamp_buffer.argtypes = [ctypes.c_void_p]
+    dev = torch.device("cuda", 0)
+    N, K, pad = 256, 15, 7
+    Lc = 1000
+    for b, (ci, co) in enumerate([(12, 32), (32, 64), (64, 128), (128, 256)]):
+        x = torch.randn(N, ci, Lc, device=dev)
+        w = torch.randn(co, ci, K, device=dev) * 0.05
+        bias = torch.randn(co, device=dev)
+        wf, _ = F.conv1d_pack(w, need_bwd=False)
+        y = torch.empty(N, co, Lc, device=dev)
+        P = L.query("ecg_conv1d_fwd_stat_partials", N, ci, co, Lc, K, pad)
+        part = torch.empty(co * P * 2, device=dev)
+        stamps = torch.zeros(8192 * 8, dtype=torch.int64, device=dev)
+        for rep in range(3):
+            stamps.zero_()
+            lib.ecg_debug_set_stamp_buffer(stamps.data_ptr())
+            L.call("ecg_conv1d_fwd", L.f32(x), L.f32(wf), L.f32(bias), L.f32(y), L.f32(part), N, ci, co, Lc, K, pad, L.stream())
+            torch.cuda.synchronize()
+        s = stamps.cpu().numpy().reshape(-1, 8)
+        s = s[s[:, 0] != 0]
+        rt0, rt1 = s[:, 7].astype(np.float64), s[:, 6].astype(np.float64)      # s_memrealtime, 100 MHz
+        t = s[:, :5].astype(np.float64)
+        dur_ticks = t[:, 4] - t[:, 0]
+        clk = float(np.median(dur_ticks / np.maximum(rt1 - rt0, 1.0))) * 100e6     # s_memtime ticks per second
+        ph = np.diff(t, axis=1)
+        span_us = (rt1.max() - rt0.min()) / 100.0
+        out = {"block": b, "workgroups": int(len(s)), "clock_GHz_est": round(clk / 1e9, 3), "kernel_span_us": round(span_us, 1),
+               "start_spread_us": round((rt0.max() - rt0.min()) / 100.0, 2),
+               "end_spread_us": round((rt1.max() - rt1.min()) / 100.0, 2),
+               "median_us": {k: round(float(np.median(ph[:, i])) / clk * 1e6, 2) for i, k in
+                             enumerate(["prologue", "first_chunk", "other_chunks", "epilogue"])},
+               "p90_us": {k: round(float(np.percentile(ph[:, i], 90)) / clk * 1e6, 2) for i, k in
+                          enumerate(["prologue", "first_chunk", "other_chunks", "epilogue"])},
+               "wg_total_median_us": round(float(np.median(dur_ticks)) / clk * 1e6, 2)}
+        print(json.dumps(out))
+        Lc //= 2
+
+
+if __name__ == "__main__":
+    main()
