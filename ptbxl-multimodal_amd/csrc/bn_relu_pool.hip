@@ -85,21 +85,40 @@ __global__ void bn_invstd_kernel(const float *__restrict__ var, float *__restric
 // ---------------------------------------------------------------------------------------
 // forward
 // ---------------------------------------------------------------------------------------
-// thread <-> pooled output; a wave reads 512 contiguous bytes of y and writes 256 of p.
+// grid = (C, S2): a block owns channel c and the samples of split s2 and walks their pooled positions flat, four
+// iterations in flight (loads unconditional, clamped); a wave reads 512 contiguous bytes of y and writes 256 of p.
 __global__ __launch_bounds__(kBlock) void bn_relu_pool_fwd_kernel(
     const float *__restrict__ y, const float *__restrict__ gamma, const float *__restrict__ beta,
     const float *__restrict__ mean, const float *__restrict__ invstd, float *__restrict__ p,
-    int C, int L, int Lp, size_t total) {
-    size_t idx = (size_t)blockIdx.x * kBlock + threadIdx.x;
-    if (idx >= total) return;
-    size_t row = idx / Lp;
-    int j = (int)(idx - row * Lp);
-    int c = (int)(row % C);
-    float sc = invstd[c] * gamma[c], mu = mean[c], be = beta[c];
-    const float *r = y + row * L + 2 * j;
-    float a0 = bn_apply1(r[0], mu, sc, be), a1 = bn_apply1(r[1], mu, sc, be);
-    float m = a1 > a0 ? a1 : a0;
-    p[idx] = m > 0.f ? m : 0.f;
+    int N, int C, int L, int Lp, int S2) {
+    const int c = blockIdx.x, s2 = blockIdx.y, tl = threadIdx.x;
+    const float sc = invstd[c] * gamma[c], mu = mean[c], be = beta[c];
+    const int n0 = (int)((long long)N * s2 / S2), n1 = (int)((long long)N * (s2 + 1) / S2);
+    const int total = (n1 - n0) * Lp;
+    constexpr int U = 4;
+    for (int base = tl; base < total; base += U * kBlock) {
+        float y0[U], y1[U];
+        size_t out[U];
+        bool live[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int idx = base + u * kBlock;
+            live[u] = idx < total;
+            const int ic = live[u] ? idx : tl;
+            const int nl = ic / Lp, j = ic - nl * Lp;
+            const size_t row = (size_t)(n0 + nl) * C + c;
+            const float *r = y + row * L + 2 * j;
+            y0[u] = r[0]; y1[u] = r[1];
+            out[u] = row * Lp + j;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (!live[u]) continue;
+            const float a0 = bn_apply1(y0[u], mu, sc, be), a1 = bn_apply1(y1[u], mu, sc, be);
+            const float m = a1 > a0 ? a1 : a0;
+            p[out[u]] = m > 0.f ? m : 0.f;
+        }
+    }
 }
 
 // Last block of the backbone: BatchNorm -> ReLU -> MaxPool(2) -> AdaptiveAvgPool1d(1) without
@@ -207,68 +226,103 @@ __global__ __launch_bounds__(kBlock) void bn_bwd_reduce_kernel(
         partials[((size_t)c * S + s) * 2 + tl] = red[0][tl] + red[1][tl] + red[2][tl] + red[3][tl];
 }
 
-// sums[c][0] = dbeta, sums[c][1] = dgamma (also written to dbeta/dgamma);  coef[c] = (k1, k2) =
-// (dbeta/M, dgamma/M) in train mode, (0, 0) in eval mode.
-__global__ __launch_bounds__(64) void bn_bwd_finalize_kernel(
-    const float *__restrict__ partials, int S, double M, float *__restrict__ dgamma,
-    float *__restrict__ dbeta, float *__restrict__ coef, int train) {
-    const int c = blockIdx.x, lane = threadIdx.x;
-    double a = 0.0, q = 0.0;
-    for (int p = lane; p < S; p += 64) {
-        a += (double)partials[((size_t)c * S + p) * 2];
-        q += (double)partials[((size_t)c * S + p) * 2 + 1];
-    }
-    a = wave_sum(a); q = wave_sum(q);
-    if (lane == 0) {
-        if (dbeta) dbeta[c] = (float)a;
-        if (dgamma) dgamma[c] = (float)q;
-        coef[2 * c] = train ? (float)(a / M) : 0.f;
-        coef[2 * c + 1] = train ? (float)(q / M) : 0.f;
-    }
-}
-
-// dy[t] = gamma*invstd * (da[t] - k1 - xhat[t]*k2).  thread <-> output pair (2j, 2j+1).
-// dy rows have stride ldy >= L; the pad [L, ldy) is written as zeros (Lh = ceil(ldy/2) pairs per
-// row): the weight-gradient kernel streams such rows by LDS-DMA and needs the zeros.
+// dy[t] = gamma*invstd * (da[t] - k1 - xhat[t]*k2), (k1, k2) = (dbeta, dgamma) / M in train mode, (0, 0) in eval mode.
+// grid = (C, S2): a block owns channel c and the samples of split s2 and walks their (sample, output pair) positions
+// flat, four iterations in flight (all loads unconditional, as in the reduce kernel above).
+// The combine of the S reduce partials is FOLDED in: every block re-derives (dbeta, dgamma) of its channel in double,
+// in a fixed order (thread t sums partials t, t+256, ...; lanes by butterfly; waves 0..3 in order) — S <= 1024/C + 1
+// numbers out of L2 — instead of a separate 4.9 us launch per layer; block s2 == 0 writes dbeta / dgamma.
+// dy rows have stride ldy >= L; the pad [L, ldy) is written as zeros (Lh = ceil(ldy/2) pairs per row): the
+// weight-gradient kernel streams such rows by LDS-DMA and needs the zeros.
 template <bool FUSED>
 __global__ __launch_bounds__(kBlock) void bn_bwd_dx_kernel(
     const float *__restrict__ y, const float *__restrict__ g, const float *__restrict__ gamma,
     const float *__restrict__ beta, const float *__restrict__ mean,
-    const float *__restrict__ invstd, const float *__restrict__ coef, float *__restrict__ dy,
-    int C, int L, int ldy, int Lh, size_t total, float bcast) {
-    size_t idx = (size_t)blockIdx.x * kBlock + threadIdx.x;
-    if (idx >= total) return;
-    size_t row = idx / Lh;
-    int j = (int)(idx - row * Lh);
-    float *d = dy + row * (size_t)ldy;
-    const int t0 = 2 * j;
-    if (t0 >= L) {                 // pad pair
-        d[t0] = 0.f;
-        if (t0 + 1 < ldy) d[t0 + 1] = 0.f;
-        return;
+    const float *__restrict__ invstd, const float *__restrict__ partials, int S, double M,
+    float *__restrict__ dgamma, float *__restrict__ dbeta, float *__restrict__ dy,
+    int N, int C, int L, int ldy, int Lh, int S2, float bcast, int train) {
+    __shared__ double red[4][2];
+    __shared__ float kk[2];
+    const int c = blockIdx.x, s2 = blockIdx.y, tl = threadIdx.x;
+    {
+        double a = 0.0, q = 0.0;
+        for (int p = tl; p < S; p += kBlock) {
+            a += (double)partials[((size_t)c * S + p) * 2];
+            q += (double)partials[((size_t)c * S + p) * 2 + 1];
+        }
+        a = wave_sum(a); q = wave_sum(q);
+        if ((tl & 63) == 0) { red[tl >> 6][0] = a; red[tl >> 6][1] = q; }
+        __syncthreads();
+        if (tl == 0) {
+            a = ((red[0][0] + red[1][0]) + red[2][0]) + red[3][0];
+            q = ((red[0][1] + red[1][1]) + red[2][1]) + red[3][1];
+            if (s2 == 0) {
+                if (dbeta) dbeta[c] = (float)a;
+                if (dgamma) dgamma[c] = (float)q;
+            }
+            kk[0] = train ? (float)(a / M) : 0.f;
+            kk[1] = train ? (float)(q / M) : 0.f;
+        }
+        __syncthreads();
     }
-    int c = (int)(row % C);
-    const float mu = mean[c], is = invstd[c], ga = gamma[c], sc = is * ga;
-    const float k1 = coef[2 * c], k2 = coef[2 * c + 1], gi = ga * is;
-    const float *r = y + row * L;
-    const bool has1 = t0 + 1 < L;
-    float y0 = r[t0], y1 = has1 ? r[t0 + 1] : 0.f;
-    float da0 = 0.f, da1 = 0.f;
-    if (FUSED) {
-        if (has1) {   // an odd tail sample never reaches the pool: da = 0
-            int am;
-            if (pool_route(y0, y1, mu, sc, beta[c], am)) {
-                float v = bcast != 0.f ? g[row] * bcast : g[row * (size_t)(L >> 1) + j];
-                if (am) da1 = v; else da0 = v;
+    const float k1 = kk[0], k2 = kk[1];
+    const float mu = mean[c], is = invstd[c], ga = gamma[c], sc = is * ga, gi = ga * is;
+    const float be = FUSED ? beta[c] : 0.f;
+    const int n0 = (int)((long long)N * s2 / S2), n1 = (int)((long long)N * (s2 + 1) / S2);
+    const int Lp = L >> 1;
+    const int total = (n1 - n0) * Lh;
+    constexpr int U = 4;
+    for (int base = tl; base < total; base += U * kBlock) {
+        float y0[U], y1[U], d0[U], d1[U];
+        int t0[U];
+        size_t rowv[U];
+        bool live[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int idx = base + u * kBlock;
+            live[u] = idx < total;
+            const int ic = live[u] ? idx : tl;                     // clamp to this thread's first (valid) pair
+            const int nl = ic / Lh, j = ic - nl * Lh;
+            const size_t row = (size_t)(n0 + nl) * C + c;
+            rowv[u] = row; t0[u] = 2 * j;
+            const float *r = y + row * L;
+            const int ta = min(2 * j, L - 1), tb = min(2 * j + 1, L - 1);
+            y0[u] = r[ta]; y1[u] = r[tb];
+            if (FUSED) {
+                d0[u] = bcast != 0.f ? g[row] * bcast : (Lp > 0 ? g[row * (size_t)Lp + min(j, Lp - 1)] : 0.f);
+                d1[u] = 0.f;
+            } else {
+                d0[u] = g[row * L + ta]; d1[u] = g[row * L + tb];
             }
         }
-    } else {
-        da0 = g[row * L + t0];
-        if (has1) da1 = g[row * L + t0 + 1];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (!live[u]) continue;
+            float *d = dy + rowv[u] * (size_t)ldy;
+            const int t = t0[u];
+            if (t >= L) {                  // pad pair
+                d[t] = 0.f;
+                if (t + 1 < ldy) d[t + 1] = 0.f;
+                continue;
+            }
+            const bool has1 = t + 1 < L;
+            float da0 = 0.f, da1 = 0.f;
+            if (FUSED) {
+                if (has1) {   // an odd tail sample never reaches the pool: da = 0
+                    int am;
+                    if (pool_route(y0[u], y1[u], mu, sc, be, am)) {
+                        if (am) da1 = d0[u]; else da0 = d0[u];
+                    }
+                }
+            } else {
+                da0 = d0[u];
+                if (has1) da1 = d1[u];
+            }
+            d[t] = gi * (da0 - k1 - (y0[u] - mu) * is * k2);
+            if (has1) d[t + 1] = gi * (da1 - k1 - (y1[u] - mu) * is * k2);
+            else if (t + 1 < ldy) d[t + 1] = 0.f;
+        }
     }
-    d[t0] = gi * (da0 - k1 - (y0 - mu) * is * k2);
-    if (has1) d[t0 + 1] = gi * (da1 - k1 - (y1 - mu) * is * k2);
-    else if (t0 + 1 < ldy) d[t0 + 1] = 0.f;
 }
 
 // ---------------------------------------------------------------------------------------
@@ -364,9 +418,10 @@ ECG_API int ecg_bn_relu_pool_fwd(const float *y, const float *gamma, const float
     const int Lp = L / 2;
     if (Lp == 0) return ECG_OK;   // MaxPool1d(2) of a length-1 row is empty
     ECG_REQUIRE(p, "bn_relu_pool_fwd: null output");
-    size_t total = (size_t)N * C * Lp;
-    hipLaunchKernelGGL(bn_relu_pool_fwd_kernel, dim3(cdiv(total, kBlock)), dim3(kBlock), 0,
-                       as_stream(stream), y, gamma, beta, mean, invstd, p, C, L, Lp, total);
+    int S2 = cdiv(4096, C);
+    if (S2 > N) S2 = N;
+    hipLaunchKernelGGL(bn_relu_pool_fwd_kernel, dim3(C, S2), dim3(kBlock), 0, as_stream(stream), y, gamma, beta,
+                       mean, invstd, p, N, C, L, Lp, S2);
     return check_launch("bn_relu_pool_fwd_kernel");
 }
 
@@ -395,19 +450,17 @@ static int bn_bwd_impl(const float *y, const float *g, const float *gamma, const
                        float *dbeta, float *ws, int N, int C, int L, int ldy, int train,
                        hipStream_t st, float bcast = 0.f) {
     const int S = stat_splits(N, C);
-    float *partials = ws, *coef = ws + (size_t)C * S * 2;
+    float *partials = ws;
     hipLaunchKernelGGL((bn_bwd_reduce_kernel<FUSED>), dim3(C, S), dim3(kBlock), 0, st, y, g, gamma,
                        beta, mean, invstd, partials, N, C, L, S, bcast);
     int rc = check_launch("bn_bwd_reduce_kernel");
     if (rc) return rc;
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(64), 0, st, partials, S,
-                       (double)N * L, dgamma, dbeta, coef, train);
-    rc = check_launch("bn_bwd_finalize_kernel");
-    if (rc) return rc;
+    // dx pass with the combine of the reduce partials folded in (no finalize launch)
     const int Lh = (ldy + 1) / 2;
-    size_t total = (size_t)N * C * Lh;
-    hipLaunchKernelGGL((bn_bwd_dx_kernel<FUSED>), dim3(cdiv(total, kBlock)), dim3(kBlock), 0, st, y,
-                       g, gamma, beta, mean, invstd, coef, dy, C, L, ldy, Lh, total, bcast);
+    int S2 = cdiv(4096, C);            // ~4096 blocks: enough to keep every CU streaming
+    if (S2 > N) S2 = N;
+    hipLaunchKernelGGL((bn_bwd_dx_kernel<FUSED>), dim3(C, S2), dim3(kBlock), 0, st, y, g, gamma, beta, mean,
+                       invstd, partials, S, (double)N * L, dgamma, dbeta, dy, N, C, L, ldy, Lh, S2, bcast, train);
     return check_launch("bn_bwd_dx_kernel");
 }
 

@@ -104,6 +104,13 @@ __global__ __launch_bounds__(256, 2) void conv1d_mfma_bf16_fwd_kernel(
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
+    // bias of the 16 accumulator rows of each 32-channel group, lane-indexed (lane r + 32*half holds row (r, half)),
+    // loaded before the main loop: a global load between the epilogue's stores would wait for their round trips
+    float p_b[MC];
+#pragma unroll
+    for (int i = 0; i < MC; ++i)
+        p_b[i] = bias ? bias[co0 + wco + 32 * i + acc_row_b(l31 & 15, half)] : 0.f;
+
     // ---- loop-invariant staging geometry ---------------------------------------------------
     // weight piece j of this wave: byte offset inside a chunk [K][Cout][16] bf16 -> (k, co, lane part)
     size_t woff[DPW];
@@ -205,35 +212,56 @@ __global__ __launch_bounds__(256, 2) void conv1d_mfma_bf16_fwd_kernel(
     }
     float *red = reinterpret_cast<float *>(lds);
 
-    // ---- epilogue (identical to the fp32 kernel: the accumulator layout is dtype-independent) ---
+    // ---- epilogue (as the fp32 kernel: the accumulator layout is dtype-independent) ---------------
+    // explicit (free) vmcnt(0): lets the compiler reuse the staging registers without waits between the stores;
+    // no global load and no LDS permute between the stores; per-row sums by DPP over 16-lane rows, kept in lanes
+    // r / r+16 of one register per 32 channels and combined once at the end.
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    auto pick = [&](float v, int r) {
+        const int vi = __float_as_int(v);
+        const float lo = __int_as_float(__builtin_amdgcn_readlane(vi, r));
+        const float hi = __int_as_float(__builtin_amdgcn_readlane(vi, r + 32));
+        return half ? hi : lo;
+    };
+    float st_s[MC], st_q[MC];
+#pragma unroll
+    for (int i = 0; i < MC; ++i) { st_s[i] = 0.f; st_q[i] = 0.f; }
+    float *yw = y + ((size_t)n * Cout + co0 + wco + 4 * half) * Lo + t0 + wt + l31;
 #pragma unroll
     for (int i = 0; i < MC; ++i) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int col = wco + 32 * i + acc_row_b(r, half);
-            const float bv = bias ? bias[co0 + col] : 0.f;
+            const int rowk = 32 * i + (r & 3) + 8 * (r >> 2);
+            const float bv = pick(p_b[i], r);
             float s = 0.f, q = 0.f;
 #pragma unroll
             for (int j = 0; j < MT; ++j) {
-                const int t = t0 + wt + 32 * j + l31;
                 const float v = acc[i][j][r] + bv;
-                if (t < Lo) {
-                    y[((size_t)n * Cout + co0 + col) * Lo + t] = v;
+                if (t0 + wt + 32 * j + l31 < Lo) {
+                    yw[rowk * Lo + 32 * j] = v;
                     if (STATS) { s += v; q = __fmaf_rn(v, v, q); }
                 }
             }
             if (STATS) {
-                s = half32_sum(s);
-                q = half32_sum(q);
-                if (l31 == 0) {
-                    const int lc = 32 * i + acc_row_b(r, half);
-                    red[(wave * (CO_T / WCO) + lc) * 2] = s;
-                    red[(wave * (CO_T / WCO) + lc) * 2 + 1] = q;
-                }
+                const bool mine = (l31 & 15) == r;
+                s = row16_sum(s);
+                q = row16_sum(q);
+                st_s[i] += mine ? s : 0.f;
+                st_q[i] += mine ? q : 0.f;
             }
         }
     }
     if (STATS) {
+#pragma unroll
+        for (int i = 0; i < MC; ++i) {
+            const float s = st_s[i] + __shfl_xor(st_s[i], 16, 64);
+            const float q = st_q[i] + __shfl_xor(st_q[i], 16, 64);
+            if (l31 < 16) {
+                const int lc = 32 * i + acc_row_b(l31, half);
+                red[(wave * (CO_T / WCO) + lc) * 2] = s;
+                red[(wave * (CO_T / WCO) + lc) * 2 + 1] = q;
+            }
+        }
         __syncthreads();
         for (int e = tid; e < CO_T * 2; e += 256) {
             const int col = e >> 1, w = e & 1;

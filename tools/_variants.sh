@@ -1,13 +1,11 @@
 set -o pipefail
 O=gpurun_out
-for v in "ECG_HIP_PRIO=0" "ECG_HIP_PRIO=1" "ECG_HIP_PRIO=2"; do
-  echo "== $v"
-  env $v python tools/stamp_fwd.py 2>&1 | tail -4 | python -c "
-import sys, json
-for l in sys.stdin:
-    d=json.loads(l); print(d['block'], 'span', d['kernel_span_us'], 'end_spread', d['end_spread_us'], 'wg_med', d['wg_total_median_us'], d['median_us'])"
-  env $v python tools/layer_bench.py --tag "$v" 2>/dev/null | grep -v wgrad | python -c "
-import sys, json
-rows=[json.loads(l) for l in sys.stdin if l.startswith('{')]
-print(' '.join(f\"b{r['block']}{r['op'][0]}={r['us']}\" for r in rows if 'op' in r), 'sum', round(sum(r['us'] for r in rows if 'op' in r),1))"
-done
+python -m pytest tests/test_gpu_ops.py tests/test_gpu_model.py -m gpu -x -q > $O/r02d_tests.log 2>&1; echo "tests rc=$?"; tail -3 $O/r02d_tests.log
+python bench.py --steps 30 --warmup 5 --no-cpu-baseline > $O/r02d_bench.json 2>/dev/null
+python - <<'PY'
+import json
+d=json.loads(open('gpurun_out/r02d_bench.json').read().strip().splitlines()[-1])
+def show(x, name): print(name[:70], x['value'], x['ms_per_step'], x['step_ms']['median'], x['instrumented_ms_per_step'])
+show(d, d['config']['workload'])
+for a in d['also']: show(a, a['workload'])
+PY
