@@ -136,6 +136,32 @@ int ecg_conv1d_fwd_bf16(const float *x, const void *wb_fwd, const float *bias, f
                         ecg_stream_t stream);
 int ecg_conv1d_bwd_data_bf16(const float *dy, const void *wb_bwd, float *dx, int N, int C_in,
                              int C_out, int L, int K, int pad, ecg_stream_t stream);
+/* The weight gradient's operand layout, written by the PRODUCERS instead of by packing passes: "n16" = bf16
+ * [sample group of 16][channel][position][16 samples], zero outside the row and past N.
+ *   ecg_conv1d_n16_positions(L, K, pad, which): positions per row of the dY operand (which = 0: PA = Lo rounded up
+ *     to 16) and of the x operand (which = 1: PX = PA + 16; x[.., t] sits at position t + pad, i.e. the conv's zero
+ *     padding is part of the layout).  0 when the shape is not served (K != 15 or pad != 7).
+ *   ecg_pack_n16: fp32 [N][C][ld] -> n16 with P positions, element t at position t + shift (the first layer's input).
+ *   ecg_bn_relu_pool_fwd_n16: ecg_bn_relu_pool_fwd that ALSO writes the pooled activation as the next layer's x
+ *     operand (p may be NULL when only the n16 form is wanted).
+ *   ecg_bn_relu_pool_bwd_n16: ecg_bn_relu_pool_bwd_ld (gap != 0: ..._gap_bwd_ld) that ALSO writes dY as the dY
+ *     operand; dy may be NULL when no input gradient follows (first layer).
+ *   ecg_conv1d_bwd_weight_bias_bf16_packed: the weight gradient on operands already in that layout; workspace
+ *     (slabs only) from ecg_conv1d_bwd_weight_bf16_packed_ws_floats. */
+int ecg_conv1d_n16_positions(int L, int K, int pad, int which);
+int ecg_pack_n16(const float *src, void *dst, int N, int C, int ld, int L, int P, int shift,
+                 ecg_stream_t stream);
+int ecg_bn_relu_pool_fwd_n16(const float *y, const float *gamma, const float *beta, const float *mean,
+                             const float *invstd, float *p, void *p_n16, int N, int C, int L, int PX,
+                             int shift, ecg_stream_t stream);
+int ecg_bn_relu_pool_bwd_n16(const float *y, const float *dp, const float *gamma, const float *beta,
+                             const float *mean, const float *invstd, float *dy, int ldy, void *dy_n16,
+                             int PA, float *dgamma, float *dbeta, float *ws, int N, int C, int L,
+                             int train, int gap, ecg_stream_t stream);
+size_t ecg_conv1d_bwd_weight_bf16_packed_ws_floats(int N, int C_in, int C_out, int L, int K, int pad);
+int ecg_conv1d_bwd_weight_bias_bf16_packed(const void *dy_n16, const void *x_n16, float *dw, float *db,
+                                           float *ws, int N, int C_in, int C_out, int L, int K, int pad,
+                                           ecg_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
  * BatchNorm1d / ReLU / MaxPool1d(2) — ConvBlock.net[1..3]: src/models/ecg_cnn.py:14-16.

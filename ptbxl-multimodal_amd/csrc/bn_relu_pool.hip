@@ -326,6 +326,137 @@ __global__ __launch_bounds__(kBlock) void bn_bwd_dx_kernel(
 }
 
 // ---------------------------------------------------------------------------------------
+// mixed-precision producers: the same two passes, ALSO emitting their result in the layout the bf16
+// weight-gradient kernel consumes (conv1d_wgrad_bf16.hip): bf16 [sample group of 16][channel][position][16 samples]
+// ("n16"), zero-filled outside the row and past N.  That removes the separate fp32 -> n16 packing passes
+// (a read of the fp32 tensor + a write each) from the bf16 train step.
+// thread <-> (group g, channel c, position): 16 samples per thread, 32 contiguous bytes per store, adjacent lanes
+// adjacent positions.
+// ---------------------------------------------------------------------------------------
+typedef unsigned short u16n;
+typedef unsigned u32x4n __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ unsigned pack2n(float lo, float hi) {
+    const u16n a = __builtin_bit_cast(u16n, (__bf16)lo), b = __builtin_bit_cast(u16n, (__bf16)hi);
+    return (unsigned)a | ((unsigned)b << 16);
+}
+__device__ __forceinline__ void store_n16(u16n *dst, const float *v) {
+    u32x4n lo, hi;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        lo[q] = pack2n(v[2 * q], v[2 * q + 1]);
+        hi[q] = pack2n(v[8 + 2 * q], v[8 + 2 * q + 1]);
+    }
+    u32x4n *o = reinterpret_cast<u32x4n *>(dst);
+    o[0] = lo;
+    o[1] = hi;
+}
+
+// p [N][C][Lp] fp32 (may be NULL) and pb[g][c][pos][16] with pb[.., j + shift, s] = p[16g + s][c][j].
+// grid = (ceil(PX/256), C, G)
+__global__ __launch_bounds__(kBlock) void bn_relu_pool_fwd_n16_kernel(
+    const float *__restrict__ y, const float *__restrict__ gamma, const float *__restrict__ beta,
+    const float *__restrict__ mean, const float *__restrict__ invstd, float *__restrict__ p,
+    u16n *__restrict__ pb, int N, int C, int L, int Lp, int PX, int shift) {
+    const int pos = blockIdx.x * kBlock + threadIdx.x, c = blockIdx.y, g = blockIdx.z;
+    if (pos >= PX) return;
+    const float sc = invstd[c] * gamma[c], mu = mean[c], be = beta[c];
+    const int j = pos - shift;
+    const bool in_row = (j >= 0) && (j < Lp);
+    const int jc = min(max(j, 0), Lp - 1);
+    float y0[16], y1[16];
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {                   // 32 unconditional, clamped loads in flight
+        const float *r = y + ((size_t)min(16 * g + s, N - 1) * C + c) * L + 2 * jc;
+        y0[s] = r[0]; y1[s] = r[1];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    float v[16];
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+        const float a0 = bn_apply1(y0[s], mu, sc, be), a1 = bn_apply1(y1[s], mu, sc, be);
+        float m = a1 > a0 ? a1 : a0;
+        m = m > 0.f ? m : 0.f;
+        const bool live = in_row && 16 * g + s < N;
+        v[s] = live ? m : 0.f;
+        if (live && p) p[((size_t)(16 * g + s) * C + c) * Lp + j] = m;
+    }
+    store_n16(pb + (((size_t)g * C + c) * PX + pos) * 16, v);
+}
+
+// dy [N][C][ldy] fp32 (may be NULL: the first layer has no input gradient) and dyb[g][c][t][16], t < PA, zero
+// past the row; the combine of the S reduce partials is folded in as in bn_bwd_dx_kernel.
+// grid = (ceil(PA/2/256), C, G); thread <-> output pair (2j, 2j+1) of the 16 samples of group g.
+__global__ __launch_bounds__(kBlock) void bn_bwd_dx_n16_kernel(
+    const float *__restrict__ y, const float *__restrict__ g_in, const float *__restrict__ gamma,
+    const float *__restrict__ beta, const float *__restrict__ mean, const float *__restrict__ invstd,
+    const float *__restrict__ partials, int S, double M, float *__restrict__ dgamma,
+    float *__restrict__ dbeta, float *__restrict__ dy, int ldy, u16n *__restrict__ dyb, int PA, int N,
+    int C, int L, float bcast, int train) {
+    __shared__ double red[4][2];
+    __shared__ float kk[2];
+    const int c = blockIdx.y, g = blockIdx.z, tl = threadIdx.x;
+    {
+        double a = 0.0, q = 0.0;
+        for (int pp = tl; pp < S; pp += kBlock) {
+            a += (double)partials[((size_t)c * S + pp) * 2];
+            q += (double)partials[((size_t)c * S + pp) * 2 + 1];
+        }
+        a = wave_sum(a); q = wave_sum(q);
+        if ((tl & 63) == 0) { red[tl >> 6][0] = a; red[tl >> 6][1] = q; }
+        __syncthreads();
+        if (tl == 0) {
+            a = ((red[0][0] + red[1][0]) + red[2][0]) + red[3][0];
+            q = ((red[0][1] + red[1][1]) + red[2][1]) + red[3][1];
+            if (blockIdx.x == 0 && g == 0) {
+                if (dbeta) dbeta[c] = (float)a;
+                if (dgamma) dgamma[c] = (float)q;
+            }
+            kk[0] = train ? (float)(a / M) : 0.f;
+            kk[1] = train ? (float)(q / M) : 0.f;
+        }
+        __syncthreads();
+    }
+    const int j = blockIdx.x * kBlock + tl, t0 = 2 * j;
+    if (t0 >= PA) return;
+    const float k1 = kk[0], k2 = kk[1];
+    const float mu = mean[c], is = invstd[c], ga = gamma[c], sc = is * ga, gi = ga * is, be = beta[c];
+    const int Lp = L >> 1;
+    const bool in0 = t0 < L, has1 = t0 + 1 < L;
+    const int ta = min(t0, L - 1), tb = min(t0 + 1, L - 1), jc = min(j, max(Lp - 1, 0));
+    float y0[16], y1[16], d[16];
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {                   // 48 unconditional, clamped loads in flight
+        const size_t row = (size_t)min(16 * g + s, N - 1) * C + c;
+        y0[s] = y[row * L + ta]; y1[s] = y[row * L + tb];
+        d[s] = bcast != 0.f ? g_in[row] * bcast : (Lp > 0 ? g_in[row * Lp + jc] : 0.f);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    float v0[16], v1[16];
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+        const bool valid = 16 * g + s < N;
+        float da0 = 0.f, da1 = 0.f;
+        if (has1) {      // an odd tail sample never reaches the pool: da = 0
+            int am;
+            if (pool_route(y0[s], y1[s], mu, sc, be, am)) {
+                if (am) da1 = d[s]; else da0 = d[s];
+            }
+        }
+        v0[s] = (valid && in0) ? gi * (da0 - k1 - (y0[s] - mu) * is * k2) : 0.f;
+        v1[s] = (valid && has1) ? gi * (da1 - k1 - (y1[s] - mu) * is * k2) : 0.f;
+        if (dy && valid) {
+            float *dr = dy + ((size_t)(16 * g + s) * C + c) * ldy;
+            if (t0 < ldy) dr[t0] = v0[s];
+            if (t0 + 1 < ldy) dr[t0 + 1] = v1[s];
+        }
+    }
+    u16n *o = dyb + (((size_t)g * C + c) * PA + t0) * 16;
+    store_n16(o, v0);
+    store_n16(o + 16, v1);
+}
+
+// ---------------------------------------------------------------------------------------
 // unfused ReLU / MaxPool leaves
 // ---------------------------------------------------------------------------------------
 __global__ void relu_fwd_kernel(const float *__restrict__ x, float *__restrict__ out, size_t n) {
@@ -562,4 +693,46 @@ ECG_API int ecg_bn_relu_pool_gap_bwd(const float *y, const float *dg, const floa
                                      int C, int L, int train, ecg_stream_t stream) {
     return ecg_bn_relu_pool_gap_bwd_ld(y, dg, gamma, beta, mean, invstd, dy, L, dgamma, dbeta, ws, N, C,
                                        L, train, stream);
+}
+
+// ---- mixed-precision producers (see the kernels above) -------------------------------------------------
+ECG_API int ecg_bn_relu_pool_fwd_n16(const float *y, const float *gamma, const float *beta, const float *mean,
+                                     const float *invstd, float *p, void *p_n16, int N, int C, int L, int PX,
+                                     int shift, ecg_stream_t stream) {
+    int rc = check_ncl("bn_relu_pool_fwd_n16", N, C, L);
+    if (rc) return rc;
+    ECG_REQUIRE(y && gamma && beta && mean && invstd && p_n16, "bn_relu_pool_fwd_n16: null pointer");
+    const int Lp = L / 2;
+    ECG_REQUIRE(Lp >= 1 && shift >= 0 && PX >= shift + Lp, "bn_relu_pool_fwd_n16: PX=%d cannot hold %d positions at shift %d",
+                PX, Lp, shift);
+    ECG_REQUIRE((reinterpret_cast<uintptr_t>(p_n16) & 15) == 0, "bn_relu_pool_fwd_n16: n16 output must be 16-byte aligned");
+    const int G = cdiv(N, 16);
+    hipLaunchKernelGGL(bn_relu_pool_fwd_n16_kernel, dim3(cdiv(PX, kBlock), C, G), dim3(kBlock), 0, as_stream(stream),
+                       y, gamma, beta, mean, invstd, p, static_cast<u16n *>(p_n16), N, C, L, Lp, PX, shift);
+    return check_launch("bn_relu_pool_fwd_n16_kernel");
+}
+
+ECG_API int ecg_bn_relu_pool_bwd_n16(const float *y, const float *dp, const float *gamma, const float *beta,
+                                     const float *mean, const float *invstd, float *dy, int ldy, void *dy_n16,
+                                     int PA, float *dgamma, float *dbeta, float *ws, int N, int C, int L,
+                                     int train, int gap, ecg_stream_t stream) {
+    int rc = check_ncl("bn_relu_pool_bwd_n16", N, C, L);
+    if (rc) return rc;
+    ECG_REQUIRE(y && dp && gamma && beta && mean && invstd && dy_n16 && ws, "bn_relu_pool_bwd_n16: null pointer");
+    ECG_REQUIRE(L >= 2, "bn_relu_pool_bwd_n16: L=%d leaves an empty pooled row", L);
+    ECG_REQUIRE(PA >= L && PA % 2 == 0, "bn_relu_pool_bwd_n16: PA=%d must be even and >= L=%d", PA, L);
+    ECG_REQUIRE(!dy || (ldy >= L && ldy <= PA), "bn_relu_pool_bwd_n16: dY row stride %d outside [L, PA]", ldy);
+    ECG_REQUIRE((reinterpret_cast<uintptr_t>(dy_n16) & 15) == 0, "bn_relu_pool_bwd_n16: n16 output must be 16-byte aligned");
+    const float bcast = gap ? 1.0f / (float)(L / 2) : 0.f;
+    const int S = stat_splits(N, C);
+    hipStream_t st = as_stream(stream);
+    hipLaunchKernelGGL((bn_bwd_reduce_kernel<true>), dim3(C, S), dim3(kBlock), 0, st, y, dp, gamma, beta, mean,
+                       invstd, ws, N, C, L, S, bcast);
+    rc = check_launch("bn_bwd_reduce_kernel");
+    if (rc) return rc;
+    const int G = cdiv(N, 16);
+    hipLaunchKernelGGL(bn_bwd_dx_n16_kernel, dim3(cdiv(PA / 2, kBlock), C, G), dim3(kBlock), 0, st, y, dp, gamma, beta,
+                       mean, invstd, ws, S, (double)N * L, dgamma, dbeta, dy, ldy, static_cast<u16n *>(dy_n16), PA, N,
+                       C, L, bcast, train);
+    return check_launch("bn_bwd_dx_n16_kernel");
 }

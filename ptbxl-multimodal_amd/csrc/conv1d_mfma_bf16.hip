@@ -53,29 +53,42 @@ __global__ void pack_weights_bf16_kernel(const float *__restrict__ w, u16 *__res
     }
 }
 
-// grid = (ceil(Lo/T_T), Cout/CO_T, N); 256 threads = 4 waves laid out WCO x WT.
+// grid = ceil(Lo/T_T) * Cout/CO_T * N workgroups (XCD-chunked order); WCO x WT waves (4 or 8) per workgroup.
+//
+// With bf16 operands an MFMA is 16x faster than the fp32 one but a weight chunk is only 2x smaller, so the operand
+// STREAMS bound this kernel, not the matrix pipe:
+//   * weight chunk [15][CO_T][16] bf16 per (workgroup, 16 input channels): L2 -> LDS by DMA.  A 64 x 128 tile needs
+//     ~31 B/clk/CU of it with four workgroups per CU — the L2 -> LDS rate a CU sustains (~30 B/clk).  Tiles are
+//     therefore as large as the layer allows: 128 x 256 (eight waves, one workgroup per CU) re-streams 4x fewer
+//     weight bytes per MFMA, 64 x 256 2x fewer.
+//   * LDS reads: one 16-byte fragment per lane feeds MC*MT MFMAs per MC+MT reads; MC = MT = 2 needs 128 B/clk/CU
+//     (half the LDS peak), the old MC = 1, MT = 2 needed 192.
 template <int CO_T, int T_T, int WCO, int WT, bool STATS>
-__global__ __launch_bounds__(256, 2) void conv1d_mfma_bf16_fwd_kernel(
+__global__ __launch_bounds__(64 * WCO * WT) void conv1d_mfma_bf16_fwd_kernel(
     const float *__restrict__ x, const u16 *__restrict__ wb, const float *__restrict__ bias,
     float *__restrict__ y, float *__restrict__ partials, int Cin, int Cout, int L, int Lo, int pad,
     int P, int tiles_t) {
-    static_assert(WCO * WT == 4, "4 waves per workgroup");
+    constexpr int NW = WCO * WT, NT = 64 * NW;
+    static_assert(NW == 4 || NW == 8, "4 or 8 waves per workgroup");
     constexpr int KK = kKB;
     constexpr int MC = CO_T / WCO / 32, MT = T_T / WT / 32;
     static_assert(MC >= 1 && MT >= 1, "wave tile must hold at least one 32x32 accumulator");
     constexpr int SPAN = T_T + KK - 1;                   // x-tile positions
     constexpr int WBYTES = KK * CO_T * kCB * 2;          // bytes of one weight chunk [K][CO_T][16] bf16
     constexpr int NDMA = (WBYTES + 1023) / 1024;         // 1 KB wave-instructions per chunk
-    constexpr int WPADB = NDMA * 1024;
-    constexpr int DPW = (NDMA + 3) / 4;
-    constexpr int XBYTES = SPAN * kCB * 2;
-    constexpr int IMGB = WPADB + ((XBYTES + 15) / 16) * 16;
+    constexpr int DPW = (NDMA + NW - 1) / NW;
+    constexpr int WPADB = NDMA * 1024;                   // every wave issues DPW pieces unconditionally: pieces past the
+                                                         // slice repeat its last piece (same bytes, same place)
     constexpr int XITEMS = SPAN * 4;                     // (pos, quarter of 4 channels)
-    constexpr int XL = (XITEMS + 255) / 256;
+    constexpr int XL = (XITEMS + NT - 1) / NT;
+    constexpr int XBYTES = ((SPAN * kCB * 2 + 8 + 15) / 16) * 16;   // every thread commits XL items unconditionally: items
+                                                         // past the tile all land in one dummy slot behind it
+    constexpr int IMGB = WPADB + XBYTES;
     constexpr int NOPS = XL + DPW + XL;                  // commits, DMA pieces, loads
-    static_assert(NOPS <= KK, "not enough steps to spread the staging over");
-    constexpr int REDB = STATS ? 4 * (CO_T / WCO) * 2 * 4 : 0;
+    constexpr int OPS = (NOPS + KK - 1) / KK;            // staging operations per tap step
+    constexpr int REDB = STATS ? NW * (CO_T / WCO) * 2 * 4 : 0;
     static_assert(REDB <= IMGB, "stat scratch aliases image 0");
+    static_assert(2 * IMGB <= 160 * 1024, "LDS");
 
     __shared__ __attribute__((aligned(1024))) unsigned char lds[2 * IMGB];
 
@@ -112,24 +125,28 @@ __global__ __launch_bounds__(256, 2) void conv1d_mfma_bf16_fwd_kernel(
         p_b[i] = bias ? bias[co0 + wco + 32 * i + acc_row_b(l31 & 15, half)] : 0.f;
 
     // ---- loop-invariant staging geometry ---------------------------------------------------
-    // weight piece j of this wave: byte offset inside a chunk [K][Cout][16] bf16 -> (k, co, lane part)
+    // weight piece j of this wave: byte offset inside a chunk [K][Cout][16] bf16 -> (k, co, lane part); pieces past
+    // the slice re-read its last 16 bytes into the padding of the image
     size_t woff[DPW];
 #pragma unroll
     for (int j = 0; j < DPW; ++j) {
-        const int e = min(((j * 4 + wave) * 64 + lane) * 16, WBYTES - 16);   // byte in the LDS image
+        const int e = min((min(j * NW + wave, NDMA - 1) * 64 + lane) * 16, WBYTES - 16);   // byte in the LDS image
         const int k = e / (CO_T * kCB * 2), rem = e - k * (CO_T * kCB * 2);  // rem = co_local*32 + part
         woff[j] = ((size_t)k * Cout + co0) * kCB * 2 + rem;                   // byte offset in the global chunk
     }
-    int xpos[XL], xq[XL], xsrc[XL];
+    int xdst[XL], xq[XL], xsrc[XL];
     unsigned xin = 0;                 // bit j: position inside the sequence
 #pragma unroll
     for (int j = 0; j < XL; ++j) {
-        const int it = min(tid + 256 * j, XITEMS - 1);
-        xq[j] = it / SPAN;
-        xpos[j] = it - xq[j] * SPAN;
-        const int s = t0 - pad + xpos[j];
+        const int it = tid + NT * j;
+        const int itc = min(it, XITEMS - 1);
+        xq[j] = itc / SPAN;
+        const int pos = itc - xq[j] * SPAN;
+        const int s = t0 - pad + pos;
         xsrc[j] = min(max(s, 0), L - 1);
         xin |= ((s >= 0) && (s < L)) ? (1u << j) : 0u;
+        // items past the tile land in the padding behind it (byte offset inside the x region)
+        xdst[j] = it < XITEMS ? (pos * kCB + 4 * xq[j]) * 2 : SPAN * kCB * 2;
     }
     float xreg[XL][4];
     unsigned xok = 0;                 // bit j: item j of the chunk in registers is real data
@@ -137,10 +154,9 @@ __global__ __launch_bounds__(256, 2) void conv1d_mfma_bf16_fwd_kernel(
     const unsigned char *wbase = reinterpret_cast<const unsigned char *>(wb);
     const size_t chunk_bytes = (size_t)KK * Cout * kCB * 2;
     auto dma_w = [&](int j, int c, unsigned char *img) {
-        if ((j * 4 + wave) < NDMA)
-            __builtin_amdgcn_global_load_lds(
-                (const __attribute__((address_space(1))) void *)(wbase + (size_t)c * chunk_bytes + woff[j]),
-                (__attribute__((address_space(3))) void *)(img + (j * 4 + wave) * 1024), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds(
+            (const __attribute__((address_space(1))) void *)(wbase + (size_t)c * chunk_bytes + woff[j]),
+            (__attribute__((address_space(3))) void *)(img + min(j * NW + wave, NDMA - 1) * 1024), 16, 0, 0);
     };
     auto load_x = [&](int j, int c) {
         const int ci = c * kCB + 4 * xq[j];
@@ -154,27 +170,25 @@ __global__ __launch_bounds__(256, 2) void conv1d_mfma_bf16_fwd_kernel(
         const unsigned keep = 0u - ((xok >> j) & 1u);
         const unsigned lo = pack2_bf16(xreg[j][0], xreg[j][1]) & keep;
         const unsigned hi = pack2_bf16(xreg[j][2], xreg[j][3]) & keep;
-        if (256 * (j + 1) <= XITEMS || tid + 256 * j < XITEMS)
-            *reinterpret_cast<uint2 *>(img + WPADB + (xpos[j] * kCB + 4 * xq[j]) * 2) = make_uint2(lo, hi);
+        *reinterpret_cast<uint2 *>(img + WPADB + xdst[j]) = make_uint2(lo, hi);
     };
 
-    // prologue: chunk 0 -> image 0; x of chunk 1 -> registers
+    // prologue: chunk 0 -> image 0; x of chunk 1 -> registers (clamped to the last chunk: the loop below stages
+    // unconditionally, the stages past the end re-stage valid data nobody reads)
 #pragma unroll
     for (int j = 0; j < DPW; ++j) dma_w(j, 0, lds);
 #pragma unroll
     for (int j = 0; j < XL; ++j) load_x(j, 0);
 #pragma unroll
     for (int j = 0; j < XL; ++j) commit_x(j, lds);
-    if (nchunks > 1) {
 #pragma unroll
-        for (int j = 0; j < XL; ++j) load_x(j, 1);
-    }
+    for (int j = 0; j < XL; ++j) load_x(j, min(1, nchunks - 1));
     __syncthreads();
 
     for (int c = 0; c < nchunks; ++c) {
         const unsigned char *ws = lds + (c & 1) * IMGB, *xs = ws + WPADB;
         unsigned char *nxt = lds + ((c + 1) & 1) * IMGB;
-        const bool do_next = c + 1 < nchunks, do_next2 = c + 2 < nchunks;
+        const int c1 = min(c + 1, nchunks - 1), c2 = min(c + 2, nchunks - 1);
 
         auto ld = [&](int k, bf16x8 *a, bf16x8 *b) {
 #pragma unroll
@@ -189,12 +203,11 @@ __global__ __launch_bounds__(256, 2) void conv1d_mfma_bf16_fwd_kernel(
 #pragma unroll
         for (int k = 0; k < KK; ++k) {
             ld(k + 1 < KK ? k + 1 : 0, a_n, b_n);
-            if (k < XL) {
-                if (do_next) commit_x(k, nxt);
-            } else if (k < XL + DPW) {
-                if (do_next) dma_w(k - XL, c + 1, nxt);
-            } else if (k < 2 * XL + DPW) {
-                if (do_next2) load_x(k - XL - DPW, c + 2);
+#pragma unroll
+            for (int o = k * OPS; o < (k + 1) * OPS; ++o) {      // commits, then weight DMA pieces, then x loads
+                if (o < XL) commit_x(o, nxt);
+                else if (o < XL + DPW) dma_w(o - XL, c1, nxt);
+                else if (o < NOPS) load_x(o - XL - DPW, c2);
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -263,7 +276,7 @@ __global__ __launch_bounds__(256, 2) void conv1d_mfma_bf16_fwd_kernel(
             }
         }
         __syncthreads();
-        for (int e = tid; e < CO_T * 2; e += 256) {
+        for (int e = tid; e < CO_T * 2; e += NT) {
             const int col = e >> 1, w = e & 1;
             const int wrow = col / (CO_T / WCO), lc = col - wrow * (CO_T / WCO);
             float s = 0.f;
@@ -280,9 +293,17 @@ bool bf16_fwd_supported(int Cin, int Cout, int K, int pad) {
     return K == kKB && Cin % 4 == 0 && Cout % 32 == 0;
 }
 
-static int bf16_tile_t(int Cout) { return Cout % 64 == 0 ? 128 : 256; }
+// Tile choice: the largest C_out tile the layer has, 256 time steps when the row is long enough to fill them
+// (at 12x1000 the last block's rows are 125 long: a 256-wide tile would idle half its lanes).
+struct Bf16Cfg { int co_t, t_t; };
+static Bf16Cfg bf16_cfg(int Cout, int Lo) {
+    const bool wide = Lo > 160;
+    if (Cout % 128 == 0 && wide) return {128, 256};
+    if (Cout % 64 == 0) return {64, wide ? 256 : 128};
+    return {32, 256};
+}
 
-int bf16_fwd_stat_partials(int N, int Cout, int Lo) { return N * cdiv(Lo, bf16_tile_t(Cout)); }
+int bf16_fwd_stat_partials(int N, int Cout, int Lo) { return N * cdiv(Lo, bf16_cfg(Cout, Lo).t_t); }
 
 size_t bf16_packed_elems(int Cred, int Cout, int K) {       // reduction channels padded to 16
     return (size_t)((Cred + kCB - 1) / kCB) * K * Cout * kCB;
@@ -292,7 +313,7 @@ template <int CO_T, int T_T, int WCO, int WT>
 static void launch_bf16(const float *x, const u16 *wb, const float *bias, float *y, float *partials,
                         int N, int Cin, int Cout, int L, int Lo, int pad, hipStream_t st) {
     const int tiles_t = cdiv(Lo, T_T);
-    dim3 grid((unsigned)((size_t)tiles_t * (Cout / CO_T) * N)), block(256);
+    dim3 grid((unsigned)((size_t)tiles_t * (Cout / CO_T) * N)), block(64 * WCO * WT);
     const int P = N * tiles_t;
     if (partials)
         hipLaunchKernelGGL((conv1d_mfma_bf16_fwd_kernel<CO_T, T_T, WCO, WT, true>), grid, block, 0, st,
@@ -306,10 +327,11 @@ int bf16_fwd(const float *x, const void *wb, const float *bias, float *y, float 
              int Cin, int Cout, int L, int K, int pad, hipStream_t st) {
     const int Lo = L + 2 * pad - K + 1;
     const u16 *w = static_cast<const u16 *>(wb);
-    if (Cout % 64 == 0)
-        launch_bf16<64, 128, 2, 2>(x, w, bias, y, partials, N, Cin, Cout, L, Lo, pad, st);
-    else
-        launch_bf16<32, 256, 1, 4>(x, w, bias, y, partials, N, Cin, Cout, L, Lo, pad, st);
+    const Bf16Cfg c = bf16_cfg(Cout, Lo);
+    if (c.co_t == 128) launch_bf16<128, 256, 2, 4>(x, w, bias, y, partials, N, Cin, Cout, L, Lo, pad, st);
+    else if (c.co_t == 64 && c.t_t == 256) launch_bf16<64, 256, 1, 4>(x, w, bias, y, partials, N, Cin, Cout, L, Lo, pad, st);
+    else if (c.co_t == 64) launch_bf16<64, 128, 2, 2>(x, w, bias, y, partials, N, Cin, Cout, L, Lo, pad, st);
+    else launch_bf16<32, 256, 1, 4>(x, w, bias, y, partials, N, Cin, Cout, L, Lo, pad, st);
     return check_launch("conv1d_mfma_bf16_fwd_kernel");
 }
 
@@ -337,6 +359,11 @@ bool wgrad_bf16_supported(int Cin, int Cout, int K, int pad);
 size_t wgrad_bf16_ws_floats(int N, int Cin, int Cout, int L, int K, int pad);
 int wgrad_bf16(const float *dy, int ldy, const float *x, float *dw, float *db, float *ws, int N, int Cin,
                int Cout, int L, int K, int pad, hipStream_t st);
+void wgrad_bf16_positions(int L, int K, int pad, int *PA, int *PX);
+size_t wgrad_bf16_packed_ws_floats(int N, int Cin, int Cout, int L, int K, int pad);
+int wgrad_bf16_packed(const void *dyb, const void *xb, float *dw, float *db, float *ws, int N, int Cin, int Cout,
+                      int L, int K, int pad, hipStream_t st);
+int pack_n16(const float *src, void *dst, int N, int C, int ld, int Lsrc, int P, int shift, hipStream_t st);
 }  // namespace ecg
 
 ECG_API int ecg_conv1d_bf16_supported(int C_in, int C_out, int K, int pad) {
@@ -363,6 +390,39 @@ ECG_API int ecg_conv1d_bwd_weight_bias_bf16(const float *dy, int ldy, const floa
     ECG_REQUIRE(ldy >= L + 2 * pad - K + 1, "conv1d_bwd_weight_bias_bf16: dY row stride %d too small", ldy);
     ECG_REQUIRE((reinterpret_cast<uintptr_t>(ws) & 15) == 0, "conv1d_bwd_weight_bias_bf16: workspace must be 16-byte aligned");
     return wgrad_bf16(dy, ldy, x, dw, db, ws, N, C_in, C_out, L, K, pad, as_stream(stream));
+}
+
+ECG_API int ecg_conv1d_n16_positions(int L, int K, int pad, int which) {
+    if (K != kKB || pad != kKB / 2 || L + 2 * pad - K + 1 <= 0) return 0;
+    int PA = 0, PX = 0;
+    wgrad_bf16_positions(L, K, pad, &PA, &PX);
+    return which ? PX : PA;
+}
+
+ECG_API int ecg_pack_n16(const float *src, void *dst, int N, int C, int ld, int L, int P, int shift,
+                         ecg_stream_t stream) {
+    ECG_REQUIRE(src && dst && N > 0 && N <= 16 * 65535 && C > 0 && C <= 65535 && L > 0 && ld >= L && P > 0 && shift >= 0,
+                "pack_n16: bad argument");
+    ECG_REQUIRE((reinterpret_cast<uintptr_t>(dst) & 15) == 0, "pack_n16: destination must be 16-byte aligned");
+    return pack_n16(src, dst, N, C, ld, L, P, shift, as_stream(stream));
+}
+
+ECG_API size_t ecg_conv1d_bwd_weight_bf16_packed_ws_floats(int N, int C_in, int C_out, int L, int K, int pad) {
+    if (!wgrad_bf16_supported(C_in, C_out, K, pad) || N <= 0 || L + 2 * pad - K + 1 <= 0) return 0;
+    return wgrad_bf16_packed_ws_floats(N, C_in, C_out, L, K, pad);
+}
+
+ECG_API int ecg_conv1d_bwd_weight_bias_bf16_packed(const void *dy_n16, const void *x_n16, float *dw, float *db,
+                                                   float *ws, int N, int C_in, int C_out, int L, int K, int pad,
+                                                   ecg_stream_t stream) {
+    int rc = check_bf16_shape("conv1d_bwd_weight_bias_bf16_packed", N, C_in, C_out, L, K, pad);
+    if (rc) return rc;
+    ECG_REQUIRE(dy_n16 && x_n16 && dw && ws, "conv1d_bwd_weight_bias_bf16_packed: null pointer");
+    ECG_REQUIRE(wgrad_bf16_supported(C_in, C_out, K, pad),
+                "conv1d_bwd_weight_bias_bf16_packed: needs K == 15, pad == 7, C_out %% 32 == 0");
+    ECG_REQUIRE(((reinterpret_cast<uintptr_t>(dy_n16) | reinterpret_cast<uintptr_t>(x_n16)) & 15) == 0,
+                "conv1d_bwd_weight_bias_bf16_packed: operands must be 16-byte aligned");
+    return wgrad_bf16_packed(dy_n16, x_n16, dw, db, ws, N, C_in, C_out, L, K, pad, as_stream(stream));
 }
 
 ECG_API size_t ecg_conv1d_bf16_packed_elems(int C_reduce, int C_result, int K) {

@@ -262,6 +262,25 @@ size_t wgrad_bf16_ws_floats(int N, int Cin, int Cout, int L, int K, int pad) {
     return p.slab_floats + (p.dyb_elems + p.xb_elems + 1) / 2 + 16;
 }
 
+// the MFMA kernel + the slab reduce on operands that are already in the n16 layout
+static int wgrad_bf16_run(const u16 *dyb, const u16 *xb, float *dw, float *db, float *slab, const WgBf16Plan &p,
+                          int Cin, int Cout, int K, hipStream_t st) {
+    const int R = Cin * K;
+    dim3 block(256);
+    if (Cout % 64 == 0) {
+        dim3 grid((unsigned)(cdiv(R, 128) * (Cout / 64) * p.splits));
+        hipLaunchKernelGGL((conv1d_wgrad_bf16_kernel<64, 128, 2, 2>), grid, block, 0, st, dyb, xb, slab, p.G, Cin,
+                           Cout, p.PA, p.PX, p.ntt, p.splits);
+    } else {                               // C_out = 32 (block 0): one 32-channel row of wide column tiles
+        dim3 grid((unsigned)(cdiv(R, 256) * (Cout / 32) * p.splits));
+        hipLaunchKernelGGL((conv1d_wgrad_bf16_kernel<32, 256, 1, 4>), grid, block, 0, st, dyb, xb, slab, p.G, Cin,
+                           Cout, p.PA, p.PX, p.ntt, p.splits);
+    }
+    int rc = check_launch("conv1d_wgrad_bf16_kernel");
+    if (rc) return rc;
+    return wgrad_reduce(slab, dw, db, (size_t)Cout * R, Cout, p.splits, st);
+}
+
 int wgrad_bf16(const float *dy, int ldy, const float *x, float *dw, float *db, float *ws, int N, int Cin,
                int Cout, int L, int K, int pad, hipStream_t st) {
     const int Lo = L + 2 * pad - K + 1;
@@ -275,20 +294,29 @@ int wgrad_bf16(const float *dy, int ldy, const float *x, float *dw, float *db, f
                        p.PX, pad);
     int rc = check_launch("pack_n16_kernel");
     if (rc) return rc;
-    const int R = Cin * K;
-    dim3 block(256);
-    if (Cout % 64 == 0) {
-        dim3 grid((unsigned)(cdiv(R, 128) * (Cout / 64) * p.splits));
-        hipLaunchKernelGGL((conv1d_wgrad_bf16_kernel<64, 128, 2, 2>), grid, block, 0, st, dyb, xb, slab, p.G, Cin,
-                           Cout, p.PA, p.PX, p.ntt, p.splits);
-    } else {                               // C_out = 32 (block 0): one 32-channel row of wide column tiles
-        dim3 grid((unsigned)(cdiv(R, 256) * (Cout / 32) * p.splits));
-        hipLaunchKernelGGL((conv1d_wgrad_bf16_kernel<32, 256, 1, 4>), grid, block, 0, st, dyb, xb, slab, p.G, Cin,
-                           Cout, p.PA, p.PX, p.ntt, p.splits);
-    }
-    rc = check_launch("conv1d_wgrad_bf16_kernel");
-    if (rc) return rc;
-    return wgrad_reduce(slab, dw, db, (size_t)Cout * R, Cout, p.splits, st);
+    return wgrad_bf16_run(dyb, xb, dw, db, slab, p, Cin, Cout, K, st);
+}
+
+// n16 geometry of a layer, for producers that write the operands in that layout themselves
+void wgrad_bf16_positions(int L, int K, int pad, int *PA, int *PX) {
+    const WgBf16Plan p = wgrad_bf16_plan(16, 4, 32, L + 2 * pad - K + 1);
+    *PA = p.PA; *PX = p.PX;
+}
+
+size_t wgrad_bf16_packed_ws_floats(int N, int Cin, int Cout, int L, int K, int pad) {
+    return wgrad_bf16_plan(N, Cin, Cout, L + 2 * pad - K + 1).slab_floats + 16;
+}
+
+int wgrad_bf16_packed(const void *dyb, const void *xb, float *dw, float *db, float *ws, int N, int Cin, int Cout,
+                      int L, int K, int pad, hipStream_t st) {
+    const WgBf16Plan p = wgrad_bf16_plan(N, Cin, Cout, L + 2 * pad - K + 1);
+    return wgrad_bf16_run(static_cast<const u16 *>(dyb), static_cast<const u16 *>(xb), dw, db, ws, p, Cin, Cout, K, st);
+}
+
+int pack_n16(const float *src, void *dst, int N, int C, int ld, int Lsrc, int P, int shift, hipStream_t st) {
+    hipLaunchKernelGGL(pack_n16_kernel, dim3(cdiv(P, 256), C, cdiv(N, 16)), dim3(256), 0, st, src,
+                       static_cast<u16 *>(dst), N, C, ld, Lsrc, P, shift);
+    return check_launch("pack_n16_kernel");
 }
 
 }  // namespace ecg

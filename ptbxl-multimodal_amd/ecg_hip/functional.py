@@ -325,7 +325,11 @@ class ConvBlockFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, w, b, gamma, beta, running_mean, running_var, nbt, training, momentum,
-                eps, pad, gap=False, packed=None, grad_enabled=True):
+                eps, pad, gap=False, packed=None, grad_enabled=True, x_n16=None, next_geom=None):
+        """Returns (p, p_n16).  p_n16 is None except in bf16 mode when `next_geom` = (K, pad) of the conv that
+        consumes p is given: then the BN+ReLU+pool pass also writes p in the bf16 "n16" layout that conv's weight
+        gradient reads (no packing pass later).  `x_n16` is this block's own input in that layout (from the
+        previous block), kept for backward."""
         x, w = _contig(x), _contig(w)
         Co, _, K = w.shape
         use_batch = training or running_mean is None
@@ -351,13 +355,13 @@ class ConvBlockFn(torch.autograd.Function):
                 _call("ecg_conv1d_bn_relu_pool_eval_fwd", _f32(x), _f32(w_fwd), _f32(b), _f32(gamma),
                       _f32(beta), _f32(running_mean), _f32(running_var), float(eps), _f32(p),
                       N, Ci, Co, Lin, K, pad, _st())
-                return p
+                return p, None
             if gap and _query("ecg_conv1d_bn_relu_pool_gap_eval_supported", Ci, Co, Lin, K, pad):
                 g = _empty(x, N, Co)
                 _call("ecg_conv1d_bn_relu_pool_gap_eval_fwd", _f32(x), _f32(w_fwd), _f32(b), _f32(gamma),
                       _f32(beta), _f32(running_mean), _f32(running_var), float(eps), _f32(g),
                       N, Ci, Co, Lin, K, pad, _st())
-                return g
+                return g, None
         if bf16:
             y, partials, P = conv1d_forward_bf16_raw(x, w_fwd, b, Co, K, pad, want_stats=use_batch)
         else:
@@ -368,39 +372,80 @@ class ConvBlockFn(torch.autograd.Function):
         else:
             mean, invstd = bn_eval_stats(running_mean, running_var, eps)
         N, _, Lo = y.shape
+        p_n16 = None
         if gap:      # last block: AdaptiveAvgPool1d(1) folded in, the pooled tensor never exists
             p = _empty(x, N, Co)
             _call("ecg_bn_relu_pool_gap_fwd", _f32(y), _f32(gamma), _f32(beta), _f32(mean),
                   _f32(invstd), _f32(p), N, Co, Lo, _st())
         else:
             p = _empty(x, N, Co, Lo // 2)
-            _call("ecg_bn_relu_pool_fwd", _f32(y), _f32(gamma), _f32(beta), _f32(mean), _f32(invstd),
-                  _f32(p), N, Co, Lo, _st())
+            PX = 0
+            if bf16 and need_grad and next_geom is not None and Lo >= 2:
+                PX = _query("ecg_conv1d_n16_positions", Lo // 2, next_geom[0], next_geom[1], 1)
+            if PX:       # mixed precision: p also as the next conv's weight-gradient operand (bf16, n16 layout)
+                p_n16 = torch.empty(((N + 15) // 16) * Co * PX * 16, dtype=torch.bfloat16, device=x.device)
+                _call("ecg_bn_relu_pool_fwd_n16", _f32(y), _f32(gamma), _f32(beta), _f32(mean), _f32(invstd),
+                      _f32(p), L.ptr(p_n16), N, Co, Lo, PX, next_geom[1], _st())
+                ctx.mark_non_differentiable(p_n16)
+                ctx.set_materialize_grads(False)     # no zero-filled "gradient" for the n16 by-product (41 MB fill)
+            else:
+                _call("ecg_bn_relu_pool_fwd", _f32(y), _f32(gamma), _f32(beta), _f32(mean), _f32(invstd),
+                      _f32(p), N, Co, Lo, _st())
         ctx.save_for_backward(x, w, y, gamma, beta, mean, invstd)
         ctx.w_bwd, ctx.pad, ctx.batch_stats, ctx.gap = w_bwd, pad, use_batch, gap
         ctx.sink_keys = (_key(w), _key(b), _key(gamma), _key(beta))
-        return p
+        ctx.x_n16 = x_n16 if bf16 else None
+        return p, p_n16
 
     @staticmethod
-    def backward(ctx, dp):
+    def backward(ctx, dp, _dp_n16=None):
         x, w, y, gamma, beta, mean, invstd = ctx.saved_tensors
+        if dp is None:          # (only possible with set_materialize_grads(False): p unused downstream)
+            dp = torch.zeros(y.shape[0], y.shape[1], *(() if ctx.gap else (y.shape[2] // 2,)), device=y.device)
         dp = _contig(dp)
         N, Co, Lo = y.shape
-        # dY never leaves this function: give it the row stride the conv gradients stream best
-        # (rows padded to 64 floats, zero pad -> LDS-DMA in the weight gradient)
+        Ci, Lin, K = x.shape[1], x.shape[2], w.shape[2]
         need_dx = ctx.needs_input_grad[0]
-        ldy = Lo if (ctx.bf16 and need_dx) else _query("ecg_conv1d_dy_row_stride", N, x.shape[1], Co,
-                                                       x.shape[2], w.shape[2], ctx.pad, int(bool(need_dx)))
-        dy = _empty(y, N, Co, ldy)
         kw, kb, kg, kbe = ctx.sink_keys
         dgamma, dbeta = _grad_out(kg, y, Co), _grad_out(kbe, y, Co)
         ws = _empty(y, _query("ecg_bn_relu_pool_bwd_ws_floats", N, Co, Lo))
+        nones = (None,) * 12
+        PA = _query("ecg_conv1d_n16_positions", Lin, K, ctx.pad, 0) if ctx.bf16 else 0
+        if PA and Lo >= 2 and (_query("ecg_conv1d_bf16_supported", Ci, Co, K, ctx.pad) & 4):
+            # mixed precision: the BatchNorm backward writes dY straight in the weight gradient's operand layout
+            # (bf16 n16) — and in fp32 only when an input gradient follows; x is already there from the forward
+            # pass of the previous block (or packed here for the first block)
+            G = (N + 15) // 16
+            dy = _empty(y, N, Co, Lo) if need_dx else None
+            dyb = torch.empty(G * Co * PA * 16, dtype=torch.bfloat16, device=y.device)
+            _call("ecg_bn_relu_pool_bwd_n16", _f32(y), _f32(dp), _f32(gamma), _f32(beta), _f32(mean), _f32(invstd),
+                  _f32(dy), Lo, L.ptr(dyb), PA, _f32(dgamma), _f32(dbeta), _f32(ws), N, Co, Lo,
+                  1 if ctx.batch_stats else 0, 1 if ctx.gap else 0, _st())
+            xb = ctx.x_n16
+            PX = _query("ecg_conv1d_n16_positions", Lin, K, ctx.pad, 1)
+            if xb is None or xb.numel() != G * Ci * PX * 16:
+                xb = torch.empty(G * Ci * PX * 16, dtype=torch.bfloat16, device=y.device)
+                _call("ecg_pack_n16", _f32(x), L.ptr(xb), N, Ci, Lin, Lin, PX, ctx.pad, _st())
+            dw, db = _grad_out(kw, x, Co, Ci, K), _grad_out(kb, x, Co)
+            ws2 = _empty(x, max(1, _query("ecg_conv1d_bwd_weight_bf16_packed_ws_floats", N, Ci, Co, Lin, K, ctx.pad)))
+            _call("ecg_conv1d_bwd_weight_bias_bf16_packed", L.ptr(dyb), L.ptr(xb), _f32(dw), _f32(db), _f32(ws2),
+                  N, Ci, Co, Lin, K, ctx.pad, _st())
+            dx = None
+            if need_dx:
+                dx = torch.empty_like(x)
+                _call("ecg_conv1d_bwd_data_bf16", _f32(dy), L.ptr(ctx.w_bwd), _f32(dx), N, Ci, Co, Lin, K, ctx.pad, _st())
+            return (dx, dw, db, dgamma, dbeta) + nones
+        # dY never leaves this function: give it the row stride the conv gradients stream best
+        # (rows padded to 64 floats, zero pad -> LDS-DMA in the weight gradient)
+        ldy = Lo if (ctx.bf16 and need_dx) else _query("ecg_conv1d_dy_row_stride", N, Ci, Co, Lin, K, ctx.pad,
+                                                       int(bool(need_dx)))
+        dy = _empty(y, N, Co, ldy)
         _call("ecg_bn_relu_pool_gap_bwd_ld" if ctx.gap else "ecg_bn_relu_pool_bwd_ld", _f32(y), _f32(dp),
               _f32(gamma), _f32(beta), _f32(mean), _f32(invstd), _f32(dy), ldy, _f32(dgamma),
               _f32(dbeta), _f32(ws), N, Co, Lo, 1 if ctx.batch_stats else 0, _st())
         dx, dw, db = conv1d_backward_raw(x, dy, w.shape, ctx.w_bwd, ctx.pad, need_dx,
                                          overlap=True, bf16=ctx.bf16, ldy=ldy, sink_keys=(kw, kb))
-        return dx, dw, db, dgamma, dbeta, None, None, None, None, None, None, None, None, None, None
+        return (dx, dw, db, dgamma, dbeta) + nones
 
 
 # --------------------------------------------------------------------------------------
@@ -613,9 +658,19 @@ def backward_from_loss(loss):
 # --------------------------------------------------------------------------------------
 def conv_block(x, conv, bn, gap=False, packed=None):
     """Fused Conv1d -> BatchNorm1d -> ReLU -> MaxPool1d(2) [-> AdaptiveAvgPool1d(1).squeeze(-1)]."""
+    return conv_block_chain(x, conv, bn, gap, packed)[0]
+
+
+def conv_block_chain(x, conv, bn, gap=False, packed=None, x_n16=None, next_conv=None):
+    """conv_block for a chain of blocks: returns (p, p_n16).  In bf16 mode p_n16 is p in the layout the NEXT conv's
+    weight gradient reads (next_conv given), and x_n16 is this block's input in that layout (the previous block's
+    p_n16): the mixed-precision train step then needs no packing pass except for the network input."""
+    geom = None
+    if next_conv is not None and _conv_precision == "bf16":
+        geom = (next_conv.kernel_size[0], next_conv.padding[0])
     return ConvBlockFn.apply(x, conv.weight, conv.bias, bn.weight, bn.bias, bn.running_mean,
                              bn.running_var, bn.num_batches_tracked, bn.training, bn.momentum,
-                             bn.eps, conv.padding[0], gap, packed, torch.is_grad_enabled())
+                             bn.eps, conv.padding[0], gap, packed, torch.is_grad_enabled(), x_n16, geom)
 
 
 class TailFn(torch.autograd.Function):

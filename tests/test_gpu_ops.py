@@ -456,7 +456,7 @@ def test_conv_block_with_fused_gap(hip, oracle):
     dg = rng.standard_normal((N, Co)).astype(np.float32)
     xs, ws, bs, gs, bes = (dev(a).requires_grad_(True) for a in (x, w, b, gamma, beta))
     rm, rv, nbt = torch.zeros(Co).cuda(), torch.ones(Co).cuda(), torch.zeros((), dtype=torch.int64).cuda()
-    g = hip.ConvBlockFn.apply(xs, ws, bs, gs, bes, rm, rv, nbt, True, 0.1, 1e-5, 7, True)
+    g, _ = hip.ConvBlockFn.apply(xs, ws, bs, gs, bes, rm, rv, nbt, True, 0.1, 1e-5, 7, True)
     g.backward(dev(dg))
     y = oracle.conv1d_fwd(x, w, b, 7)
     mean, invstd = oracle.bn_stats(y)
@@ -571,7 +571,9 @@ def _bf16_round(a):
     return torch.from_numpy(np.ascontiguousarray(a)).to(torch.bfloat16).to(torch.float32).numpy()
 
 
-@pytest.mark.parametrize("case", [(3, 12, 32, 300), (2, 32, 64, 257), (2, 64, 128, 130), (2, 128, 256, 70), (1, 12, 32, 16)])
+# every tile configuration of the bf16 kernel: 32x256, 64x256 (rows > 160), 64x128, 128x256 (eight waves), ragged last tiles
+@pytest.mark.parametrize("case", [(3, 12, 32, 300), (2, 32, 64, 257), (2, 64, 128, 130), (2, 128, 256, 70), (1, 12, 32, 16),
+                                  (2, 64, 128, 300), (1, 128, 256, 520), (2, 32, 128, 161)])
 def test_bf16_conv_is_exact_on_bf16_rounded_operands(hip, oracle, case):
     """Mixed-precision path (config 5): the bf16 kernel must equal the oracle evaluated on the
     bf16-rounded operands up to fp32 accumulation error — this pins operand layout, rounding mode
@@ -637,3 +639,79 @@ def test_bf16_weight_grad_is_exact_on_bf16_rounded_operands(hip, oracle, case, p
     with pytest.raises(L.EcgHipError, match="C_out"):
         L.call("ecg_conv1d_bwd_weight_bias_bf16", L.f32(dyd), ldy, L.f32(xd), L.f32(dw), L.f32(db), L.f32(ws),
                N, Ci, 48, Lin, 15, 7, L.stream())
+
+
+def _unpack_n16(buf, G, C, P):
+    """bf16 [G][C][P][16] (a flat torch.bfloat16 tensor) -> float32 numpy [16*G][C][P]."""
+    a = buf.view(G, C, P, 16).to(torch.float32).cpu().numpy()
+    return np.ascontiguousarray(a.transpose(0, 3, 1, 2)).reshape(G * 16, C, P)
+
+
+@pytest.mark.parametrize("shape", [(19, 32, 300), (5, 64, 125), (16, 32, 64), (33, 128, 31)])
+def test_bn_relu_pool_n16_producers_match_the_plain_passes(hip, oracle, shape):
+    """Mixed precision: the BN+ReLU+pool forward / backward that also emit the weight gradient's operand layout
+    (bf16 n16) give the same fp32 results as the plain passes, and n16 buffers that equal the bf16 rounding of
+    those results laid out [group][channel][position][16] with zeros outside the row and past N."""
+    from ecg_hip import _lib as L
+    N, C, Lo = shape
+    rng = np.random.default_rng(sum(shape))
+    y = dev(rng.standard_normal((N, C, Lo)).astype(np.float32))
+    gamma, beta = dev((rng.random(C) + 0.5).astype(np.float32)), dev(rng.standard_normal(C).astype(np.float32) * 0.3)
+    mean, invstd = hip.bn_batch_stats(y, None, 0, None, None, None, 0.1, 1e-5)
+    Lp, G = Lo // 2, (N + 15) // 16
+    p_ref = torch.empty(N, C, Lp, device="cuda")
+    L.call("ecg_bn_relu_pool_fwd", L.f32(y), L.f32(gamma), L.f32(beta), L.f32(mean), L.f32(invstd), L.f32(p_ref), N, C, Lo, L.stream())
+    PX = L.query("ecg_conv1d_n16_positions", Lp, 15, 7, 1)
+    PA = L.query("ecg_conv1d_n16_positions", Lo, 15, 7, 0)
+    assert PA == (Lo + 15) // 16 * 16 and PX == (Lp + 15) // 16 * 16 + 16
+    p = torch.empty(N, C, Lp, device="cuda")
+    pb = torch.full((G * C * PX * 16,), 7.0, dtype=torch.bfloat16, device="cuda")
+    L.call("ecg_bn_relu_pool_fwd_n16", L.f32(y), L.f32(gamma), L.f32(beta), L.f32(mean), L.f32(invstd), L.f32(p), L.ptr(pb),
+           N, C, Lo, PX, 7, L.stream())
+    assert torch.equal(p, p_ref)
+    want = np.zeros((G * 16, C, PX), np.float32)
+    want[:N, :, 7:7 + Lp] = _bf16_round(host(p_ref))
+    assert np.array_equal(_unpack_n16(pb, G, C, PX), want)
+    # the packing entry point gives the same buffer from the fp32 tensor
+    pb2 = torch.empty_like(pb)
+    L.call("ecg_pack_n16", L.f32(p_ref), L.ptr(pb2), N, C, Lp, Lp, PX, 7, L.stream())
+    assert torch.equal(pb, pb2)
+    # backward
+    dp = dev(rng.standard_normal((N, C, Lp)).astype(np.float32))
+    ws = torch.empty(L.query("ecg_bn_relu_pool_bwd_ws_floats", N, C, Lo), device="cuda")
+    dy_ref, dg_ref, db_ref = torch.empty(N, C, Lo, device="cuda"), torch.empty(C, device="cuda"), torch.empty(C, device="cuda")
+    L.call("ecg_bn_relu_pool_bwd_ld", L.f32(y), L.f32(dp), L.f32(gamma), L.f32(beta), L.f32(mean), L.f32(invstd),
+           L.f32(dy_ref), Lo, L.f32(dg_ref), L.f32(db_ref), L.f32(ws), N, C, Lo, 1, L.stream())
+    for with_dy in (True, False):
+        dy, dg, db = torch.empty(N, C, Lo, device="cuda"), torch.empty(C, device="cuda"), torch.empty(C, device="cuda")
+        dyb = torch.full((G * C * PA * 16,), 7.0, dtype=torch.bfloat16, device="cuda")
+        L.call("ecg_bn_relu_pool_bwd_n16", L.f32(y), L.f32(dp), L.f32(gamma), L.f32(beta), L.f32(mean), L.f32(invstd),
+               L.f32(dy) if with_dy else None, Lo, L.ptr(dyb), PA, L.f32(dg), L.f32(db), L.f32(ws), N, C, Lo, 1, 0, L.stream())
+        if with_dy:
+            assert torch.equal(dy, dy_ref)
+        assert torch.equal(dg, dg_ref) and torch.equal(db, db_ref)
+        want = np.zeros((G * 16, C, PA), np.float32)
+        want[:N, :, :Lo] = _bf16_round(host(dy_ref))
+        assert np.array_equal(_unpack_n16(dyb, G, C, PA), want)
+
+
+@pytest.mark.parametrize("case", [(19, 12, 32, 300), (37, 64, 128, 125), (16, 32, 64, 64)])
+def test_bf16_weight_grad_on_packed_operands_equals_the_packing_entry_point(hip, oracle, case):
+    from ecg_hip import _lib as L
+    N, Ci, Co, Lin = case
+    rng = np.random.default_rng(sum(case) + 1)
+    x, dy = dev(rng.standard_normal((N, Ci, Lin)).astype(np.float32)), dev(rng.standard_normal((N, Co, Lin)).astype(np.float32))
+    dw, db = torch.empty(Co, Ci, 15, device="cuda"), torch.empty(Co, device="cuda")
+    ws = torch.empty(L.query("ecg_conv1d_bwd_weight_bf16_ws_floats", N, Ci, Co, Lin, 15, 7), device="cuda")
+    L.call("ecg_conv1d_bwd_weight_bias_bf16", L.f32(dy), Lin, L.f32(x), L.f32(dw), L.f32(db), L.f32(ws), N, Ci, Co, Lin, 15, 7, L.stream())
+    G = (N + 15) // 16
+    PA, PX = L.query("ecg_conv1d_n16_positions", Lin, 15, 7, 0), L.query("ecg_conv1d_n16_positions", Lin, 15, 7, 1)
+    dyb = torch.empty(G * Co * PA * 16, dtype=torch.bfloat16, device="cuda")
+    xb = torch.empty(G * Ci * PX * 16, dtype=torch.bfloat16, device="cuda")
+    L.call("ecg_pack_n16", L.f32(dy), L.ptr(dyb), N, Co, Lin, Lin, PA, 0, L.stream())
+    L.call("ecg_pack_n16", L.f32(x), L.ptr(xb), N, Ci, Lin, Lin, PX, 7, L.stream())
+    dw2, db2 = torch.empty_like(dw), torch.empty_like(db)
+    ws2 = torch.empty(L.query("ecg_conv1d_bwd_weight_bf16_packed_ws_floats", N, Ci, Co, Lin, 15, 7), device="cuda")
+    L.call("ecg_conv1d_bwd_weight_bias_bf16_packed", L.ptr(dyb), L.ptr(xb), L.f32(dw2), L.f32(db2), L.f32(ws2),
+           N, Ci, Co, Lin, 15, 7, L.stream())
+    assert torch.equal(dw, dw2) and torch.equal(db, db2)
