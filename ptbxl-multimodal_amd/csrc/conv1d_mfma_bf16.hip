@@ -22,6 +22,17 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned short u16;
 
+// in-kernel stamps of the diagnostic build (make STAMP=1), as in conv1d_mfma.hip
+#ifdef ECG_STAMP
+__device__ unsigned long long *g_stamps_b = nullptr;
+#define ECG_STAMPB_AT(slot) do { if (g_stamps_b && threadIdx.x == 0) { \
+    g_stamps_b[(size_t)blockIdx.x * 8 + (slot)] = __builtin_amdgcn_s_memtime(); \
+    if ((slot) == 0) g_stamps_b[(size_t)blockIdx.x * 8 + 7] = __builtin_amdgcn_s_memrealtime(); \
+    if ((slot) == 4) g_stamps_b[(size_t)blockIdx.x * 8 + 6] = __builtin_amdgcn_s_memrealtime(); } } while (0)
+#else
+#define ECG_STAMPB_AT(slot) do { } while (0)
+#endif
+
 constexpr int kKB = 15;      // kernel size staged by this path
 constexpr int kCB = 16;      // input channels per MFMA (its K dimension)
 
@@ -53,21 +64,33 @@ __global__ void pack_weights_bf16_kernel(const float *__restrict__ w, u16 *__res
     }
 }
 
-// grid = ceil(Lo/T_T) * Cout/CO_T * N workgroups (XCD-chunked order); WCO x WT waves (4 or 8) per workgroup.
+// PERSISTENT workgroups: grid = (Cout/CO_T) * G; workgroup (tile_co, g) owns the (n, t-tile) tiles
+// [ntiles*g/G, ntiles*(g+1)/G) of its C_out tile; WCO x WT waves (4 or 8) per workgroup.
 //
-// With bf16 operands an MFMA is 16x faster than the fp32 one but a weight chunk is only 2x smaller, so the operand
-// STREAMS bound this kernel, not the matrix pipe:
-//   * weight chunk [15][CO_T][16] bf16 per (workgroup, 16 input channels): L2 -> LDS by DMA.  A 64 x 128 tile needs
+// With bf16 operands an MFMA is 16x faster than the fp32 one, so what the fp32 kernel could ignore decides here:
+//   * one tile per workgroup (measured, 12x5000, in-kernel stamps): first operand fetch 2.6-3.8 us + store of the
+//     tile 3-5.3 us against 0.5-20 us of MFMA work per tile — 25 % (block 3) to 95 % (block 0) of a workgroup's life
+//     with the matrix pipe idle.  So the chunk pipeline runs FLAT across the tiles of a workgroup (the "next chunk"
+//     may be chunk 0 of the next tile: only the first tile pays a prologue), and a finished tile is stored
+//     fire-and-forget: the wave issues its stores (bias, BN statistics on the way) and goes straight on to the next
+//     tile, whose operands are already staged; the stores drain under its MFMAs.  (Parking the finished accumulators
+//     in a second register set to interleave the stores with the next tile's MFMAs was tried: 256 VGPRs + scratch.)
+//   * weight chunk [15][CO_T][16] bf16 per (tile, 16 input channels): L2 -> LDS by DMA.  A 64 x 128 tile needs
 //     ~31 B/clk/CU of it with four workgroups per CU — the L2 -> LDS rate a CU sustains (~30 B/clk).  Tiles are
 //     therefore as large as the layer allows: 128 x 256 (eight waves, one workgroup per CU) re-streams 4x fewer
 //     weight bytes per MFMA, 64 x 256 2x fewer.
 //   * LDS reads: one 16-byte fragment per lane feeds MC*MT MFMAs per MC+MT reads; MC = MT = 2 needs 128 B/clk/CU
-//     (half the LDS peak), the old MC = 1, MT = 2 needed 192.
+//     (half the LDS peak), MC = 1, MT = 2 needs 192.  Rows are 32 bytes ([16 channels] bf16) and a lane reads one
+//     16-byte half of a row: read plainly, the 16 lanes ds_read_b128 serves per cycle ({0-3,12-15,20-27}, ...)
+//     hit every bank twice.  The two halves of row r are therefore stored swapped when bit 3 of r is set (the rows a
+//     lane group pairs up are 8 or 24 apart, for any tap shift): conflict-free, one LDS cycle per 16 lanes.
+//   * BN statistics stay in registers until the workgroup ends (16-lane DPP row sums kept in lanes r / r+16 of one
+//     VGPR per 32 channels): one (sum, sum^2) partial per (channel, workgroup), P = G.
 template <int CO_T, int T_T, int WCO, int WT, bool STATS>
 __global__ __launch_bounds__(64 * WCO * WT) void conv1d_mfma_bf16_fwd_kernel(
     const float *__restrict__ x, const u16 *__restrict__ wb, const float *__restrict__ bias,
     float *__restrict__ y, float *__restrict__ partials, int Cin, int Cout, int L, int Lo, int pad,
-    int P, int tiles_t) {
+    int tiles_t, int N, int G) {
     constexpr int NW = WCO * WT, NT = 64 * NW;
     static_assert(NW == 4 || NW == 8, "4 or 8 waves per workgroup");
     constexpr int KK = kKB;
@@ -84,7 +107,7 @@ __global__ __launch_bounds__(64 * WCO * WT) void conv1d_mfma_bf16_fwd_kernel(
     constexpr int XBYTES = ((SPAN * kCB * 2 + 8 + 15) / 16) * 16;   // every thread commits XL items unconditionally: items
                                                          // past the tile all land in one dummy slot behind it
     constexpr int IMGB = WPADB + XBYTES;
-    constexpr int NOPS = XL + DPW + XL;                  // commits, DMA pieces, loads
+    constexpr int NOPS = XL + DPW + XL;                  // DMA pieces, commits, loads
     constexpr int OPS = (NOPS + KK - 1) / KK;            // staging operations per tap step
     constexpr int REDB = STATS ? NW * (CO_T / WCO) * 2 * 4 : 0;
     static_assert(REDB <= IMGB, "stat scratch aliases image 0");
@@ -94,20 +117,23 @@ __global__ __launch_bounds__(64 * WCO * WT) void conv1d_mfma_bf16_fwd_kernel(
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int half = lane >> 5, l31 = lane & 31;
-    // XCD-aware tile order (as conv1d_mfma.hip): the C_out tiles of one (n, t tile) read the same x panel
-    int tile;
+    ECG_STAMPB_AT(0);
+    // XCD-aware workgroup order (as conv1d_mfma.hip): the C_out tiles of one tile range read the same x panels
+    int wg;
     {
         const int nwg = gridDim.x, bid = blockIdx.x;
         const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
-        tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+        wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
     }
     const int CT = Cout / CO_T;
-    const int tile_co = tile % CT, tile_nt = tile / CT;
-    const int tile_t = tile_nt % tiles_t, n = tile_nt / tiles_t;
-    const int t0 = tile_t * T_T, co0 = tile_co * CO_T;
+    const int tile_co = wg % CT, g = wg / CT;
+    const int ntiles = N * tiles_t;
+    const int q0 = (int)((long long)ntiles * g / G), q1 = (int)((long long)ntiles * (g + 1) / G);
+    const int co0 = tile_co * CO_T;
     const int wco = (wave / WT) * (CO_T / WCO), wt = (wave % WT) * (T_T / WT);
-    const float *xn = x + (size_t)n * Cin * L;
     const int nchunks = (Cin + kCB - 1) / kCB;
+    const int total = (q1 - q0) * nchunks;               // flat chunks of this workgroup
+    if (total <= 0) return;                              // uniform: more workgroups than tiles
 
     f32x16 acc[MC][MT];
 #pragma unroll
@@ -119,51 +145,66 @@ __global__ __launch_bounds__(64 * WCO * WT) void conv1d_mfma_bf16_fwd_kernel(
 
     // bias of the 16 accumulator rows of each 32-channel group, lane-indexed (lane r + 32*half holds row (r, half)),
     // loaded before the main loop: a global load between the epilogue's stores would wait for their round trips
-    float p_b[MC];
+    float p_b[MC], st_s[MC], st_q[MC];
 #pragma unroll
-    for (int i = 0; i < MC; ++i)
+    for (int i = 0; i < MC; ++i) {
         p_b[i] = bias ? bias[co0 + wco + 32 * i + acc_row_b(l31 & 15, half)] : 0.f;
+        st_s[i] = 0.f; st_q[i] = 0.f;
+    }
 
     // ---- loop-invariant staging geometry ---------------------------------------------------
     // weight piece j of this wave: byte offset inside a chunk [K][Cout][16] bf16 -> (k, co, lane part); pieces past
-    // the slice re-read its last 16 bytes into the padding of the image
-    size_t woff[DPW];
+    // the slice re-read its last piece
+    int woff[DPW];
 #pragma unroll
     for (int j = 0; j < DPW; ++j) {
         const int e = min((min(j * NW + wave, NDMA - 1) * 64 + lane) * 16, WBYTES - 16);   // byte in the LDS image
-        const int k = e / (CO_T * kCB * 2), rem = e - k * (CO_T * kCB * 2);  // rem = co_local*32 + part
-        woff[j] = ((size_t)k * Cout + co0) * kCB * 2 + rem;                   // byte offset in the global chunk
+        const int k = e / (CO_T * kCB * 2), rem = e - k * (CO_T * kCB * 2);  // rem = co_local*32 + stored half*16
+        const int col = rem >> 5, sh = (rem >> 4) & 1;                       // LDS half sh of row col holds half sh ^ bit3(col)
+        woff[j] = (k * Cout + co0) * kCB * 2 + col * 32 + ((sh ^ ((col >> 3) & 1)) << 4);   // byte offset in the global chunk
     }
-    int xdst[XL], xq[XL], xsrc[XL];
-    unsigned xin = 0;                 // bit j: position inside the sequence
+    int xdst[XL], xq4[XL], xpm[XL];
 #pragma unroll
     for (int j = 0; j < XL; ++j) {
         const int it = tid + NT * j;
         const int itc = min(it, XITEMS - 1);
-        xq[j] = itc / SPAN;
-        const int pos = itc - xq[j] * SPAN;
-        const int s = t0 - pad + pos;
-        xsrc[j] = min(max(s, 0), L - 1);
-        xin |= ((s >= 0) && (s < L)) ? (1u << j) : 0u;
-        // items past the tile land in the padding behind it (byte offset inside the x region)
-        xdst[j] = it < XITEMS ? (pos * kCB + 4 * xq[j]) * 2 : SPAN * kCB * 2;
+        const int q = itc / SPAN, pos = itc - q * SPAN;
+        xq4[j] = 4 * q;                 // first channel of the quarter inside the chunk
+        xpm[j] = pos - pad;             // sequence index relative to the tile origin
+        // quarter q = channels 4q..4q+3 of position pos: half (q >> 1), stored swapped when bit 3 of pos is set
+        xdst[j] = it < XITEMS ? pos * 32 + ((((q >> 1) ^ (pos >> 3)) & 1) << 4) + (q & 1) * 8 : SPAN * kCB * 2;
     }
     float xreg[XL][4];
     unsigned xok = 0;                 // bit j: item j of the chunk in registers is real data
 
+    // ---- stage coordinates: uniform, advanced by additions only ---------------------------------
+    int cn = q0 / tiles_t, ctt = q0 - cn * tiles_t, cc = 0;       // compute stage: (n, t tile, chunk)
+    const float *xld = x + (size_t)cn * Cin * L;                  // load stage: sample base, t tile, chunk
+    int ltt = ctt, lc = 0, lleft = total;
+    const size_t xstep_n = (size_t)Cin * L;
+    auto ld_advance = [&]() {                      // stays on the last chunk once everything is loaded
+        if (--lleft > 0) {
+            if (++lc == nchunks) {
+                lc = 0;
+                if (++ltt == tiles_t) { ltt = 0; xld += xstep_n; }
+            }
+        } else lleft = 1;
+    };
+
     const unsigned char *wbase = reinterpret_cast<const unsigned char *>(wb);
     const size_t chunk_bytes = (size_t)KK * Cout * kCB * 2;
-    auto dma_w = [&](int j, int c, unsigned char *img) {
+    auto dma_w = [&](int j, const unsigned char *wchunk, unsigned char *img) {
         __builtin_amdgcn_global_load_lds(
-            (const __attribute__((address_space(1))) void *)(wbase + (size_t)c * chunk_bytes + woff[j]),
+            (const __attribute__((address_space(1))) void *)(wchunk + woff[j]),
             (__attribute__((address_space(3))) void *)(img + min(j * NW + wave, NDMA - 1) * 1024), 16, 0, 0);
     };
-    auto load_x = [&](int j, int c) {
-        const int ci = c * kCB + 4 * xq[j];
-        unsigned ok = (xin >> j) & 1u;
+    auto load_x = [&](int j) {                           // item j of the x tile of the load stage
+        const int ci = lc * kCB + xq4[j];
+        const int sidx = ltt * T_T + xpm[j];
+        const int off = min(ci, Cin - 4) * L + min(max(sidx, 0), L - 1);      // Cin % 4 == 0: a quarter is all valid or all padding
 #pragma unroll
-        for (int u = 0; u < 4; ++u) xreg[j][u] = xn[(size_t)min(ci + u, Cin - 1) * L + xsrc[j]];
-        ok &= (ci < Cin) ? 1u : 0u;                      // Cin % 4 == 0: a quarter is all valid or all padding
+        for (int u = 0; u < 4; ++u) xreg[j][u] = xld[off + u * L];
+        const unsigned ok = ((sidx >= 0) && (sidx < L) && (ci < Cin)) ? 1u : 0u;
         xok = (xok & ~(1u << j)) | (ok << j);
     };
     auto commit_x = [&](int j, unsigned char *img) {
@@ -173,30 +214,62 @@ __global__ __launch_bounds__(64 * WCO * WT) void conv1d_mfma_bf16_fwd_kernel(
         *reinterpret_cast<uint2 *>(img + WPADB + xdst[j]) = make_uint2(lo, hi);
     };
 
-    // prologue: chunk 0 -> image 0; x of chunk 1 -> registers (clamped to the last chunk: the loop below stages
-    // unconditionally, the stages past the end re-stage valid data nobody reads)
+    // ---- epilogue of a finished tile: one (accumulator row r, channel group i) item per call ---------
+    float *ytile = y;                    // (n, co0, t0) of the finished tile
+    int pt0 = 0;
+    const int ylane = (wco + 4 * half) * Lo + wt + l31;
+    auto epilogue_item = [&](int it) {
+        const int i = it >> 4, r = it & 15;
+        const int bi = __float_as_int(p_b[i]);
+        const float blo = __int_as_float(__builtin_amdgcn_readlane(bi, r));
+        const float bhi = __int_as_float(__builtin_amdgcn_readlane(bi, r + 32));
+        const float bv = half ? bhi : blo;
+        float *yr = ytile + (32 * i + (r & 3) + 8 * (r >> 2)) * Lo + ylane;
+        float s = 0.f, q = 0.f;
 #pragma unroll
-    for (int j = 0; j < DPW; ++j) dma_w(j, 0, lds);
+        for (int j = 0; j < MT; ++j) {
+            const float v = acc[i][j][r] + bv;
+            if (pt0 + wt + 32 * j + l31 < Lo) {
+                yr[32 * j] = v;
+                if (STATS) { s += v; q = __fmaf_rn(v, v, q); }
+            }
+        }
+        if (STATS) {
+            const bool mine = (l31 & 15) == r;           // lanes r and r+16 of each half keep row (r, half)
+            s = row16_sum(s);
+            q = row16_sum(q);
+            st_s[i] += mine ? s : 0.f;
+            st_q[i] += mine ? q : 0.f;
+        }
+    };
+
+    // prologue: flat chunk 0 -> image 0; x of flat chunk 1 -> registers
 #pragma unroll
-    for (int j = 0; j < XL; ++j) load_x(j, 0);
+    for (int j = 0; j < DPW; ++j) dma_w(j, wbase, lds);
+#pragma unroll
+    for (int j = 0; j < XL; ++j) load_x(j);
 #pragma unroll
     for (int j = 0; j < XL; ++j) commit_x(j, lds);
+    ld_advance();
 #pragma unroll
-    for (int j = 0; j < XL; ++j) load_x(j, min(1, nchunks - 1));
+    for (int j = 0; j < XL; ++j) load_x(j);
+    ld_advance();
     __syncthreads();
+    ECG_STAMPB_AT(1);
 
-    for (int c = 0; c < nchunks; ++c) {
-        const unsigned char *ws = lds + (c & 1) * IMGB, *xs = ws + WPADB;
-        unsigned char *nxt = lds + ((c + 1) & 1) * IMGB;
-        const int c1 = min(c + 1, nchunks - 1), c2 = min(c + 2, nchunks - 1);
-
+    for (int q = 0; q < total; ++q) {        // one flat chunk: 15 tap steps
+        const unsigned char *ws = lds + (q & 1) * IMGB, *xs = ws + WPADB;
+        unsigned char *nxt = lds + ((q + 1) & 1) * IMGB;
+        const unsigned char *wnext = wbase + (size_t)((cc + 1 == nchunks) ? 0 : cc + 1) * chunk_bytes;   // weights of flat chunk q+1
         auto ld = [&](int k, bf16x8 *a, bf16x8 *b) {
+            const int ha = (half ^ (l31 >> 3)) & 1;              // CO_T, wco, 32*i are multiples of 32: bit 3 of the row is bit 3 of l31
+            const int hb = (half ^ ((l31 + k) >> 3)) & 1;        // wt, 32*i likewise: bit 3 of the position is bit 3 of l31 + k
 #pragma unroll
             for (int i = 0; i < MC; ++i)
-                a[i] = *reinterpret_cast<const bf16x8 *>(ws + ((k * CO_T + wco + 32 * i + l31) * kCB + 8 * half) * 2);
+                a[i] = *reinterpret_cast<const bf16x8 *>(ws + (k * CO_T + wco + 32 * i + l31) * 32 + ha * 16);
 #pragma unroll
             for (int i = 0; i < MT; ++i)
-                b[i] = *reinterpret_cast<const bf16x8 *>(xs + ((wt + 32 * i + l31 + k) * kCB + 8 * half) * 2);
+                b[i] = *reinterpret_cast<const bf16x8 *>(xs + (wt + 32 * i + l31 + k) * 32 + hb * 16);
         };
         bf16x8 a_c[MC], b_c[MT], a_n[MC], b_n[MT];
         ld(0, a_c, b_c);
@@ -204,10 +277,10 @@ __global__ __launch_bounds__(64 * WCO * WT) void conv1d_mfma_bf16_fwd_kernel(
         for (int k = 0; k < KK; ++k) {
             ld(k + 1 < KK ? k + 1 : 0, a_n, b_n);
 #pragma unroll
-            for (int o = k * OPS; o < (k + 1) * OPS; ++o) {      // commits, then weight DMA pieces, then x loads
-                if (o < XL) commit_x(o, nxt);
-                else if (o < XL + DPW) dma_w(o - XL, c1, nxt);
-                else if (o < NOPS) load_x(o - XL - DPW, c2);
+            for (int o = k * OPS; o < (k + 1) * OPS; ++o) {      // weight DMA pieces first (longest latency), x commits, x loads;
+                if (o < DPW) dma_w(o, wnext, nxt);               // all UNCONDITIONAL: stages past the end restage valid data
+                else if (o < DPW + XL) commit_x(o - DPW, nxt);
+                else if (o < NOPS) load_x(o - XL - DPW);
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -221,71 +294,55 @@ __global__ __launch_bounds__(64 * WCO * WT) void conv1d_mfma_bf16_fwd_kernel(
 #pragma unroll
             for (int i = 0; i < MT; ++i) b_c[i] = b_n[i];
         }
-        __syncthreads();
-    }
-    float *red = reinterpret_cast<float *>(lds);
-
-    // ---- epilogue (as the fp32 kernel: the accumulator layout is dtype-independent) ---------------
-    // explicit (free) vmcnt(0): lets the compiler reuse the staging registers without waits between the stores;
-    // no global load and no LDS permute between the stores; per-row sums by DPP over 16-lane rows, kept in lanes
-    // r / r+16 of one register per 32 channels and combined once at the end.
-    __builtin_amdgcn_s_waitcnt(0x0F70);
-    auto pick = [&](float v, int r) {
-        const int vi = __float_as_int(v);
-        const float lo = __int_as_float(__builtin_amdgcn_readlane(vi, r));
-        const float hi = __int_as_float(__builtin_amdgcn_readlane(vi, r + 32));
-        return half ? hi : lo;
-    };
-    float st_s[MC], st_q[MC];
+        ld_advance();
+        __syncthreads();      // image q&1 free again; image (q+1)&1 complete (vmcnt(0) + barrier)
+        if (q == 0) ECG_STAMPB_AT(2);
+        if (++cc == nchunks) {                     // tile complete: store it and go straight on
+            cc = 0;
+            ytile = y + ((size_t)cn * Cout + co0) * Lo + ctt * T_T;
+            pt0 = ctt * T_T;
+            // nothing is in flight here (the barrier drained vmcnt); saying so keeps compiler-inserted waits for the
+            // staging registers out of the run of stores
+            __builtin_amdgcn_s_waitcnt(0x0F70);
 #pragma unroll
-    for (int i = 0; i < MC; ++i) { st_s[i] = 0.f; st_q[i] = 0.f; }
-    float *yw = y + ((size_t)n * Cout + co0 + wco + 4 * half) * Lo + t0 + wt + l31;
+            for (int e = 0; e < 16 * MC; ++e) epilogue_item(e);
 #pragma unroll
-    for (int i = 0; i < MC; ++i) {
+            for (int a = 0; a < MC; ++a)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int rowk = 32 * i + (r & 3) + 8 * (r >> 2);
-            const float bv = pick(p_b[i], r);
-            float s = 0.f, q = 0.f;
+                for (int b = 0; b < MT; ++b)
 #pragma unroll
-            for (int j = 0; j < MT; ++j) {
-                const float v = acc[i][j][r] + bv;
-                if (t0 + wt + 32 * j + l31 < Lo) {
-                    yw[rowk * Lo + 32 * j] = v;
-                    if (STATS) { s += v; q = __fmaf_rn(v, v, q); }
-                }
-            }
-            if (STATS) {
-                const bool mine = (l31 & 15) == r;
-                s = row16_sum(s);
-                q = row16_sum(q);
-                st_s[i] += mine ? s : 0.f;
-                st_q[i] += mine ? q : 0.f;
-            }
+                    for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+            if (++ctt == tiles_t) { ctt = 0; ++cn; }
         }
     }
+    ECG_STAMPB_AT(3);
     if (STATS) {
+        float *red = reinterpret_cast<float *>(lds);      // all images are dead (last chunk's barrier)
+        __syncthreads();
 #pragma unroll
         for (int i = 0; i < MC; ++i) {
             const float s = st_s[i] + __shfl_xor(st_s[i], 16, 64);
             const float q = st_q[i] + __shfl_xor(st_q[i], 16, 64);
             if (l31 < 16) {
-                const int lc = 32 * i + acc_row_b(l31, half);
-                red[(wave * (CO_T / WCO) + lc) * 2] = s;
-                red[(wave * (CO_T / WCO) + lc) * 2 + 1] = q;
+                const int lc2 = 32 * i + acc_row_b(l31, half);
+                red[(wave * (CO_T / WCO) + lc2) * 2] = s;
+                red[(wave * (CO_T / WCO) + lc2) * 2 + 1] = q;
             }
         }
         __syncthreads();
         for (int e = tid; e < CO_T * 2; e += NT) {
             const int col = e >> 1, w = e & 1;
-            const int wrow = col / (CO_T / WCO), lc = col - wrow * (CO_T / WCO);
+            const int wrow = col / (CO_T / WCO), lc2 = col - wrow * (CO_T / WCO);
             float s = 0.f;
 #pragma unroll
-            for (int j = 0; j < WT; ++j) s += red[((wrow * WT + j) * (CO_T / WCO) + lc) * 2 + w];
-            const int pidx = n * tiles_t + tile_t;
-            partials[((size_t)(co0 + col) * P + pidx) * 2 + w] = s;
+            for (int j = 0; j < WT; ++j) s += red[((wrow * WT + j) * (CO_T / WCO) + lc2) * 2 + w];
+            partials[((size_t)(co0 + col) * G + g) * 2 + w] = s;
         }
     }
+#ifdef ECG_STAMP
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+    ECG_STAMPB_AT(4);
 }
 
 bool bf16_fwd_supported(int Cin, int Cout, int K, int pad) {
@@ -294,16 +351,27 @@ bool bf16_fwd_supported(int Cin, int Cout, int K, int pad) {
 }
 
 // Tile choice: the largest C_out tile the layer has, 256 time steps when the row is long enough to fill them
-// (at 12x1000 the last block's rows are 125 long: a 256-wide tile would idle half its lanes).
-struct Bf16Cfg { int co_t, t_t; };
-static Bf16Cfg bf16_cfg(int Cout, int Lo) {
+// (at 12x1000 the last block's rows are 125 long: a 256-wide tile would idle half its lanes); G persistent
+// workgroups per C_out tile fill the resident slots (LDS decides how many fit a CU) with equal tile counts.
+struct Bf16Cfg { int co_t, t_t, G; };
+static Bf16Cfg bf16_cfg(int N, int Cout, int Lo) {
     const bool wide = Lo > 160;
-    if (Cout % 128 == 0 && wide) return {128, 256};
-    if (Cout % 64 == 0) return {64, wide ? 256 : 128};
-    return {32, 256};
+    Bf16Cfg c;
+    int per_cu;                                       // resident workgroups per CU (LDS: 2 images each)
+    if (Cout % 128 == 0 && wide) { c = {128, 256, 0}; per_cu = 1; }
+    else if (Cout % 64 == 0) { c = {64, wide ? 256 : 128, 0}; per_cu = 2; }
+    else { c = {32, 256, 0}; per_cu = 2; }            // (VGPRs allow two 4-wave workgroups per CU)
+    const int CT = Cout / c.co_t;
+    const long long ntiles = (long long)N * cdiv(Lo, c.t_t);
+    long long G = (256LL * per_cu) / CT;
+    if (G > ntiles) G = ntiles;
+    if (G < 1) G = 1;
+    const long long per = (ntiles + G - 1) / G;       // tiles of the busiest workgroup
+    c.G = (int)((ntiles + per - 1) / per);            // fewest workgroups with that maximum
+    return c;
 }
 
-int bf16_fwd_stat_partials(int N, int Cout, int Lo) { return N * cdiv(Lo, bf16_cfg(Cout, Lo).t_t); }
+int bf16_fwd_stat_partials(int N, int Cout, int Lo) { return bf16_cfg(N, Cout, Lo).G; }
 
 size_t bf16_packed_elems(int Cred, int Cout, int K) {       // reduction channels padded to 16
     return (size_t)((Cred + kCB - 1) / kCB) * K * Cout * kCB;
@@ -311,27 +379,26 @@ size_t bf16_packed_elems(int Cred, int Cout, int K) {       // reduction channel
 
 template <int CO_T, int T_T, int WCO, int WT>
 static void launch_bf16(const float *x, const u16 *wb, const float *bias, float *y, float *partials,
-                        int N, int Cin, int Cout, int L, int Lo, int pad, hipStream_t st) {
+                        int N, int Cin, int Cout, int L, int Lo, int pad, int G, hipStream_t st) {
     const int tiles_t = cdiv(Lo, T_T);
-    dim3 grid((unsigned)((size_t)tiles_t * (Cout / CO_T) * N)), block(64 * WCO * WT);
-    const int P = N * tiles_t;
+    dim3 grid((unsigned)((size_t)(Cout / CO_T) * G)), block(64 * WCO * WT);
     if (partials)
         hipLaunchKernelGGL((conv1d_mfma_bf16_fwd_kernel<CO_T, T_T, WCO, WT, true>), grid, block, 0, st,
-                           x, wb, bias, y, partials, Cin, Cout, L, Lo, pad, P, tiles_t);
+                           x, wb, bias, y, partials, Cin, Cout, L, Lo, pad, tiles_t, N, G);
     else
         hipLaunchKernelGGL((conv1d_mfma_bf16_fwd_kernel<CO_T, T_T, WCO, WT, false>), grid, block, 0, st,
-                           x, wb, bias, y, partials, Cin, Cout, L, Lo, pad, P, tiles_t);
+                           x, wb, bias, y, partials, Cin, Cout, L, Lo, pad, tiles_t, N, G);
 }
 
 int bf16_fwd(const float *x, const void *wb, const float *bias, float *y, float *partials, int N,
              int Cin, int Cout, int L, int K, int pad, hipStream_t st) {
     const int Lo = L + 2 * pad - K + 1;
     const u16 *w = static_cast<const u16 *>(wb);
-    const Bf16Cfg c = bf16_cfg(Cout, Lo);
-    if (c.co_t == 128) launch_bf16<128, 256, 2, 4>(x, w, bias, y, partials, N, Cin, Cout, L, Lo, pad, st);
-    else if (c.co_t == 64 && c.t_t == 256) launch_bf16<64, 256, 1, 4>(x, w, bias, y, partials, N, Cin, Cout, L, Lo, pad, st);
-    else if (c.co_t == 64) launch_bf16<64, 128, 2, 2>(x, w, bias, y, partials, N, Cin, Cout, L, Lo, pad, st);
-    else launch_bf16<32, 256, 1, 4>(x, w, bias, y, partials, N, Cin, Cout, L, Lo, pad, st);
+    const Bf16Cfg c = bf16_cfg(N, Cout, Lo);
+    if (c.co_t == 128) launch_bf16<128, 256, 2, 4>(x, w, bias, y, partials, N, Cin, Cout, L, Lo, pad, c.G, st);
+    else if (c.co_t == 64 && c.t_t == 256) launch_bf16<64, 256, 1, 4>(x, w, bias, y, partials, N, Cin, Cout, L, Lo, pad, c.G, st);
+    else if (c.co_t == 64) launch_bf16<64, 128, 2, 2>(x, w, bias, y, partials, N, Cin, Cout, L, Lo, pad, c.G, st);
+    else launch_bf16<32, 256, 1, 4>(x, w, bias, y, partials, N, Cin, Cout, L, Lo, pad, c.G, st);
     return check_launch("conv1d_mfma_bf16_fwd_kernel");
 }
 
@@ -460,3 +527,9 @@ ECG_API int ecg_conv1d_bwd_data_bf16(const float *dy, const void *wb_bwd, float 
     ECG_REQUIRE(bf16_fwd_supported(C_out, C_in, K, padb), "conv1d_bwd_data_bf16: needs C_out %% 4 == 0, C_in %% 32 == 0");
     return bf16_fwd(dy, wb_bwd, nullptr, dx, nullptr, N, C_out, C_in, Lo, K, padb, as_stream(stream));
 }
+
+#ifdef ECG_STAMP
+extern "C" __attribute__((visibility("default"))) int ecg_debug_set_stamp_buffer_bf16(unsigned long long *buf) {
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(ecg::g_stamps_b), &buf, sizeof(buf));
+}
+#endif

@@ -18,25 +18,31 @@ os.environ["ECG_HIP_FWD_PERSISTENT"] = "0"
 def main():
     import numpy as np
     import torch
+    bf16 = "--bf16" in sys.argv
+    T = 5000 if "--long" in sys.argv else 1000
     from ecg_hip import _lib as L, functional as F
     lib = L.load()
-    lib.ecg_debug_set_stamp_buffer.argtypes = [ctypes.c_void_p]
+    setter = lib.ecg_debug_set_stamp_buffer_bf16 if bf16 else lib.ecg_debug_set_stamp_buffer
+    setter.argtypes = [ctypes.c_void_p]
     dev = torch.device("cuda", 0)
     N, K, pad = 256, 15, 7
-    Lc = 1000
+    Lc = T
     for b, (ci, co) in enumerate([(12, 32), (32, 64), (64, 128), (128, 256)]):
         x = torch.randn(N, ci, Lc, device=dev)
         w = torch.randn(co, ci, K, device=dev) * 0.05
         bias = torch.randn(co, device=dev)
-        wf, _ = F.conv1d_pack(w, need_bwd=False)
+        wf, _ = (F.conv1d_pack_bf16 if bf16 else F.conv1d_pack)(w, need_bwd=False)
         y = torch.empty(N, co, Lc, device=dev)
-        P = L.query("ecg_conv1d_fwd_stat_partials", N, ci, co, Lc, K, pad)
+        P = L.query("ecg_conv1d_fwd_bf16_stat_partials" if bf16 else "ecg_conv1d_fwd_stat_partials", N, ci, co, Lc, K, pad)
         part = torch.empty(co * P * 2, device=dev)
-        stamps = torch.zeros(8192 * 8, dtype=torch.int64, device=dev)
+        stamps = torch.zeros(16384 * 8, dtype=torch.int64, device=dev)
         for rep in range(3):
             stamps.zero_()
-            lib.ecg_debug_set_stamp_buffer(stamps.data_ptr())
-            L.call("ecg_conv1d_fwd", L.f32(x), L.f32(wf), L.f32(bias), L.f32(y), L.f32(part), N, ci, co, Lc, K, pad, L.stream())
+            setter(stamps.data_ptr())
+            if bf16:
+                L.call("ecg_conv1d_fwd_bf16", L.f32(x), L.ptr(wf), L.f32(bias), L.f32(y), L.f32(part), N, ci, co, Lc, K, pad, L.stream())
+            else:
+                L.call("ecg_conv1d_fwd", L.f32(x), L.f32(wf), L.f32(bias), L.f32(y), L.f32(part), N, ci, co, Lc, K, pad, L.stream())
             torch.cuda.synchronize()
         s = stamps.cpu().numpy().reshape(-1, 8)
         s = s[s[:, 0] != 0]
