@@ -174,10 +174,11 @@ def test_g6_gradcam_hooks_and_demo_gradient():
         np.testing.assert_allclose(l2.cpu().numpy(), logits.detach().cpu().numpy(), atol=2e-5)
 
 
-@pytest.mark.parametrize("name,B,T", [("cnn5", 256, 1000), ("mm", 256, 1000), ("cnn1", 64, 5000)])
+@pytest.mark.parametrize("name,B,T", [("cnn5", 256, 1000), ("mm", 256, 1000), ("cnn1", 64, 5000), ("cnn1", 256, 5000)])
 def test_full_size_train_step_vs_cpu_oracle(name, B, T):
-    """BASELINE.json sizes (B=256, 12x1000; the AF-binary 12x5000 window of config 5 at B=64): one train
-    step vs the stock-torch CPU restatement."""
+    """BASELINE.json sizes (B=256, 12x1000 = configs[1]/[2]; the AF-binary 12x5000 window of configs[4] at B=64 and
+    at its full B=256): one fp32 train step vs the stock-torch CPU restatement — logits 1e-4, thresholded
+    predictions exact, first-step gradients, BN buffers and counters."""
     from ecg_hip.optim import FlatAdamW
     from src.utils.seed import set_seed
     from ecg_hip import functional as hipF

@@ -715,3 +715,47 @@ def test_bf16_weight_grad_on_packed_operands_equals_the_packing_entry_point(hip,
     L.call("ecg_conv1d_bwd_weight_bias_bf16_packed", L.ptr(dyb), L.ptr(xb), L.f32(dw2), L.f32(db2), L.f32(ws2),
            N, Ci, Co, Lin, 15, 7, L.stream())
     assert torch.equal(dw, dw2) and torch.equal(db, db2)
+
+
+@pytest.mark.parametrize("block", [0, 1, 2, 3])
+def test_bf16_conv_full_size_config5_vs_torch_on_rounded_operands(hip, block):
+    """BASELINE.json configs[4] at its full size (B=256, 12x5000: block inputs 5000/2500/1250/625 long): bf16 forward,
+    input gradient and weight gradient (through the n16 producers' layout) against stock torch (CPU, fp32) evaluated
+    on the bf16-ROUNDED operands — what test_bf16_*_exact_on_bf16_rounded_operands pin at small N with the C oracle."""
+    from ecg_hip import _lib as L
+    Ci, Co = [(12, 32), (32, 64), (64, 128), (128, 256)][block]
+    N, Lin = 256, 5000 >> block
+    g = torch.Generator().manual_seed(block)
+    x = torch.randn(N, Ci, Lin, generator=g)
+    w = torch.randn(Co, Ci, 15, generator=g) / float(np.sqrt(Ci * 15))
+    b = torch.randn(Co, generator=g)
+    dy = torch.randn(N, Co, Lin, generator=g)
+    rnd = lambda t: t.to(torch.bfloat16).to(torch.float32)
+    xr, wr, dyr = rnd(x).requires_grad_(block > 0), rnd(w).requires_grad_(True), rnd(dy)
+    torch.nn.functional.conv1d(xr, wr, b, padding=7).backward(dyr)
+    with torch.no_grad():
+        ry = torch.nn.functional.conv1d(xr, wr, b, padding=7)
+    xd, dyd = x.cuda(), dy.cuda()
+    wb_fwd, wb_bwd = hip.conv1d_pack_bf16(w.cuda(), need_bwd=block > 0)
+    y, partials, P = hip.conv1d_forward_bf16_raw(xd, wb_fwd, b.cuda(), Co, 15, 7, want_stats=True)
+    assert float((y.cpu() - ry).abs().max()) < 1e-4
+    mean, invstd = hip.bn_batch_stats(y, partials, P, None, None, None, 0.1, 1e-5)
+    np.testing.assert_allclose(host(mean), ry.mean(dim=(0, 2)).numpy(), atol=2e-5)
+    np.testing.assert_allclose(host(invstd), (1.0 / torch.sqrt(ry.var(dim=(0, 2), unbiased=False) + 1e-5)).numpy(), rtol=1e-4)
+    if block > 0:
+        dx = torch.empty_like(xd)
+        L.call("ecg_conv1d_bwd_data_bf16", L.f32(dyd), L.ptr(wb_bwd), L.f32(dx), N, Ci, Co, Lin, 15, 7, L.stream())
+        assert float((dx.cpu() - xr.grad).abs().max()) < 2e-4
+    G = N // 16
+    PA, PX = L.query("ecg_conv1d_n16_positions", Lin, 15, 7, 0), L.query("ecg_conv1d_n16_positions", Lin, 15, 7, 1)
+    dyb = torch.empty(G * Co * PA * 16, dtype=torch.bfloat16, device="cuda")
+    xb = torch.empty(G * Ci * PX * 16, dtype=torch.bfloat16, device="cuda")
+    L.call("ecg_pack_n16", L.f32(dyd), L.ptr(dyb), N, Co, Lin, Lin, PA, 0, L.stream())
+    L.call("ecg_pack_n16", L.f32(xd), L.ptr(xb), N, Ci, Lin, Lin, PX, 7, L.stream())
+    dw, db = torch.empty(Co, Ci, 15, device="cuda"), torch.empty(Co, device="cuda")
+    ws = torch.empty(L.query("ecg_conv1d_bwd_weight_bf16_packed_ws_floats", N, Ci, Co, Lin, 15, 7), device="cuda")
+    L.call("ecg_conv1d_bwd_weight_bias_bf16_packed", L.ptr(dyb), L.ptr(xb), L.f32(dw), L.f32(db), L.f32(ws), N, Ci, Co, Lin, 15, 7, L.stream())
+    # both sides accumulate ~N*L products in fp32 (in different orders): a few ulp of the largest entries
+    assert float((dw.cpu() - wr.grad).abs().max()) < 5e-6 * float(wr.grad.abs().max()) + 2e-5
+    rdb = dyr.sum(dim=(0, 2))
+    assert float((db.cpu() - rdb).abs().max()) < 5e-6 * float(rdb.abs().max()) + 1e-3
