@@ -188,6 +188,16 @@ int ecg_bn_invstd(const float *var, float *invstd, int C, float eps, ecg_stream_
 int ecg_bn_relu_pool_fwd(const float *y, const float *gamma, const float *beta,
                          const float *mean, const float *invstd, float *p,
                          int N, int C, int L, ecg_stream_t stream);
+/* ecg_bn_finalize + BN-apply + ReLU + MaxPool(2) in ONE launch: the statistics combine is folded into the streaming
+ * pass (every workgroup re-derives mean / invstd of its channel from the P partials — same arithmetic and bits as
+ * ecg_bn_finalize — one workgroup per channel stores them and updates running statistics / counter).  mean and
+ * invstd are OUTPUTS.  mode 0: out = p [N][C][L/2]; mode 1: + global average pool, out = g [N][C]; mode 2: out = p
+ * (may be NULL) and p_n16 = the bf16 "n16" copy with PX positions at `shift` (mixed precision, see below). */
+int ecg_bn_stats_relu_pool_fwd(const float *stat_partials, int P, long long count, float *running_mean,
+                               float *running_var, long long *num_batches_tracked, float momentum, float eps,
+                               const float *y, const float *gamma, const float *beta, float *mean,
+                               float *invstd, float *out, void *p_n16, int N, int C, int L, int PX, int shift,
+                               int mode, ecg_stream_t stream);
 
 size_t ecg_bn_relu_pool_bwd_ws_floats(int N, int C, int L);
 /* Backward of the fused tail: dp [N][C][L/2] -> dy [N][C][L], dgamma[C], dbeta[C].

@@ -41,17 +41,23 @@ __global__ __launch_bounds__(kBlock) void bn_stat_partials_kernel(
         partials[((size_t)c * S + s) * 2 + tl] = red[0][tl] + red[1][tl] + red[2][tl] + red[3][tl];
 }
 
-// One workgroup (4 waves) per channel: double-precision, fixed-order combine of the P partials
-// (thread t sums partials t, t+256, ...; lanes by butterfly; waves 0..3 in order).
-__global__ __launch_bounds__(256) void bn_finalize_kernel(
-    const float *__restrict__ partials, int P, double count, float *__restrict__ mean,
-    float *__restrict__ invstd, float *__restrict__ running_mean, float *__restrict__ running_var,
-    long long *__restrict__ nbt, float momentum, float eps) {
+// Double-precision, fixed-order combine of the P statistics partials of channel c by one 256-thread workgroup
+// (thread t sums partials t, t+256, ...; lanes by butterfly; waves 0..3 in order) -> batch mean / invstd, returned
+// to every thread.  `writer` (one workgroup per channel) also stores them and updates the running statistics
+// (momentum, unbiased variance) and, for channel 0, the batch counter.  Used by bn_finalize_kernel (its own launch)
+// and, FOLDED IN, by the BN+ReLU+pool forward kernels: every workgroup re-derives the numbers of its channel from
+// L2 instead of waiting for a 4.7 us launch per layer; same arithmetic, same bits.
+struct BnFin {
+    const float *partials; int P; double count; float *mean, *invstd, *running_mean, *running_var;
+    long long *nbt; float momentum, eps;
+};
+__device__ __forceinline__ void bn_finalize_block(const BnFin &f, int c, bool writer, float &mu_out, float &is_out) {
     __shared__ double red[4][2];
-    const int c = blockIdx.x, tl = threadIdx.x;
-    const float2 *pc = reinterpret_cast<const float2 *>(partials) + (size_t)c * P;
+    __shared__ float res[2];
+    const int tl = threadIdx.x;
+    const float2 *pc = reinterpret_cast<const float2 *>(f.partials) + (size_t)c * f.P;
     double a = 0.0, q = 0.0;
-    for (int p = tl; p < P; p += 256) {
+    for (int p = tl; p < f.P; p += 256) {
         const float2 v = pc[p];
         a += (double)v.x;
         q += (double)v.y;
@@ -62,18 +68,29 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(
     if (tl == 0) {
         a = ((red[0][0] + red[1][0]) + red[2][0]) + red[3][0];
         q = ((red[0][1] + red[1][1]) + red[2][1]) + red[3][1];
-        double mu = a / count;
-        double var = q / count - mu * mu;
+        const double mu = a / f.count;
+        double var = q / f.count - mu * mu;
         if (var < 0.0) var = 0.0;
-        mean[c] = (float)mu;
-        invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
-        if (running_mean) {
-            double unb = count > 1.0 ? var * count / (count - 1.0) : var;
-            running_mean[c] = (float)((1.0 - momentum) * running_mean[c] + momentum * mu);
-            running_var[c] = (float)((1.0 - momentum) * running_var[c] + momentum * unb);
+        const float mf = (float)mu, isf = (float)(1.0 / sqrt(var + (double)f.eps));
+        res[0] = mf; res[1] = isf;
+        if (writer) {
+            f.mean[c] = mf;
+            f.invstd[c] = isf;
+            if (f.running_mean) {
+                const double unb = f.count > 1.0 ? var * f.count / (f.count - 1.0) : var;
+                f.running_mean[c] = (float)((1.0 - f.momentum) * f.running_mean[c] + f.momentum * mu);
+                f.running_var[c] = (float)((1.0 - f.momentum) * f.running_var[c] + f.momentum * unb);
+            }
+            if (f.nbt && c == 0) *f.nbt += 1;
         }
-        if (nbt && c == 0) *nbt += 1;
     }
+    __syncthreads();
+    mu_out = res[0]; is_out = res[1];
+}
+
+__global__ __launch_bounds__(256) void bn_finalize_kernel(BnFin f) {
+    float mu, is;
+    bn_finalize_block(f, blockIdx.x, true, mu, is);
 }
 
 __global__ void bn_invstd_kernel(const float *__restrict__ var, float *__restrict__ invstd, int C,
@@ -87,12 +104,16 @@ __global__ void bn_invstd_kernel(const float *__restrict__ var, float *__restric
 // ---------------------------------------------------------------------------------------
 // grid = (C, S2): a block owns channel c and the samples of split s2 and walks their pooled positions flat, four
 // iterations in flight (loads unconditional, clamped); a wave reads 512 contiguous bytes of y and writes 256 of p.
+template <bool FIN>
 __global__ __launch_bounds__(kBlock) void bn_relu_pool_fwd_kernel(
     const float *__restrict__ y, const float *__restrict__ gamma, const float *__restrict__ beta,
     const float *__restrict__ mean, const float *__restrict__ invstd, float *__restrict__ p,
-    int N, int C, int L, int Lp, int S2) {
+    int N, int C, int L, int Lp, int S2, BnFin fin) {
     const int c = blockIdx.x, s2 = blockIdx.y, tl = threadIdx.x;
-    const float sc = invstd[c] * gamma[c], mu = mean[c], be = beta[c];
+    float mu, is;
+    if (FIN) bn_finalize_block(fin, c, s2 == 0, mu, is);      // statistics combine folded in (no finalize launch)
+    else { mu = mean[c]; is = invstd[c]; }
+    const float sc = is * gamma[c], be = beta[c];
     const int n0 = (int)((long long)N * s2 / S2), n1 = (int)((long long)N * (s2 + 1) / S2);
     const int total = (n1 - n0) * Lp;
     constexpr int U = 4;
@@ -122,24 +143,32 @@ __global__ __launch_bounds__(kBlock) void bn_relu_pool_fwd_kernel(
 }
 
 // Last block of the backbone: BatchNorm -> ReLU -> MaxPool(2) -> AdaptiveAvgPool1d(1) without
-// materialising the pooled tensor.  One wave per (n, c) row; g[row] = mean_j pooled[row][j].
+// materialising the pooled tensor.  grid = (C, S2): a workgroup owns channel c and the samples of split s2, one wave
+// per (n, c) row at a time; g[row] = mean_j pooled[row][j].
+template <bool FIN>
 __global__ __launch_bounds__(kBlock) void bn_relu_pool_gap_fwd_kernel(
     const float *__restrict__ y, const float *__restrict__ gamma, const float *__restrict__ beta,
     const float *__restrict__ mean, const float *__restrict__ invstd, float *__restrict__ g,
-    int C, int L, int Lp, int rows) {
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= rows) return;
-    const int lane = threadIdx.x & 63, c = row % C;
-    const float sc = invstd[c] * gamma[c], mu = mean[c], be = beta[c];
-    const float *r = y + (size_t)row * L;
-    float a = 0.f;
-    for (int j = lane; j < Lp; j += 64) {
-        float a0 = bn_apply1(r[2 * j], mu, sc, be), a1 = bn_apply1(r[2 * j + 1], mu, sc, be);
-        float m = a1 > a0 ? a1 : a0;
-        a += m > 0.f ? m : 0.f;
+    int N, int C, int L, int Lp, int S2, BnFin fin) {
+    const int c = blockIdx.x, s2 = blockIdx.y;
+    float mu, is;
+    if (FIN) bn_finalize_block(fin, c, s2 == 0, mu, is);
+    else { mu = mean[c]; is = invstd[c]; }
+    const float sc = is * gamma[c], be = beta[c];
+    const int n0 = (int)((long long)N * s2 / S2), n1 = (int)((long long)N * (s2 + 1) / S2);
+    const int lane = threadIdx.x & 63;
+    for (int n = n0 + (threadIdx.x >> 6); n < n1; n += 4) {
+        const size_t row = (size_t)n * C + c;
+        const float *r = y + row * L;
+        float a = 0.f;
+        for (int j = lane; j < Lp; j += 64) {
+            float a0 = bn_apply1(r[2 * j], mu, sc, be), a1 = bn_apply1(r[2 * j + 1], mu, sc, be);
+            float m = a1 > a0 ? a1 : a0;
+            a += m > 0.f ? m : 0.f;
+        }
+        a = wave_sum(a);
+        if (lane == 0) g[row] = a / (float)Lp;
     }
-    a = wave_sum(a);
-    if (lane == 0) g[row] = a / (float)Lp;
 }
 
 __global__ __launch_bounds__(kBlock) void bn_apply_fwd_kernel(
@@ -354,13 +383,17 @@ __device__ __forceinline__ void store_n16(u16n *dst, const float *v) {
 
 // p [N][C][Lp] fp32 (may be NULL) and pb[g][c][pos][16] with pb[.., j + shift, s] = p[16g + s][c][j].
 // grid = (ceil(PX/256), C, G)
+template <bool FIN>
 __global__ __launch_bounds__(kBlock) void bn_relu_pool_fwd_n16_kernel(
     const float *__restrict__ y, const float *__restrict__ gamma, const float *__restrict__ beta,
     const float *__restrict__ mean, const float *__restrict__ invstd, float *__restrict__ p,
-    u16n *__restrict__ pb, int N, int C, int L, int Lp, int PX, int shift) {
+    u16n *__restrict__ pb, int N, int C, int L, int Lp, int PX, int shift, BnFin fin) {
     const int pos = blockIdx.x * kBlock + threadIdx.x, c = blockIdx.y, g = blockIdx.z;
+    float mu, is;
+    if (FIN) bn_finalize_block(fin, c, blockIdx.x == 0 && g == 0, mu, is);
+    else { mu = mean[c]; is = invstd[c]; }
     if (pos >= PX) return;
-    const float sc = invstd[c] * gamma[c], mu = mean[c], be = beta[c];
+    const float sc = is * gamma[c], be = beta[c];
     const int j = pos - shift;
     const bool in_row = (j >= 0) && (j < Lp);
     const int jc = min(max(j, 0), Lp - 1);
@@ -527,9 +560,9 @@ ECG_API int ecg_bn_finalize(const float *stat_partials, int P, long long count, 
     ECG_REQUIRE(P > 0 && C > 0 && count > 0, "bn_finalize: P=%d C=%d count=%lld", P, C, count);
     ECG_REQUIRE((running_mean == nullptr) == (running_var == nullptr),
                 "bn_finalize: running_mean/var must both be given or both NULL");
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(256), 0, as_stream(stream), stat_partials,
-                       P, (double)count, mean, invstd, running_mean, running_var,
-                       num_batches_tracked, momentum, eps);
+    const BnFin f{stat_partials, P, (double)count, mean, invstd, running_mean, running_var, num_batches_tracked,
+                  momentum, eps};
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(256), 0, as_stream(stream), f);
     return check_launch("bn_finalize_kernel");
 }
 
@@ -540,33 +573,106 @@ ECG_API int ecg_bn_invstd(const float *var, float *invstd, int C, float eps, ecg
     return check_launch("bn_invstd_kernel");
 }
 
-ECG_API int ecg_bn_relu_pool_fwd(const float *y, const float *gamma, const float *beta,
-                                 const float *mean, const float *invstd, float *p, int N, int C,
-                                 int L, ecg_stream_t stream) {
+// ---- BN-apply + ReLU + MaxPool(2) forward, optionally with the statistics combine folded in (fin != NULL) ----------
+static int check_fin(const char *who, const BnFin &f, int C) {
+    ECG_REQUIRE(f.partials && f.mean && f.invstd, "%s: null pointer", who);
+    ECG_REQUIRE(f.P > 0 && C > 0 && f.count > 0, "%s: P=%d C=%d count=%g", who, f.P, C, f.count);
+    ECG_REQUIRE((f.running_mean == nullptr) == (f.running_var == nullptr),
+                "%s: running_mean/var must both be given or both NULL", who);
+    return ECG_OK;
+}
+
+static int pool_fwd_impl(const BnFin *fin, const float *y, const float *gamma, const float *beta, const float *mean,
+                         const float *invstd, float *p, int N, int C, int L, hipStream_t st) {
     int rc = check_ncl("bn_relu_pool_fwd", N, C, L);
     if (rc) return rc;
     ECG_REQUIRE(y && gamma && beta && mean && invstd, "bn_relu_pool_fwd: null pointer");
     const int Lp = L / 2;
-    if (Lp == 0) return ECG_OK;   // MaxPool1d(2) of a length-1 row is empty
-    ECG_REQUIRE(p, "bn_relu_pool_fwd: null output");
+    if (Lp == 0 && !fin) return ECG_OK;   // MaxPool1d(2) of a length-1 row is empty
+    ECG_REQUIRE(p || Lp == 0, "bn_relu_pool_fwd: null output");
     int S2 = cdiv(4096, C);
     if (S2 > N) S2 = N;
-    hipLaunchKernelGGL(bn_relu_pool_fwd_kernel, dim3(C, S2), dim3(kBlock), 0, as_stream(stream), y, gamma, beta,
-                       mean, invstd, p, N, C, L, Lp, S2);
+    if (fin)
+        hipLaunchKernelGGL(bn_relu_pool_fwd_kernel<true>, dim3(C, S2), dim3(kBlock), 0, st, y, gamma, beta, mean,
+                           invstd, p, N, C, L, Lp, S2, *fin);
+    else
+        hipLaunchKernelGGL(bn_relu_pool_fwd_kernel<false>, dim3(C, S2), dim3(kBlock), 0, st, y, gamma, beta, mean,
+                           invstd, p, N, C, L, Lp, S2, BnFin{});
     return check_launch("bn_relu_pool_fwd_kernel");
+}
+
+static int pool_gap_fwd_impl(const BnFin *fin, const float *y, const float *gamma, const float *beta,
+                             const float *mean, const float *invstd, float *g, int N, int C, int L, hipStream_t st) {
+    int rc = check_ncl("bn_relu_pool_gap_fwd", N, C, L);
+    if (rc) return rc;
+    ECG_REQUIRE(y && gamma && beta && mean && invstd && g, "bn_relu_pool_gap_fwd: null pointer");
+    ECG_REQUIRE(L >= 2, "bn_relu_pool_gap_fwd: L=%d leaves an empty pooled row", L);
+    int S2 = cdiv(4096, C);
+    if (S2 > cdiv(N, 4)) S2 = cdiv(N, 4);          // four rows (one per wave) in flight per workgroup
+    if (fin)
+        hipLaunchKernelGGL(bn_relu_pool_gap_fwd_kernel<true>, dim3(C, S2), dim3(kBlock), 0, st, y, gamma, beta, mean,
+                           invstd, g, N, C, L, L / 2, S2, *fin);
+    else
+        hipLaunchKernelGGL(bn_relu_pool_gap_fwd_kernel<false>, dim3(C, S2), dim3(kBlock), 0, st, y, gamma, beta, mean,
+                           invstd, g, N, C, L, L / 2, S2, BnFin{});
+    return check_launch("bn_relu_pool_gap_fwd_kernel");
+}
+
+static int pool_fwd_n16_impl(const BnFin *fin, const float *y, const float *gamma, const float *beta,
+                             const float *mean, const float *invstd, float *p, void *p_n16, int N, int C, int L,
+                             int PX, int shift, hipStream_t st) {
+    int rc = check_ncl("bn_relu_pool_fwd_n16", N, C, L);
+    if (rc) return rc;
+    ECG_REQUIRE(y && gamma && beta && mean && invstd && p_n16, "bn_relu_pool_fwd_n16: null pointer");
+    const int Lp = L / 2;
+    ECG_REQUIRE(Lp >= 1 && shift >= 0 && PX >= shift + Lp, "bn_relu_pool_fwd_n16: PX=%d cannot hold %d positions at shift %d",
+                PX, Lp, shift);
+    ECG_REQUIRE((reinterpret_cast<uintptr_t>(p_n16) & 15) == 0, "bn_relu_pool_fwd_n16: n16 output must be 16-byte aligned");
+    const int G = cdiv(N, 16);
+    if (fin)
+        hipLaunchKernelGGL(bn_relu_pool_fwd_n16_kernel<true>, dim3(cdiv(PX, kBlock), C, G), dim3(kBlock), 0, st, y,
+                           gamma, beta, mean, invstd, p, static_cast<u16n *>(p_n16), N, C, L, Lp, PX, shift, *fin);
+    else
+        hipLaunchKernelGGL(bn_relu_pool_fwd_n16_kernel<false>, dim3(cdiv(PX, kBlock), C, G), dim3(kBlock), 0, st, y,
+                           gamma, beta, mean, invstd, p, static_cast<u16n *>(p_n16), N, C, L, Lp, PX, shift, BnFin{});
+    return check_launch("bn_relu_pool_fwd_n16_kernel");
+}
+
+ECG_API int ecg_bn_relu_pool_fwd(const float *y, const float *gamma, const float *beta,
+                                 const float *mean, const float *invstd, float *p, int N, int C,
+                                 int L, ecg_stream_t stream) {
+    return pool_fwd_impl(nullptr, y, gamma, beta, mean, invstd, p, N, C, L, as_stream(stream));
 }
 
 ECG_API int ecg_bn_relu_pool_gap_fwd(const float *y, const float *gamma, const float *beta,
                                      const float *mean, const float *invstd, float *g, int N,
                                      int C, int L, ecg_stream_t stream) {
-    int rc = check_ncl("bn_relu_pool_gap_fwd", N, C, L);
+    return pool_gap_fwd_impl(nullptr, y, gamma, beta, mean, invstd, g, N, C, L, as_stream(stream));
+}
+
+ECG_API int ecg_bn_relu_pool_fwd_n16(const float *y, const float *gamma, const float *beta, const float *mean,
+                                     const float *invstd, float *p, void *p_n16, int N, int C, int L, int PX,
+                                     int shift, ecg_stream_t stream) {
+    return pool_fwd_n16_impl(nullptr, y, gamma, beta, mean, invstd, p, p_n16, N, C, L, PX, shift, as_stream(stream));
+}
+
+// ecg_bn_finalize + the pass above in ONE launch: mean / invstd are OUTPUTS here (and the running statistics and the
+// counter are updated), written by one workgroup per channel while every workgroup re-derives them for itself.
+// mode: 0 = pool -> out [N][C][L/2]; 1 = pool + global average -> out [N][C]; 2 = pool, fp32 out (may be NULL) and
+// the n16 bf16 copy p_n16 with PX positions at `shift`.
+ECG_API int ecg_bn_stats_relu_pool_fwd(const float *stat_partials, int P, long long count, float *running_mean,
+                                       float *running_var, long long *num_batches_tracked, float momentum, float eps,
+                                       const float *y, const float *gamma, const float *beta, float *mean,
+                                       float *invstd, float *out, void *p_n16, int N, int C, int L, int PX, int shift,
+                                       int mode, ecg_stream_t stream) {
+    const BnFin f{stat_partials, P, (double)count, mean, invstd, running_mean, running_var, num_batches_tracked,
+                  momentum, eps};
+    int rc = check_fin("bn_stats_relu_pool_fwd", f, C);
     if (rc) return rc;
-    ECG_REQUIRE(y && gamma && beta && mean && invstd && g, "bn_relu_pool_gap_fwd: null pointer");
-    ECG_REQUIRE(L >= 2, "bn_relu_pool_gap_fwd: L=%d leaves an empty pooled row", L);
-    const int rows = N * C;
-    hipLaunchKernelGGL(bn_relu_pool_gap_fwd_kernel, dim3(cdiv(rows, 4)), dim3(kBlock), 0,
-                       as_stream(stream), y, gamma, beta, mean, invstd, g, C, L, L / 2, rows);
-    return check_launch("bn_relu_pool_gap_fwd_kernel");
+    ECG_REQUIRE(mode >= 0 && mode <= 2, "bn_stats_relu_pool_fwd: mode %d", mode);
+    if (mode == 0) return pool_fwd_impl(&f, y, gamma, beta, mean, invstd, out, N, C, L, as_stream(stream));
+    if (mode == 1) return pool_gap_fwd_impl(&f, y, gamma, beta, mean, invstd, out, N, C, L, as_stream(stream));
+    return pool_fwd_n16_impl(&f, y, gamma, beta, mean, invstd, out, p_n16, N, C, L, PX, shift, as_stream(stream));
 }
 
 ECG_API size_t ecg_bn_relu_pool_bwd_ws_floats(int N, int C, int L) {
@@ -696,22 +802,6 @@ ECG_API int ecg_bn_relu_pool_gap_bwd(const float *y, const float *dg, const floa
 }
 
 // ---- mixed-precision producers (see the kernels above) -------------------------------------------------
-ECG_API int ecg_bn_relu_pool_fwd_n16(const float *y, const float *gamma, const float *beta, const float *mean,
-                                     const float *invstd, float *p, void *p_n16, int N, int C, int L, int PX,
-                                     int shift, ecg_stream_t stream) {
-    int rc = check_ncl("bn_relu_pool_fwd_n16", N, C, L);
-    if (rc) return rc;
-    ECG_REQUIRE(y && gamma && beta && mean && invstd && p_n16, "bn_relu_pool_fwd_n16: null pointer");
-    const int Lp = L / 2;
-    ECG_REQUIRE(Lp >= 1 && shift >= 0 && PX >= shift + Lp, "bn_relu_pool_fwd_n16: PX=%d cannot hold %d positions at shift %d",
-                PX, Lp, shift);
-    ECG_REQUIRE((reinterpret_cast<uintptr_t>(p_n16) & 15) == 0, "bn_relu_pool_fwd_n16: n16 output must be 16-byte aligned");
-    const int G = cdiv(N, 16);
-    hipLaunchKernelGGL(bn_relu_pool_fwd_n16_kernel, dim3(cdiv(PX, kBlock), C, G), dim3(kBlock), 0, as_stream(stream),
-                       y, gamma, beta, mean, invstd, p, static_cast<u16n *>(p_n16), N, C, L, Lp, PX, shift);
-    return check_launch("bn_relu_pool_fwd_n16_kernel");
-}
-
 ECG_API int ecg_bn_relu_pool_bwd_n16(const float *y, const float *dp, const float *gamma, const float *beta,
                                      const float *mean, const float *invstd, float *dy, int ldy, void *dy_n16,
                                      int PA, float *dgamma, float *dbeta, float *ws, int N, int C, int L,

@@ -52,6 +52,7 @@ SIGNATURES = {
     "ecg_bn_finalize": (_i, [_vp, _i, _ll, _vp, _vp, _vp, _vp, _vp, _i, _f, _f, _vp]),
     "ecg_bn_invstd": (_i, [_vp, _vp, _i, _f, _vp]),
     "ecg_bn_relu_pool_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
+    "ecg_bn_stats_relu_pool_fwd": (_i, [_vp, _i, _ll, _vp, _vp, _vp, _f, _f] + [_vp] * 7 + [_i] * 6 + [_vp]),
     "ecg_bn_relu_pool_bwd_ws_floats": (_sz, [_i, _i, _i]),
     "ecg_bn_relu_pool_bwd": (_i, [_vp] * 10 + [_i, _i, _i, _i, _vp]),
     "ecg_bn_relu_pool_bwd_ld": (_i, [_vp] * 7 + [_i] + [_vp] * 3 + [_i, _i, _i, _i, _vp]),

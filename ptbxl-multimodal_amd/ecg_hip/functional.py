@@ -366,28 +366,34 @@ class ConvBlockFn(torch.autograd.Function):
             y, partials, P = conv1d_forward_bf16_raw(x, w_fwd, b, Co, K, pad, want_stats=use_batch)
         else:
             y, partials, P = conv1d_forward_raw(x, w_fwd, b, Co, K, pad, want_stats=use_batch)
+        N, _, Lo = y.shape
+        p_n16, PX, shift = None, 0, 0
+        if not gap and bf16 and need_grad and next_geom is not None and Lo >= 2:
+            # mixed precision: p also as the next conv's weight-gradient operand (bf16, n16 layout)
+            PX, shift = _query("ecg_conv1d_n16_positions", Lo // 2, next_geom[0], next_geom[1], 1), next_geom[1]
+        if PX:
+            p_n16 = torch.empty(((N + 15) // 16) * Co * PX * 16, dtype=torch.bfloat16, device=x.device)
+            ctx.mark_non_differentiable(p_n16)
+            ctx.set_materialize_grads(False)     # no zero-filled "gradient" for the n16 by-product (41 MB fill)
+        p = _empty(x, N, Co) if gap else _empty(x, N, Co, Lo // 2)
+        mode = 1 if gap else (2 if PX else 0)
         if use_batch:
+            # statistics combine + BN-apply + ReLU + pool in ONE launch (ecg_bn_finalize folded into the streaming pass)
             rm, rv, cnt = (running_mean, running_var, nbt) if training else (None, None, None)
-            mean, invstd = bn_batch_stats(y, partials, P, rm, rv, cnt, _bn_momentum(momentum, nbt), eps)
+            if cnt is not None and cnt.dtype != torch.int64:
+                raise L.EcgHipError("num_batches_tracked must be int64")
+            mean, invstd = _empty(y, Co), _empty(y, Co)
+            _call("ecg_bn_stats_relu_pool_fwd", _f32(partials), P, N * Lo, _f32(rm), _f32(rv), L.ptr(cnt),
+                  _bn_momentum(momentum, nbt), float(eps), _f32(y), _f32(gamma), _f32(beta), _f32(mean), _f32(invstd),
+                  _f32(p), L.ptr(p_n16), N, Co, Lo, PX, shift, mode, _st())
         else:
             mean, invstd = bn_eval_stats(running_mean, running_var, eps)
-        N, _, Lo = y.shape
-        p_n16 = None
-        if gap:      # last block: AdaptiveAvgPool1d(1) folded in, the pooled tensor never exists
-            p = _empty(x, N, Co)
-            _call("ecg_bn_relu_pool_gap_fwd", _f32(y), _f32(gamma), _f32(beta), _f32(mean),
-                  _f32(invstd), _f32(p), N, Co, Lo, _st())
-        else:
-            p = _empty(x, N, Co, Lo // 2)
-            PX = 0
-            if bf16 and need_grad and next_geom is not None and Lo >= 2:
-                PX = _query("ecg_conv1d_n16_positions", Lo // 2, next_geom[0], next_geom[1], 1)
-            if PX:       # mixed precision: p also as the next conv's weight-gradient operand (bf16, n16 layout)
-                p_n16 = torch.empty(((N + 15) // 16) * Co * PX * 16, dtype=torch.bfloat16, device=x.device)
+            if gap:      # last block: AdaptiveAvgPool1d(1) folded in, the pooled tensor never exists
+                _call("ecg_bn_relu_pool_gap_fwd", _f32(y), _f32(gamma), _f32(beta), _f32(mean),
+                      _f32(invstd), _f32(p), N, Co, Lo, _st())
+            elif PX:
                 _call("ecg_bn_relu_pool_fwd_n16", _f32(y), _f32(gamma), _f32(beta), _f32(mean), _f32(invstd),
-                      _f32(p), L.ptr(p_n16), N, Co, Lo, PX, next_geom[1], _st())
-                ctx.mark_non_differentiable(p_n16)
-                ctx.set_materialize_grads(False)     # no zero-filled "gradient" for the n16 by-product (41 MB fill)
+                      _f32(p), L.ptr(p_n16), N, Co, Lo, PX, shift, _st())
             else:
                 _call("ecg_bn_relu_pool_fwd", _f32(y), _f32(gamma), _f32(beta), _f32(mean), _f32(invstd),
                       _f32(p), N, Co, Lo, _st())

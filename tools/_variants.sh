@@ -1,4 +1,11 @@
 set -o pipefail
 O=gpurun_out
-python -m pytest tests/test_gpu_ops.py -m gpu -q -k "full_size" > $O/r02i_tests.log 2>&1; echo "tests rc=$?"; tail -4 $O/r02i_tests.log
-bash tools/collect_profiles.sh r02 > $O/r02_collect.log 2>&1; echo "collect rc=$?"; tail -5 $O/r02_collect.log
+python -m pytest tests -m gpu -q -x > $O/r02j_tests.log 2>&1; echo "tests rc=$?"; tail -4 $O/r02j_tests.log
+python bench.py --steps 30 --warmup 5 --no-cpu-baseline > $O/r02j_bench.json 2>/dev/null
+python - <<'PY'
+import json
+d=json.loads(open('gpurun_out/r02j_bench.json').read().strip().splitlines()[-1])
+def show(x, name): print(name[:70], x['value'], x['ms_per_step'], x['step_ms']['median'], x['instrumented_ms_per_step'])
+show(d, d['config']['workload'])
+for a in d['also']: show(a, a['workload'])
+PY
