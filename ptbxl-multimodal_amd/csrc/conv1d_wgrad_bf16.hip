@@ -14,7 +14,9 @@
 //                      and outside the row (for X that bakes the conv's zero padding into the layout)
 //   conv1d_wgrad_bf16_kernel   workgroup tile M_T (co) x R_T (r = ci*15 + k); a stage = (sample group,
 //                      16 time steps); both operand tiles go global -> LDS by DMA (no registers, no
-//                      masks — the layouts already contain every zero); per time step one conflict-free
+//                      masks — the layouts already contain every zero; measured, NOT adopted: a 128 x 256
+//                      eight-wave tile with a 2- or 3-image DMA ring and the pieces issued between the MFMAs ran
+//                      at the same 190-200 us on block 3 of 12x5000 as this kernel); per time step one conflict-free
 //                      ds_read_b128 per fragment (the two 16-byte halves of a granule are XOR-swizzled by
 //                      bit 3 of the granule index; the x rows are 31 granules apart so that the column
 //                      index r maps to consecutive granules mod 16).  Split over stages into slabs that
@@ -127,14 +129,18 @@ __global__ __launch_bounds__(256, 3) void conv1d_wgrad_bf16_kernel(
     const bool want_bias = (tile_r == 0) && (wr == 0);
 
     // ---- DMA geometry: LDS slot -> element offset from the stage base (loop-invariant) -------------
-    // slot s = 2*granule + (half ^ bit3(granule)); A granule = t*M_T + co, B granule = ci_local*kXP + pos
+    // A image: [co][2*kTW 16-byte slots], slot (2t + half) of row co stored at slot ^ (co & 15): a DMA piece is two
+    // whole channel rows, i.e. two CONTIGUOUS 512-byte runs of the n16 tensor (a [t][co] image would gather 32 bytes
+    // from each of 32 rows 20 KB apart: a quarter of every line it touches), and the fragment read below — 32 lanes,
+    // 32 rows, one time step — still covers all banks once per 16-lane group.
+    // B image: slot = 2*granule + (half ^ bit3(granule)), granule = ci_local*kXP + pos (contiguous per channel row).
     int aoff[APW], boff[BPW];
 #pragma unroll
     for (int j = 0; j < APW; ++j) {
         const int sl = (j * 4 + wave) * 64 + lane;
-        const int qa = sl >> 1, h = (sl & 1) ^ ((qa >> 3) & 1);
-        const int t = qa / M_T, co = qa - t * M_T;
-        aoff[j] = (co * PA + t) * 16 + 8 * h;
+        const int co = sl / (2 * kTW), ls = sl - co * (2 * kTW);     // LDS slot ls of row co ...
+        const int gs = ls ^ (co & 15);                               // ... holds global slot gs = 2t + half
+        aoff[j] = (co * PA + (gs >> 1)) * 16 + 8 * (gs & 1);
     }
 #pragma unroll
     for (int j = 0; j < BPW; ++j) {
@@ -166,8 +172,8 @@ __global__ __launch_bounds__(256, 3) void conv1d_wgrad_bf16_kernel(
         auto ld = [&](int t, bf16x8 *a, bf16x8 *b) {
 #pragma unroll
             for (int i = 0; i < MC; ++i) {
-                const int qa = t * M_T + wm0 + 32 * i + l31;
-                a[i] = *reinterpret_cast<const bf16x8 *>(aimg + (2 * qa + (half ^ ((qa >> 3) & 1))) * 16);
+                const int co = wm0 + 32 * i + l31;
+                a[i] = *reinterpret_cast<const bf16x8 *>(aimg + (co * (2 * kTW) + ((2 * t + half) ^ (co & 15))) * 16);
             }
 #pragma unroll
             for (int j = 0; j < MR; ++j) {

@@ -207,8 +207,10 @@ def test_row_padded_dy_entry_points(hip, oracle, case):
     np.testing.assert_allclose(host(dx), oracle.conv1d_bwd_data(dy, w, Lin, pad), atol=5e-5)
     rdw, rdb = oracle.conv1d_bwd_weight(dy, x, K, pad)
     scale = np.sqrt(N * Lin)
-    np.testing.assert_allclose(host(dw), rdw, atol=2e-6 * scale + 2e-5)
-    np.testing.assert_allclose(host(db), rdb, atol=2e-6 * scale + 2e-5)
+    # fp32 accumulation of N*L exact bf16 products in a different order than the oracle's doubles: a few ulp of the
+    # largest entries (the number of splits, i.e. the chain length, depends on the tile plan)
+    np.testing.assert_allclose(host(dw), rdw, atol=3e-6 * float(np.abs(rdw).max()) + 2e-5)
+    np.testing.assert_allclose(host(db), rdb, atol=3e-6 * float(np.abs(rdb).max()) + 2e-6 * scale + 2e-5)
     np.testing.assert_allclose(host(dw), host(dw0), atol=2e-6 * scale + 2e-5)
 
 
@@ -229,8 +231,10 @@ def test_row_padded_dy_first_layer_weight_grad(hip, oracle, case):
     _, dw, db = hip.conv1d_backward_raw(xd, dyd, (Co, Ci, 15), None, 7, need_dx=False, ldy=ldy)
     rdw, rdb = oracle.conv1d_bwd_weight(dy, x, 15, 7)
     scale = np.sqrt(N * Lin)
-    np.testing.assert_allclose(host(dw), rdw, atol=2e-6 * scale + 2e-5)
-    np.testing.assert_allclose(host(db), rdb, atol=2e-6 * scale + 2e-5)
+    # fp32 accumulation of N*L exact bf16 products in a different order than the oracle's doubles: a few ulp of the
+    # largest entries (the number of splits, i.e. the chain length, depends on the tile plan)
+    np.testing.assert_allclose(host(dw), rdw, atol=3e-6 * float(np.abs(rdw).max()) + 2e-5)
+    np.testing.assert_allclose(host(db), rdb, atol=3e-6 * float(np.abs(rdb).max()) + 2e-6 * scale + 2e-5)
 
 
 def test_row_padded_dy_is_refused_where_unsupported(hip):
@@ -632,8 +636,10 @@ def test_bf16_weight_grad_is_exact_on_bf16_rounded_operands(hip, oracle, case, p
            N, Ci, Co, Lin, 15, 7, L.stream())
     rdw, rdb = oracle.conv1d_bwd_weight(_bf16_round(dy), _bf16_round(x), 15, 7)
     scale = np.sqrt(N * Lin)
-    np.testing.assert_allclose(host(dw), rdw, atol=2e-6 * scale + 2e-5)
-    np.testing.assert_allclose(host(db), rdb, atol=2e-6 * scale + 2e-5)
+    # fp32 accumulation of N*L exact bf16 products in a different order than the oracle's doubles: a few ulp of the
+    # largest entries (the number of splits, i.e. the chain length, depends on the tile plan)
+    np.testing.assert_allclose(host(dw), rdw, atol=3e-6 * float(np.abs(rdw).max()) + 2e-5)
+    np.testing.assert_allclose(host(db), rdb, atol=3e-6 * float(np.abs(rdb).max()) + 2e-6 * scale + 2e-5)
     full, _ = oracle.conv1d_bwd_weight(dy, x, 15, 7)            # and a bf16-accurate approximation of the fp32 result
     assert np.abs(host(dw) - full).max() < 0.02 * scale
     with pytest.raises(L.EcgHipError, match="C_out"):
