@@ -38,6 +38,22 @@ constexpr int kCB = 16;      // input channels per MFMA (its K dimension)
 
 __device__ __forceinline__ int acc_row_b(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }
 
+// s_waitcnt lgkmcnt(n) with vmcnt / expcnt left at "no wait" (n is a compile-time constant after unrolling)
+__device__ __forceinline__ void wait_lgkm(int n) {
+    switch (n) {
+        case 0: __builtin_amdgcn_s_waitcnt(0xC07F); break;
+        case 1: __builtin_amdgcn_s_waitcnt(0xC17F); break;
+        case 2: __builtin_amdgcn_s_waitcnt(0xC27F); break;
+        case 3: __builtin_amdgcn_s_waitcnt(0xC37F); break;
+        case 4: __builtin_amdgcn_s_waitcnt(0xC47F); break;
+        case 5: __builtin_amdgcn_s_waitcnt(0xC57F); break;
+        case 6: __builtin_amdgcn_s_waitcnt(0xC67F); break;
+        case 7: __builtin_amdgcn_s_waitcnt(0xC77F); break;
+        case 8: __builtin_amdgcn_s_waitcnt(0xC87F); break;
+        default: break;                                   // more than the counter is worth tracking: let the compiler decide
+    }
+}
+
 __device__ __forceinline__ unsigned pack2_bf16(float lo, float hi) {
     const u16 a = __builtin_bit_cast(u16, (__bf16)lo), b = __builtin_bit_cast(u16, (__bf16)hi);
     return (unsigned)a | ((unsigned)b << 16);
@@ -276,6 +292,11 @@ __global__ __launch_bounds__(64 * WCO * WT) void conv1d_mfma_bf16_fwd_kernel(
 #pragma unroll
         for (int k = 0; k < KK; ++k) {
             ld(k + 1 < KK ? k + 1 : 0, a_n, b_n);
+            // The MFMAs below need the fragments read ONE step ago; the MC + MT reads just issued may stay in flight.
+            // Left alone, hipcc waits lgkmcnt(0) on every second step and after every LDS-DMA issue — the full LDS
+            // latency of the reads just issued, in front of MFMAs that do not need them.  The explicit counted wait
+            // sits BEFORE the staging operation so that the compiler sees the operands complete at that point.
+            wait_lgkm(MC + MT);
 #pragma unroll
             for (int o = k * OPS; o < (k + 1) * OPS; ++o) {      // weight DMA pieces first (longest latency), x commits, x loads;
                 if (o < DPW) dma_w(o, wnext, nxt);               // all UNCONDITIONAL: stages past the end restage valid data

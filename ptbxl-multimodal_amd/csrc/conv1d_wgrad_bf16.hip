@@ -37,6 +37,18 @@ constexpr int kXP = 31;        // x-tile granules per channel row: >= kTW + 14, 
 
 __device__ __forceinline__ int acc_row_w(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }
 
+// s_waitcnt lgkmcnt(n), vmcnt / expcnt left at "no wait" (n compile-time after unrolling)
+__device__ __forceinline__ void wait_lgkm_w(int n) {
+    switch (n) {
+        case 2: __builtin_amdgcn_s_waitcnt(0xC27F); break;
+        case 3: __builtin_amdgcn_s_waitcnt(0xC37F); break;
+        case 4: __builtin_amdgcn_s_waitcnt(0xC47F); break;
+        case 5: __builtin_amdgcn_s_waitcnt(0xC57F); break;
+        case 6: __builtin_amdgcn_s_waitcnt(0xC67F); break;
+        default: break;
+    }
+}
+
 __device__ __forceinline__ unsigned pack2(float lo, float hi) {
     const u16 a = __builtin_bit_cast(u16, (__bf16)lo), b = __builtin_bit_cast(u16, (__bf16)hi);
     return (unsigned)a | ((unsigned)b << 16);
@@ -186,6 +198,7 @@ __global__ __launch_bounds__(256, 3) void conv1d_wgrad_bf16_kernel(
 #pragma unroll
         for (int t = 0; t < kTW; ++t) {
             ld(t + 1 < kTW ? t + 1 : 0, a_n, b_n);
+            wait_lgkm_w(MC + MR);        // the MFMAs need the fragments read one step ago, not the ones just issued
             __builtin_amdgcn_sched_barrier(0);
             if (want_bias) {                      // db rides on the A fragments (bf16-rounded dY, fp32 sum)
 #pragma unroll
