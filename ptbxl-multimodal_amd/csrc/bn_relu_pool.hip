@@ -11,6 +11,18 @@ namespace ecg {
 
 constexpr int kBlock = 256;
 
+// the pooling pair (r[0], r[1]) as ONE 8-byte load when the pair is 8-byte aligned (even row length: every row of
+// the 12x1000 / 12x5000 models except the last block's), two 4-byte loads otherwise (AL8 is chosen per launch by the host)
+template <bool AL8>
+__device__ __forceinline__ void ld_pair(const float *r, float &a, float &b) {
+    if (AL8) {
+        const float2 v = *reinterpret_cast<const float2 *>(r);
+        a = v.x; b = v.y;
+    } else {
+        a = r[0]; b = r[1];
+    }
+}
+
 // ---------------------------------------------------------------------------------------
 // statistics
 // ---------------------------------------------------------------------------------------
@@ -104,7 +116,7 @@ __global__ void bn_invstd_kernel(const float *__restrict__ var, float *__restric
 // ---------------------------------------------------------------------------------------
 // grid = (C, S2): a block owns channel c and the samples of split s2 and walks their pooled positions flat, four
 // iterations in flight (loads unconditional, clamped); a wave reads 512 contiguous bytes of y and writes 256 of p.
-template <bool FIN>
+template <bool FIN, bool AL8>
 __global__ __launch_bounds__(kBlock) void bn_relu_pool_fwd_kernel(
     const float *__restrict__ y, const float *__restrict__ gamma, const float *__restrict__ beta,
     const float *__restrict__ mean, const float *__restrict__ invstd, float *__restrict__ p,
@@ -128,8 +140,7 @@ __global__ __launch_bounds__(kBlock) void bn_relu_pool_fwd_kernel(
             const int ic = live[u] ? idx : tl;
             const int nl = ic / Lp, j = ic - nl * Lp;
             const size_t row = (size_t)(n0 + nl) * C + c;
-            const float *r = y + row * L + 2 * j;
-            y0[u] = r[0]; y1[u] = r[1];
+            ld_pair<AL8>(y + row * L + 2 * j, y0[u], y1[u]);
             out[u] = row * Lp + j;
         }
 #pragma unroll
@@ -195,7 +206,7 @@ __device__ __forceinline__ bool pool_route(float y0, float y1, float mu, float s
 // otherwise da = dout (plain BatchNorm backward).  grid = (C, S).
 // bcast != 0 (FUSED only): dp[row][j] = g[row] * bcast for every j — the gradient of a global
 // average pool that was fused behind the max-pool (g = dG [N*C], bcast = 1/Lp).
-template <bool FUSED>
+template <bool FUSED, bool AL8>
 __global__ __launch_bounds__(kBlock) void bn_bwd_reduce_kernel(
     const float *__restrict__ y, const float *__restrict__ g, const float *__restrict__ gamma,
     const float *__restrict__ beta, const float *__restrict__ mean,
@@ -226,7 +237,7 @@ __global__ __launch_bounds__(kBlock) void bn_bwd_reduce_kernel(
             const size_t row = (size_t)(n0 + nl) * C + c;
             const float *r = y + row * L;
             if (FUSED) {
-                y0[u] = r[2 * j]; y1[u] = r[2 * j + 1];
+                ld_pair<AL8>(r + 2 * j, y0[u], y1[u]);
                 d[u] = bcast != 0.f ? g[row] * bcast : g[row * Lp + j];
             } else {
                 y0[u] = r[j]; y1[u] = 0.f;
@@ -263,7 +274,7 @@ __global__ __launch_bounds__(kBlock) void bn_bwd_reduce_kernel(
 // numbers out of L2 — instead of a separate 4.9 us launch per layer; block s2 == 0 writes dbeta / dgamma.
 // dy rows have stride ldy >= L; the pad [L, ldy) is written as zeros (Lh = ceil(ldy/2) pairs per row): the
 // weight-gradient kernel streams such rows by LDS-DMA and needs the zeros.
-template <bool FUSED>
+template <bool FUSED, bool AL8>
 __global__ __launch_bounds__(kBlock) void bn_bwd_dx_kernel(
     const float *__restrict__ y, const float *__restrict__ g, const float *__restrict__ gamma,
     const float *__restrict__ beta, const float *__restrict__ mean,
@@ -316,7 +327,8 @@ __global__ __launch_bounds__(kBlock) void bn_bwd_dx_kernel(
             rowv[u] = row; t0[u] = 2 * j;
             const float *r = y + row * L;
             const int ta = min(2 * j, L - 1), tb = min(2 * j + 1, L - 1);
-            y0[u] = r[ta]; y1[u] = r[tb];
+            if (AL8) ld_pair<true>(r + min(2 * j, L - 2), y0[u], y1[u]);      // (pad pairs read the row's last pair: unused)
+            else { y0[u] = r[ta]; y1[u] = r[tb]; }
             if (FUSED) {
                 d0[u] = bcast != 0.f ? g[row] * bcast : (Lp > 0 ? g[row * (size_t)Lp + min(j, Lp - 1)] : 0.f);
                 d1[u] = 0.f;
@@ -383,7 +395,7 @@ __device__ __forceinline__ void store_n16(u16n *dst, const float *v) {
 
 // p [N][C][Lp] fp32 (may be NULL) and pb[g][c][pos][16] with pb[.., j + shift, s] = p[16g + s][c][j].
 // grid = (ceil(PX/256), C, G)
-template <bool FIN>
+template <bool FIN, bool AL8>
 __global__ __launch_bounds__(kBlock) void bn_relu_pool_fwd_n16_kernel(
     const float *__restrict__ y, const float *__restrict__ gamma, const float *__restrict__ beta,
     const float *__restrict__ mean, const float *__restrict__ invstd, float *__restrict__ p,
@@ -399,10 +411,8 @@ __global__ __launch_bounds__(kBlock) void bn_relu_pool_fwd_n16_kernel(
     const int jc = min(max(j, 0), Lp - 1);
     float y0[16], y1[16];
 #pragma unroll
-    for (int s = 0; s < 16; ++s) {                   // 32 unconditional, clamped loads in flight
-        const float *r = y + ((size_t)min(16 * g + s, N - 1) * C + c) * L + 2 * jc;
-        y0[s] = r[0]; y1[s] = r[1];
-    }
+    for (int s = 0; s < 16; ++s)                     // 16 unconditional, clamped pair loads in flight
+        ld_pair<AL8>(y + ((size_t)min(16 * g + s, N - 1) * C + c) * L + 2 * jc, y0[s], y1[s]);
     __builtin_amdgcn_sched_barrier(0);
     float v[16];
 #pragma unroll
@@ -420,6 +430,7 @@ __global__ __launch_bounds__(kBlock) void bn_relu_pool_fwd_n16_kernel(
 // dy [N][C][ldy] fp32 (may be NULL: the first layer has no input gradient) and dyb[g][c][t][16], t < PA, zero
 // past the row; the combine of the S reduce partials is folded in as in bn_bwd_dx_kernel.
 // grid = (ceil(PA/2/256), C, G); thread <-> output pair (2j, 2j+1) of the 16 samples of group g.
+template <bool AL8>
 __global__ __launch_bounds__(kBlock) void bn_bwd_dx_n16_kernel(
     const float *__restrict__ y, const float *__restrict__ g_in, const float *__restrict__ gamma,
     const float *__restrict__ beta, const float *__restrict__ mean, const float *__restrict__ invstd,
@@ -461,7 +472,8 @@ __global__ __launch_bounds__(kBlock) void bn_bwd_dx_n16_kernel(
 #pragma unroll
     for (int s = 0; s < 16; ++s) {                   // 48 unconditional, clamped loads in flight
         const size_t row = (size_t)min(16 * g + s, N - 1) * C + c;
-        y0[s] = y[row * L + ta]; y1[s] = y[row * L + tb];
+        if (AL8) ld_pair<true>(y + row * L + min(t0, L - 2), y0[s], y1[s]);      // (pad pairs read the row's last pair: unused)
+        else { y0[s] = y[row * L + ta]; y1[s] = y[row * L + tb]; }
         d[s] = bcast != 0.f ? g_in[row] * bcast : (Lp > 0 ? g_in[row * Lp + jc] : 0.f);
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -533,6 +545,9 @@ __global__ void maxpool2_bwd_kernel(const float *__restrict__ x, const float *__
 
 using namespace ecg;
 
+// every pooling pair (2j, 2j+1) of every row is 8-byte aligned: even rows from an 8-byte aligned base
+static bool pairs_aligned(const float *y, int L) { return (L & 1) == 0 && (reinterpret_cast<uintptr_t>(y) & 7) == 0; }
+
 static int check_ncl(const char *who, int N, int C, int L) {
     ECG_REQUIRE(N > 0 && C > 0 && L > 0, "%s: N=%d C=%d L=%d must be > 0", who, N, C, L);
     ECG_REQUIRE(C <= 65535 && N <= 65535, "%s: N/C exceed grid limits", who);
@@ -592,12 +607,13 @@ static int pool_fwd_impl(const BnFin *fin, const float *y, const float *gamma, c
     ECG_REQUIRE(p || Lp == 0, "bn_relu_pool_fwd: null output");
     int S2 = cdiv(4096, C);
     if (S2 > N) S2 = N;
-    if (fin)
-        hipLaunchKernelGGL(bn_relu_pool_fwd_kernel<true>, dim3(C, S2), dim3(kBlock), 0, st, y, gamma, beta, mean,
-                           invstd, p, N, C, L, Lp, S2, *fin);
-    else
-        hipLaunchKernelGGL(bn_relu_pool_fwd_kernel<false>, dim3(C, S2), dim3(kBlock), 0, st, y, gamma, beta, mean,
-                           invstd, p, N, C, L, Lp, S2, BnFin{});
+    const bool al8 = pairs_aligned(y, L);
+    const BnFin f = fin ? *fin : BnFin{};
+#define ECG_POOL(FIN, AL8) hipLaunchKernelGGL((bn_relu_pool_fwd_kernel<FIN, AL8>), dim3(C, S2), dim3(kBlock), 0, st, y, gamma, \
+                                              beta, mean, invstd, p, N, C, L, Lp, S2, f)
+    if (fin) { if (al8) ECG_POOL(true, true); else ECG_POOL(true, false); }
+    else { if (al8) ECG_POOL(false, true); else ECG_POOL(false, false); }
+#undef ECG_POOL
     return check_launch("bn_relu_pool_fwd_kernel");
 }
 
@@ -629,12 +645,14 @@ static int pool_fwd_n16_impl(const BnFin *fin, const float *y, const float *gamm
                 PX, Lp, shift);
     ECG_REQUIRE((reinterpret_cast<uintptr_t>(p_n16) & 15) == 0, "bn_relu_pool_fwd_n16: n16 output must be 16-byte aligned");
     const int G = cdiv(N, 16);
-    if (fin)
-        hipLaunchKernelGGL(bn_relu_pool_fwd_n16_kernel<true>, dim3(cdiv(PX, kBlock), C, G), dim3(kBlock), 0, st, y,
-                           gamma, beta, mean, invstd, p, static_cast<u16n *>(p_n16), N, C, L, Lp, PX, shift, *fin);
-    else
-        hipLaunchKernelGGL(bn_relu_pool_fwd_n16_kernel<false>, dim3(cdiv(PX, kBlock), C, G), dim3(kBlock), 0, st, y,
-                           gamma, beta, mean, invstd, p, static_cast<u16n *>(p_n16), N, C, L, Lp, PX, shift, BnFin{});
+    const bool al8 = pairs_aligned(y, L);
+    const BnFin f = fin ? *fin : BnFin{};
+#define ECG_POOLN(FIN, AL8) hipLaunchKernelGGL((bn_relu_pool_fwd_n16_kernel<FIN, AL8>), dim3(cdiv(PX, kBlock), C, G), \
+                                               dim3(kBlock), 0, st, y, gamma, beta, mean, invstd, p,                   \
+                                               static_cast<u16n *>(p_n16), N, C, L, Lp, PX, shift, f)
+    if (fin) { if (al8) ECG_POOLN(true, true); else ECG_POOLN(true, false); }
+    else { if (al8) ECG_POOLN(false, true); else ECG_POOLN(false, false); }
+#undef ECG_POOLN
     return check_launch("bn_relu_pool_fwd_n16_kernel");
 }
 
@@ -688,16 +706,25 @@ static int bn_bwd_impl(const float *y, const float *g, const float *gamma, const
                        hipStream_t st, float bcast = 0.f) {
     const int S = stat_splits(N, C);
     float *partials = ws;
-    hipLaunchKernelGGL((bn_bwd_reduce_kernel<FUSED>), dim3(C, S), dim3(kBlock), 0, st, y, g, gamma,
-                       beta, mean, invstd, partials, N, C, L, S, bcast);
+    const bool al8 = FUSED && pairs_aligned(y, L);
+    if (al8)
+        hipLaunchKernelGGL((bn_bwd_reduce_kernel<FUSED, true>), dim3(C, S), dim3(kBlock), 0, st, y, g, gamma,
+                           beta, mean, invstd, partials, N, C, L, S, bcast);
+    else
+        hipLaunchKernelGGL((bn_bwd_reduce_kernel<FUSED, false>), dim3(C, S), dim3(kBlock), 0, st, y, g, gamma,
+                           beta, mean, invstd, partials, N, C, L, S, bcast);
     int rc = check_launch("bn_bwd_reduce_kernel");
     if (rc) return rc;
     // dx pass with the combine of the reduce partials folded in (no finalize launch)
     const int Lh = (ldy + 1) / 2;
     int S2 = cdiv(4096, C);            // ~4096 blocks: enough to keep every CU streaming
     if (S2 > N) S2 = N;
-    hipLaunchKernelGGL((bn_bwd_dx_kernel<FUSED>), dim3(C, S2), dim3(kBlock), 0, st, y, g, gamma, beta, mean,
-                       invstd, partials, S, (double)N * L, dgamma, dbeta, dy, N, C, L, ldy, Lh, S2, bcast, train);
+    if (pairs_aligned(y, L) && L >= 2)
+        hipLaunchKernelGGL((bn_bwd_dx_kernel<FUSED, true>), dim3(C, S2), dim3(kBlock), 0, st, y, g, gamma, beta, mean,
+                           invstd, partials, S, (double)N * L, dgamma, dbeta, dy, N, C, L, ldy, Lh, S2, bcast, train);
+    else
+        hipLaunchKernelGGL((bn_bwd_dx_kernel<FUSED, false>), dim3(C, S2), dim3(kBlock), 0, st, y, g, gamma, beta, mean,
+                           invstd, partials, S, (double)N * L, dgamma, dbeta, dy, N, C, L, ldy, Lh, S2, bcast, train);
     return check_launch("bn_bwd_dx_kernel");
 }
 
@@ -816,13 +843,23 @@ ECG_API int ecg_bn_relu_pool_bwd_n16(const float *y, const float *dp, const floa
     const float bcast = gap ? 1.0f / (float)(L / 2) : 0.f;
     const int S = stat_splits(N, C);
     hipStream_t st = as_stream(stream);
-    hipLaunchKernelGGL((bn_bwd_reduce_kernel<true>), dim3(C, S), dim3(kBlock), 0, st, y, dp, gamma, beta, mean,
-                       invstd, ws, N, C, L, S, bcast);
+    const bool al8 = pairs_aligned(y, L);
+    if (al8)
+        hipLaunchKernelGGL((bn_bwd_reduce_kernel<true, true>), dim3(C, S), dim3(kBlock), 0, st, y, dp, gamma, beta, mean,
+                           invstd, ws, N, C, L, S, bcast);
+    else
+        hipLaunchKernelGGL((bn_bwd_reduce_kernel<true, false>), dim3(C, S), dim3(kBlock), 0, st, y, dp, gamma, beta, mean,
+                           invstd, ws, N, C, L, S, bcast);
     rc = check_launch("bn_bwd_reduce_kernel");
     if (rc) return rc;
     const int G = cdiv(N, 16);
-    hipLaunchKernelGGL(bn_bwd_dx_n16_kernel, dim3(cdiv(PA / 2, kBlock), C, G), dim3(kBlock), 0, st, y, dp, gamma, beta,
-                       mean, invstd, ws, S, (double)N * L, dgamma, dbeta, dy, ldy, static_cast<u16n *>(dy_n16), PA, N,
-                       C, L, bcast, train);
+    if (al8)
+        hipLaunchKernelGGL(bn_bwd_dx_n16_kernel<true>, dim3(cdiv(PA / 2, kBlock), C, G), dim3(kBlock), 0, st, y, dp, gamma,
+                           beta, mean, invstd, ws, S, (double)N * L, dgamma, dbeta, dy, ldy, static_cast<u16n *>(dy_n16),
+                           PA, N, C, L, bcast, train);
+    else
+        hipLaunchKernelGGL(bn_bwd_dx_n16_kernel<false>, dim3(cdiv(PA / 2, kBlock), C, G), dim3(kBlock), 0, st, y, dp, gamma,
+                           beta, mean, invstd, ws, S, (double)N * L, dgamma, dbeta, dy, ldy, static_cast<u16n *>(dy_n16),
+                           PA, N, C, L, bcast, train);
     return check_launch("bn_bwd_dx_n16_kernel");
 }
