@@ -43,7 +43,7 @@ CONV_GEOM = [(12, 32), (32, 64), (64, 128), (128, 256)]
 FWD, DGRAD, WGRAD = "fwd", "dgrad", "wgrad"
 CONV_ENTRY = {"ecg_conv1d_fwd": (FWD, "f32"), "ecg_conv1d_fwd_bf16": (FWD, "bf16"),
               "ecg_conv1d_bwd_data": (DGRAD, "f32"), "ecg_conv1d_bwd_data_ld": (DGRAD, "f32"),
-              "ecg_conv1d_bwd_data_bf16": (DGRAD, "bf16"),
+              "ecg_conv1d_bwd_data_bf16": (DGRAD, "bf16"), "ecg_conv1d_bwd_data_bf16h": (DGRAD, "bf16"),
               "ecg_conv1d_bwd_weight_bias": (WGRAD, "f32"), "ecg_conv1d_bwd_weight_bias_ld": (WGRAD, "f32"),
               "ecg_conv1d_bwd_weight_bias_bf16": (WGRAD, "bf16"), "ecg_conv1d_bwd_weight_bias_bf16_packed": (WGRAD, "bf16")}
 

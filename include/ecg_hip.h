@@ -145,7 +145,7 @@ int ecg_conv1d_bwd_data_bf16(const float *dy, const void *wb_bwd, float *dx, int
  *   ecg_bn_relu_pool_fwd_n16: ecg_bn_relu_pool_fwd that ALSO writes the pooled activation as the next layer's x
  *     operand (p may be NULL when only the n16 form is wanted).
  *   ecg_bn_relu_pool_bwd_n16: ecg_bn_relu_pool_bwd_ld (gap != 0: ..._gap_bwd_ld) that ALSO writes dY as the dY
- *     operand; dy may be NULL when no input gradient follows (first layer).
+ *     operand; dy may be NULL when no fp32 dY is wanted (first layer, or when dy_bf16 feeds the input gradient).
  *   ecg_conv1d_bwd_weight_bias_bf16_packed: the weight gradient on operands already in that layout; workspace
  *     (slabs only) from ecg_conv1d_bwd_weight_bf16_packed_ws_floats. */
 int ecg_conv1d_n16_positions(int L, int K, int pad, int which);
@@ -157,7 +157,11 @@ int ecg_bn_relu_pool_fwd_n16(const float *y, const float *gamma, const float *be
 int ecg_bn_relu_pool_bwd_n16(const float *y, const float *dp, const float *gamma, const float *beta,
                              const float *mean, const float *invstd, float *dy, int ldy, void *dy_n16,
                              int PA, float *dgamma, float *dbeta, float *ws, int N, int C, int L,
-                             int train, int gap, ecg_stream_t stream);
+                             int train, int gap, void *dy_bf16, ecg_stream_t stream);
+/* dy_bf16 (may be NULL): dY once more as bf16 [N][C][PA] (rows zero-filled past L) for ecg_conv1d_bwd_data_bf16h, the
+ * input gradient that reads a bf16 dY (ldy even, K-1-pad odd): half the bytes of the fp32 dY on both sides. */
+int ecg_conv1d_bwd_data_bf16h(const void *dy_bf16, int ldy, const void *wb_bwd, float *dx, int N, int C_in,
+                              int C_out, int L, int K, int pad, ecg_stream_t stream);
 size_t ecg_conv1d_bwd_weight_bf16_packed_ws_floats(int N, int C_in, int C_out, int L, int K, int pad);
 int ecg_conv1d_bwd_weight_bias_bf16_packed(const void *dy_n16, const void *x_n16, float *dw, float *db,
                                            float *ws, int N, int C_in, int C_out, int L, int K, int pad,

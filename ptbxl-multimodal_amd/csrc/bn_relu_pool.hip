@@ -436,7 +436,7 @@ __global__ __launch_bounds__(kBlock) void bn_bwd_dx_n16_kernel(
     const float *__restrict__ beta, const float *__restrict__ mean, const float *__restrict__ invstd,
     const float *__restrict__ partials, int S, double M, float *__restrict__ dgamma,
     float *__restrict__ dbeta, float *__restrict__ dy, int ldy, u16n *__restrict__ dyb, int PA, int N,
-    int C, int L, float bcast, int train) {
+    int C, int L, float bcast, int train, unsigned *__restrict__ dyh) {
     __shared__ double red[4][2];
     __shared__ float kk[2];
     const int c = blockIdx.y, g = blockIdx.z, tl = threadIdx.x;
@@ -495,6 +495,8 @@ __global__ __launch_bounds__(kBlock) void bn_bwd_dx_n16_kernel(
             if (t0 < ldy) dr[t0] = v0[s];
             if (t0 + 1 < ldy) dr[t0 + 1] = v1[s];
         }
+        // bf16 [N][C][PA] for the input-gradient conv (rows zero-filled past L: v0 / v1 are 0 there): one dword per pair
+        if (dyh && valid) dyh[(((size_t)(16 * g + s) * C + c) * PA + t0) >> 1] = pack2n(v0[s], v1[s]);
     }
     u16n *o = dyb + (((size_t)g * C + c) * PA + t0) * 16;
     store_n16(o, v0);
@@ -832,7 +834,7 @@ ECG_API int ecg_bn_relu_pool_gap_bwd(const float *y, const float *dg, const floa
 ECG_API int ecg_bn_relu_pool_bwd_n16(const float *y, const float *dp, const float *gamma, const float *beta,
                                      const float *mean, const float *invstd, float *dy, int ldy, void *dy_n16,
                                      int PA, float *dgamma, float *dbeta, float *ws, int N, int C, int L,
-                                     int train, int gap, ecg_stream_t stream) {
+                                     int train, int gap, void *dy_bf16, ecg_stream_t stream) {
     int rc = check_ncl("bn_relu_pool_bwd_n16", N, C, L);
     if (rc) return rc;
     ECG_REQUIRE(y && dp && gamma && beta && mean && invstd && dy_n16 && ws, "bn_relu_pool_bwd_n16: null pointer");
@@ -840,6 +842,7 @@ ECG_API int ecg_bn_relu_pool_bwd_n16(const float *y, const float *dp, const floa
     ECG_REQUIRE(PA >= L && PA % 2 == 0, "bn_relu_pool_bwd_n16: PA=%d must be even and >= L=%d", PA, L);
     ECG_REQUIRE(!dy || (ldy >= L && ldy <= PA), "bn_relu_pool_bwd_n16: dY row stride %d outside [L, PA]", ldy);
     ECG_REQUIRE((reinterpret_cast<uintptr_t>(dy_n16) & 15) == 0, "bn_relu_pool_bwd_n16: n16 output must be 16-byte aligned");
+    ECG_REQUIRE((reinterpret_cast<uintptr_t>(dy_bf16) & 3) == 0, "bn_relu_pool_bwd_n16: bf16 dY must be 4-byte aligned");
     const float bcast = gap ? 1.0f / (float)(L / 2) : 0.f;
     const int S = stat_splits(N, C);
     hipStream_t st = as_stream(stream);
@@ -856,10 +859,10 @@ ECG_API int ecg_bn_relu_pool_bwd_n16(const float *y, const float *dp, const floa
     if (al8)
         hipLaunchKernelGGL(bn_bwd_dx_n16_kernel<true>, dim3(cdiv(PA / 2, kBlock), C, G), dim3(kBlock), 0, st, y, dp, gamma,
                            beta, mean, invstd, ws, S, (double)N * L, dgamma, dbeta, dy, ldy, static_cast<u16n *>(dy_n16),
-                           PA, N, C, L, bcast, train);
+                           PA, N, C, L, bcast, train, static_cast<unsigned *>(dy_bf16));
     else
         hipLaunchKernelGGL(bn_bwd_dx_n16_kernel<false>, dim3(cdiv(PA / 2, kBlock), C, G), dim3(kBlock), 0, st, y, dp, gamma,
                            beta, mean, invstd, ws, S, (double)N * L, dgamma, dbeta, dy, ldy, static_cast<u16n *>(dy_n16),
-                           PA, N, C, L, bcast, train);
+                           PA, N, C, L, bcast, train, static_cast<unsigned *>(dy_bf16));
     return check_launch("bn_bwd_dx_n16_kernel");
 }

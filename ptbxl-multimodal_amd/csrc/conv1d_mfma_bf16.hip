@@ -102,11 +102,14 @@ __global__ void pack_weights_bf16_kernel(const float *__restrict__ w, u16 *__res
 //     lane group pairs up are 8 or 24 apart, for any tap shift): conflict-free, one LDS cycle per 16 lanes.
 //   * BN statistics stay in registers until the workgroup ends (16-lane DPP row sums kept in lanes r / r+16 of one
 //     VGPR per 32 channels): one (sum, sum^2) partial per (channel, workgroup), P = G.
-template <int CO_T, int T_T, int WCO, int WT, bool STATS>
+//   * XH: the input itself is bf16 ([N][C_in][ldx] u16, rows zero-filled past L, ldx even) — the input-gradient
+//     conv reads the dY the BatchNorm backward wrote in bf16.  An item is then a PAIR of positions (2i-1, 2i) of four
+//     channels: four aligned 4-byte loads (half the bytes, half the loads of the fp32 input) feeding two LDS rows.
+template <int CO_T, int T_T, int WCO, int WT, bool STATS, bool XH = false>
 __global__ __launch_bounds__(64 * WCO * WT) void conv1d_mfma_bf16_fwd_kernel(
     const float *__restrict__ x, const u16 *__restrict__ wb, const float *__restrict__ bias,
     float *__restrict__ y, float *__restrict__ partials, int Cin, int Cout, int L, int Lo, int pad,
-    int tiles_t, int N, int G) {
+    int tiles_t, int N, int G, int ldx) {
     constexpr int NW = WCO * WT, NT = 64 * NW;
     static_assert(NW == 4 || NW == 8, "4 or 8 waves per workgroup");
     constexpr int KK = kKB;
@@ -118,7 +121,8 @@ __global__ __launch_bounds__(64 * WCO * WT) void conv1d_mfma_bf16_fwd_kernel(
     constexpr int DPW = (NDMA + NW - 1) / NW;
     constexpr int WPADB = NDMA * 1024;                   // every wave issues DPW pieces unconditionally: pieces past the
                                                          // slice repeat its last piece (same bytes, same place)
-    constexpr int XITEMS = SPAN * 4;                     // (pos, quarter of 4 channels)
+    constexpr int NPAIR = SPAN / 2 + 1;                  // XH: position pairs (2i-1, 2i), i = 0 .. SPAN/2
+    constexpr int XITEMS = XH ? NPAIR * 4 : SPAN * 4;    // (pos or pos pair, quarter of 4 channels)
     constexpr int XL = (XITEMS + NT - 1) / NT;
     constexpr int XBYTES = ((SPAN * kCB * 2 + 8 + 15) / 16) * 16;   // every thread commits XL items unconditionally: items
                                                          // past the tile all land in one dummy slot behind it
@@ -179,25 +183,35 @@ __global__ __launch_bounds__(64 * WCO * WT) void conv1d_mfma_bf16_fwd_kernel(
         const int col = rem >> 5, sh = (rem >> 4) & 1;                       // LDS half sh of row col holds half sh ^ bit3(col)
         woff[j] = (k * Cout + co0) * kCB * 2 + col * 32 + ((sh ^ ((col >> 3) & 1)) << 4);   // byte offset in the global chunk
     }
-    int xdst[XL], xq4[XL], xpm[XL];
+    // fp32 input: item = (pos, quarter); bf16 input: item = (pair i -> positions 2i-1 and 2i, quarter)
+    int xdst[XL], xdst1[XL], xq4[XL], xpm[XL];
 #pragma unroll
     for (int j = 0; j < XL; ++j) {
         const int it = tid + NT * j;
         const int itc = min(it, XITEMS - 1);
-        const int q = itc / SPAN, pos = itc - q * SPAN;
+        const int per = XH ? NPAIR : SPAN;
+        const int q = itc / per, pi = itc - q * per;
+        const int pos = XH ? 2 * pi - 1 : pi, pos1 = 2 * pi;
         xq4[j] = 4 * q;                 // first channel of the quarter inside the chunk
-        xpm[j] = pos - pad;             // sequence index relative to the tile origin
-        // quarter q = channels 4q..4q+3 of position pos: half (q >> 1), stored swapped when bit 3 of pos is set
-        xdst[j] = it < XITEMS ? pos * 32 + ((((q >> 1) ^ (pos >> 3)) & 1) << 4) + (q & 1) * 8 : SPAN * kCB * 2;
+        xpm[j] = pos - pad;             // sequence index (of the first position) relative to the tile origin
+        // quarter q = channels 4q..4q+3 of position pos: half (q >> 1), stored swapped when bit 3 of pos is set;
+        // positions outside the tile (and the items past the last one) land in the dummy slot behind it
+        auto dst = [&](int ps) {
+            return (it < XITEMS && ps >= 0 && ps < SPAN) ? ps * 32 + ((((q >> 1) ^ (ps >> 3)) & 1) << 4) + (q & 1) * 8
+                                                        : SPAN * kCB * 2;
+        };
+        xdst[j] = dst(pos);
+        xdst1[j] = dst(pos1);
     }
-    float xreg[XL][4];
-    unsigned xok = 0;                 // bit j: item j of the chunk in registers is real data
+    float xreg[XL][4];                // fp32 input: four channels of one position; bf16 input: four dwords = two positions each
+    unsigned xok = 0, xok1 = 0;       // bit j: (first / second position of) item j in registers is real data
 
     // ---- stage coordinates: uniform, advanced by additions only ---------------------------------
     int cn = q0 / tiles_t, ctt = q0 - cn * tiles_t, cc = 0;       // compute stage: (n, t tile, chunk)
-    const float *xld = x + (size_t)cn * Cin * L;                  // load stage: sample base, t tile, chunk
+    // load stage: sample base (in floats; a bf16 sample is Cin*ldx/2 floats), t tile, chunk
+    const size_t xstep_n = XH ? (size_t)Cin * ldx / 2 : (size_t)Cin * L;
+    const float *xld = x + (size_t)cn * xstep_n;
     int ltt = ctt, lc = 0, lleft = total;
-    const size_t xstep_n = (size_t)Cin * L;
     auto ld_advance = [&]() {                      // stays on the last chunk once everything is loaded
         if (--lleft > 0) {
             if (++lc == nchunks) {
@@ -217,17 +231,43 @@ __global__ __launch_bounds__(64 * WCO * WT) void conv1d_mfma_bf16_fwd_kernel(
     auto load_x = [&](int j) {                           // item j of the x tile of the load stage
         const int ci = lc * kCB + xq4[j];
         const int sidx = ltt * T_T + xpm[j];
-        const int off = min(ci, Cin - 4) * L + min(max(sidx, 0), L - 1);      // Cin % 4 == 0: a quarter is all valid or all padding
+        if (XH) {
+            // positions (sidx, sidx + 1), sidx even (T_T even, pad odd — the host checks): one aligned dword per channel.
+            // Rows are zero-filled from L to ldx, so only the row's own bounds need a mask.
+            const u16 *xh = reinterpret_cast<const u16 *>(xld);
+            const int sc = min(max(sidx, 0), ldx - 2);
+            const size_t off = (size_t)min(ci, Cin - 4) * ldx + sc;
 #pragma unroll
-        for (int u = 0; u < 4; ++u) xreg[j][u] = xld[off + u * L];
-        const unsigned ok = ((sidx >= 0) && (sidx < L) && (ci < Cin)) ? 1u : 0u;
-        xok = (xok & ~(1u << j)) | (ok << j);
+            for (int u = 0; u < 4; ++u)
+                xreg[j][u] = __uint_as_float(*reinterpret_cast<const unsigned *>(xh + off + (size_t)u * ldx));
+            const unsigned cok = ci < Cin ? 1u : 0u;
+            const unsigned ok0 = ((sidx >= 0) && (sidx < ldx)) ? cok : 0u, ok1 = ((sidx + 1 >= 0) && (sidx + 1 < ldx)) ? cok : 0u;
+            xok = (xok & ~(1u << j)) | (ok0 << j);
+            xok1 = (xok1 & ~(1u << j)) | (ok1 << j);
+        } else {
+            const int off = min(ci, Cin - 4) * L + min(max(sidx, 0), L - 1);      // Cin % 4 == 0: a quarter is all valid or all padding
+#pragma unroll
+            for (int u = 0; u < 4; ++u) xreg[j][u] = xld[off + u * L];
+            const unsigned ok = ((sidx >= 0) && (sidx < L) && (ci < Cin)) ? 1u : 0u;
+            xok = (xok & ~(1u << j)) | (ok << j);
+        }
     };
     auto commit_x = [&](int j, unsigned char *img) {
         const unsigned keep = 0u - ((xok >> j) & 1u);
-        const unsigned lo = pack2_bf16(xreg[j][0], xreg[j][1]) & keep;
-        const unsigned hi = pack2_bf16(xreg[j][2], xreg[j][3]) & keep;
-        *reinterpret_cast<uint2 *>(img + WPADB + xdst[j]) = make_uint2(lo, hi);
+        if (XH) {
+            const unsigned keep1 = 0u - ((xok1 >> j) & 1u);
+            const unsigned w0 = __float_as_uint(xreg[j][0]), w1 = __float_as_uint(xreg[j][1]);
+            const unsigned w2 = __float_as_uint(xreg[j][2]), w3 = __float_as_uint(xreg[j][3]);
+            // low halves = first position, high halves = second position, of channels 4q .. 4q+3
+            const uint2 a = make_uint2(((w0 & 0xFFFFu) | (w1 << 16)) & keep, ((w2 & 0xFFFFu) | (w3 << 16)) & keep);
+            const uint2 b = make_uint2(((w0 >> 16) | (w1 & 0xFFFF0000u)) & keep1, ((w2 >> 16) | (w3 & 0xFFFF0000u)) & keep1);
+            *reinterpret_cast<uint2 *>(img + WPADB + xdst[j]) = a;
+            *reinterpret_cast<uint2 *>(img + WPADB + xdst1[j]) = b;
+        } else {
+            const unsigned lo = pack2_bf16(xreg[j][0], xreg[j][1]) & keep;
+            const unsigned hi = pack2_bf16(xreg[j][2], xreg[j][3]) & keep;
+            *reinterpret_cast<uint2 *>(img + WPADB + xdst[j]) = make_uint2(lo, hi);
+        }
     };
 
     // ---- epilogue of a finished tile: one (accumulator row r, channel group i) item per call ---------
@@ -399,28 +439,38 @@ size_t bf16_packed_elems(int Cred, int Cout, int K) {       // reduction channel
 }
 
 template <int CO_T, int T_T, int WCO, int WT>
-static void launch_bf16(const float *x, const u16 *wb, const float *bias, float *y, float *partials,
+static void launch_bf16(const void *x, int ldx, bool xh, const u16 *wb, const float *bias, float *y, float *partials,
                         int N, int Cin, int Cout, int L, int Lo, int pad, int G, hipStream_t st) {
     const int tiles_t = cdiv(Lo, T_T);
     dim3 grid((unsigned)((size_t)(Cout / CO_T) * G)), block(64 * WCO * WT);
-    if (partials)
+    const float *xf = static_cast<const float *>(x);
+    if (xh)         // bf16 input (the input-gradient conv: no bias, no statistics)
+        hipLaunchKernelGGL((conv1d_mfma_bf16_fwd_kernel<CO_T, T_T, WCO, WT, false, true>), grid, block, 0, st,
+                           xf, wb, bias, y, partials, Cin, Cout, L, Lo, pad, tiles_t, N, G, ldx);
+    else if (partials)
         hipLaunchKernelGGL((conv1d_mfma_bf16_fwd_kernel<CO_T, T_T, WCO, WT, true>), grid, block, 0, st,
-                           x, wb, bias, y, partials, Cin, Cout, L, Lo, pad, tiles_t, N, G);
+                           xf, wb, bias, y, partials, Cin, Cout, L, Lo, pad, tiles_t, N, G, ldx);
     else
         hipLaunchKernelGGL((conv1d_mfma_bf16_fwd_kernel<CO_T, T_T, WCO, WT, false>), grid, block, 0, st,
-                           x, wb, bias, y, partials, Cin, Cout, L, Lo, pad, tiles_t, N, G);
+                           xf, wb, bias, y, partials, Cin, Cout, L, Lo, pad, tiles_t, N, G, ldx);
+}
+
+// x: fp32 [N][Cin][L] (xh false, ldx ignored) or bf16 [N][Cin][ldx] with rows zero-filled past L (xh true)
+static int bf16_fwd_any(const void *x, int ldx, bool xh, const void *wb, const float *bias, float *y, float *partials,
+                        int N, int Cin, int Cout, int L, int K, int pad, hipStream_t st) {
+    const int Lo = L + 2 * pad - K + 1;
+    const u16 *w = static_cast<const u16 *>(wb);
+    const Bf16Cfg c = bf16_cfg(N, Cout, Lo);
+    if (c.co_t == 128) launch_bf16<128, 256, 2, 4>(x, ldx, xh, w, bias, y, partials, N, Cin, Cout, L, Lo, pad, c.G, st);
+    else if (c.co_t == 64 && c.t_t == 256) launch_bf16<64, 256, 1, 4>(x, ldx, xh, w, bias, y, partials, N, Cin, Cout, L, Lo, pad, c.G, st);
+    else if (c.co_t == 64) launch_bf16<64, 128, 2, 2>(x, ldx, xh, w, bias, y, partials, N, Cin, Cout, L, Lo, pad, c.G, st);
+    else launch_bf16<32, 256, 1, 4>(x, ldx, xh, w, bias, y, partials, N, Cin, Cout, L, Lo, pad, c.G, st);
+    return check_launch("conv1d_mfma_bf16_fwd_kernel");
 }
 
 int bf16_fwd(const float *x, const void *wb, const float *bias, float *y, float *partials, int N,
              int Cin, int Cout, int L, int K, int pad, hipStream_t st) {
-    const int Lo = L + 2 * pad - K + 1;
-    const u16 *w = static_cast<const u16 *>(wb);
-    const Bf16Cfg c = bf16_cfg(N, Cout, Lo);
-    if (c.co_t == 128) launch_bf16<128, 256, 2, 4>(x, w, bias, y, partials, N, Cin, Cout, L, Lo, pad, c.G, st);
-    else if (c.co_t == 64 && c.t_t == 256) launch_bf16<64, 256, 1, 4>(x, w, bias, y, partials, N, Cin, Cout, L, Lo, pad, c.G, st);
-    else if (c.co_t == 64) launch_bf16<64, 128, 2, 2>(x, w, bias, y, partials, N, Cin, Cout, L, Lo, pad, c.G, st);
-    else launch_bf16<32, 256, 1, 4>(x, w, bias, y, partials, N, Cin, Cout, L, Lo, pad, c.G, st);
-    return check_launch("conv1d_mfma_bf16_fwd_kernel");
+    return bf16_fwd_any(x, L, false, wb, bias, y, partials, N, Cin, Cout, L, K, pad, st);
 }
 
 int bf16_pack(const float *w, void *wb_fwd, void *wb_bwd, int Co, int Ci, int K, hipStream_t st) {
@@ -537,6 +587,20 @@ ECG_API int ecg_conv1d_fwd_bf16(const float *x, const void *wb_fwd, const float 
     ECG_REQUIRE(x && wb_fwd && y, "conv1d_fwd_bf16: null pointer");
     ECG_REQUIRE(bf16_fwd_supported(C_in, C_out, K, pad), "conv1d_fwd_bf16: needs C_in %% 4 == 0, C_out %% 32 == 0");
     return bf16_fwd(x, wb_fwd, bias, y, stat_partials, N, C_in, C_out, L, K, pad, as_stream(stream));
+}
+
+// input gradient from a dY that is itself bf16: [N][C_out][ldy] u16, rows zero-filled from Lo to ldy, ldy even
+// (ecg_bn_relu_pool_bwd_n16 writes it that way) — half the bytes of the fp32 dY on both sides
+ECG_API int ecg_conv1d_bwd_data_bf16h(const void *dy_bf16, int ldy, const void *wb_bwd, float *dx, int N, int C_in,
+                                      int C_out, int L, int K, int pad, ecg_stream_t stream) {
+    int rc = check_bf16_shape("conv1d_bwd_data_bf16h", N, C_in, C_out, L, K, pad);
+    if (rc) return rc;
+    ECG_REQUIRE(dy_bf16 && wb_bwd && dx, "conv1d_bwd_data_bf16h: null pointer");
+    const int Lo = L + 2 * pad - K + 1, padb = K - 1 - pad;
+    ECG_REQUIRE(bf16_fwd_supported(C_out, C_in, K, padb), "conv1d_bwd_data_bf16h: needs C_out %% 4 == 0, C_in %% 32 == 0");
+    ECG_REQUIRE(ldy >= Lo && ldy % 2 == 0 && (padb & 1) == 1 && (reinterpret_cast<uintptr_t>(dy_bf16) & 3) == 0,
+                "conv1d_bwd_data_bf16h: needs an even row stride >= Lo, odd K-1-pad and a 4-byte aligned dY");
+    return bf16_fwd_any(dy_bf16, ldy, true, wb_bwd, nullptr, dx, nullptr, N, C_out, C_in, Lo, K, padb, as_stream(stream));
 }
 
 ECG_API int ecg_conv1d_bwd_data_bf16(const float *dy, const void *wb_bwd, float *dx, int N, int C_in,

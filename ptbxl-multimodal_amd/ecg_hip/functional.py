@@ -422,11 +422,15 @@ class ConvBlockFn(torch.autograd.Function):
             # (bf16 n16) — and in fp32 only when an input gradient follows; x is already there from the forward
             # pass of the previous block (or packed here for the first block)
             G = (N + 15) // 16
-            dy = _empty(y, N, Co, Lo) if need_dx else None
+            # the input gradient reads dY as bf16 [N][C][PA] when its staging can pair positions (odd K-1-pad);
+            # the fp32 dY is then never written
+            dyh_ok = need_dx and ((K - 1 - ctx.pad) & 1) == 1
+            dy = _empty(y, N, Co, Lo) if (need_dx and not dyh_ok) else None
+            dyh = torch.empty(N * Co * PA, dtype=torch.bfloat16, device=y.device) if dyh_ok else None
             dyb = torch.empty(G * Co * PA * 16, dtype=torch.bfloat16, device=y.device)
             _call("ecg_bn_relu_pool_bwd_n16", _f32(y), _f32(dp), _f32(gamma), _f32(beta), _f32(mean), _f32(invstd),
                   _f32(dy), Lo, L.ptr(dyb), PA, _f32(dgamma), _f32(dbeta), _f32(ws), N, Co, Lo,
-                  1 if ctx.batch_stats else 0, 1 if ctx.gap else 0, _st())
+                  1 if ctx.batch_stats else 0, 1 if ctx.gap else 0, L.ptr(dyh), _st())
             xb = ctx.x_n16
             PX = _query("ecg_conv1d_n16_positions", Lin, K, ctx.pad, 1)
             if xb is None or xb.numel() != G * Ci * PX * 16:
@@ -439,7 +443,11 @@ class ConvBlockFn(torch.autograd.Function):
             dx = None
             if need_dx:
                 dx = torch.empty_like(x)
-                _call("ecg_conv1d_bwd_data_bf16", _f32(dy), L.ptr(ctx.w_bwd), _f32(dx), N, Ci, Co, Lin, K, ctx.pad, _st())
+                if dyh_ok:
+                    _call("ecg_conv1d_bwd_data_bf16h", L.ptr(dyh), PA, L.ptr(ctx.w_bwd), _f32(dx), N, Ci, Co, Lin, K,
+                          ctx.pad, _st())
+                else:
+                    _call("ecg_conv1d_bwd_data_bf16", _f32(dy), L.ptr(ctx.w_bwd), _f32(dx), N, Ci, Co, Lin, K, ctx.pad, _st())
             return (dx, dw, db, dgamma, dbeta) + nones
         # dY never leaves this function: give it the row stride the conv gradients stream best
         # (rows padded to 64 floats, zero pad -> LDS-DMA in the weight gradient)

@@ -691,10 +691,16 @@ def test_bn_relu_pool_n16_producers_match_the_plain_passes(hip, oracle, shape):
     for with_dy in (True, False):
         dy, dg, db = torch.empty(N, C, Lo, device="cuda"), torch.empty(C, device="cuda"), torch.empty(C, device="cuda")
         dyb = torch.full((G * C * PA * 16,), 7.0, dtype=torch.bfloat16, device="cuda")
+        dyh = torch.full((N * C * PA,), 7.0, dtype=torch.bfloat16, device="cuda")
         L.call("ecg_bn_relu_pool_bwd_n16", L.f32(y), L.f32(dp), L.f32(gamma), L.f32(beta), L.f32(mean), L.f32(invstd),
-               L.f32(dy) if with_dy else None, Lo, L.ptr(dyb), PA, L.f32(dg), L.f32(db), L.f32(ws), N, C, Lo, 1, 0, L.stream())
+               L.f32(dy) if with_dy else None, Lo, L.ptr(dyb), PA, L.f32(dg), L.f32(db), L.f32(ws), N, C, Lo, 1, 0,
+               None if with_dy else L.ptr(dyh), L.stream())
         if with_dy:
             assert torch.equal(dy, dy_ref)
+        else:       # the bf16 [N][C][PA] copy for the input gradient: bf16-rounded dY, zeros past the row
+            wanth = np.zeros((N, C, PA), np.float32)
+            wanth[:, :, :Lo] = _bf16_round(host(dy_ref))
+            assert np.array_equal(dyh.view(N, C, PA).to(torch.float32).cpu().numpy(), wanth)
         assert torch.equal(dg, dg_ref) and torch.equal(db, db_ref)
         want = np.zeros((G * 16, C, PA), np.float32)
         want[:N, :, :Lo] = _bf16_round(host(dy_ref))
@@ -765,3 +771,27 @@ def test_bf16_conv_full_size_config5_vs_torch_on_rounded_operands(hip, block):
     assert float((dw.cpu() - wr.grad).abs().max()) < 5e-6 * float(wr.grad.abs().max()) + 2e-5
     rdb = dyr.sum(dim=(0, 2))
     assert float((db.cpu() - rdb).abs().max()) < 5e-6 * float(rdb.abs().max()) + 1e-3
+
+
+@pytest.mark.parametrize("case", [(3, 32, 64, 300), (2, 64, 128, 125), (2, 128, 256, 62), (1, 64, 128, 520), (5, 32, 64, 17)])
+def test_bf16_input_grad_from_bf16_dy_equals_the_fp32_dy_entry_point(hip, case):
+    """ecg_conv1d_bwd_data_bf16h reads dY as bf16 [N][C][ld] (zero-filled past the row, even stride); on a dY that is
+    already bf16-representable it must give exactly what ecg_conv1d_bwd_data_bf16 gives on the fp32 tensor (same
+    products, same order) — every tile configuration, ragged tiles, rows shorter than a tile."""
+    from ecg_hip import _lib as L
+    N, Ci, Co, Lin = case
+    rng = np.random.default_rng(sum(case) + 3)
+    w = (rng.standard_normal((Co, Ci, 15)) / np.sqrt(Ci * 15)).astype(np.float32)
+    dy = torch.from_numpy(rng.standard_normal((N, Co, Lin)).astype(np.float32)).to(torch.bfloat16)
+    _, wb_bwd = hip.conv1d_pack_bf16(dev(w), need_bwd=True)
+    dy32 = dy.to(torch.float32).cuda()
+    dx_ref = torch.empty(N, Ci, Lin, device="cuda")
+    L.call("ecg_conv1d_bwd_data_bf16", L.f32(dy32), L.ptr(wb_bwd), L.f32(dx_ref), N, Ci, Co, Lin, 15, 7, L.stream())
+    PA = L.query("ecg_conv1d_n16_positions", Lin, 15, 7, 0)
+    dyh = torch.zeros(N, Co, PA, dtype=torch.bfloat16, device="cuda")
+    dyh[:, :, :Lin] = dy.cuda()
+    dx = torch.empty(N, Ci, Lin, device="cuda")
+    L.call("ecg_conv1d_bwd_data_bf16h", L.ptr(dyh), PA, L.ptr(wb_bwd), L.f32(dx), N, Ci, Co, Lin, 15, 7, L.stream())
+    assert torch.equal(dx, dx_ref)
+    with pytest.raises(L.EcgHipError, match="even row stride"):
+        L.call("ecg_conv1d_bwd_data_bf16h", L.ptr(dyh), PA + 1, L.ptr(wb_bwd), L.f32(dx), N, Ci, Co, Lin, 15, 7, L.stream())
