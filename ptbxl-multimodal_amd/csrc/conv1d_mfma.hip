@@ -43,6 +43,21 @@ __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
 }
 
+// s_waitcnt lgkmcnt(n), vmcnt / expcnt left at "no wait" (n is a compile-time constant after unrolling).  hipcc's own
+// placement drains lgkmcnt(0) on every second step of the fragment double-buffering below — i.e. it waits for the LDS
+// reads just issued for the NEXT step in front of MFMAs that only need the previous ones; an explicit counted wait
+// placed before the MFMAs tells its scoreboard the operands are complete (a count larger than the reads really in
+// flight is harmless: the compiler still adds whatever wait correctness needs).
+__device__ __forceinline__ void wait_lgkm_f(int n) {
+    switch (n) {
+        case 1: __builtin_amdgcn_s_waitcnt(0xC17F); break;
+        case 2: __builtin_amdgcn_s_waitcnt(0xC27F); break;
+        case 3: __builtin_amdgcn_s_waitcnt(0xC37F); break;
+        case 4: __builtin_amdgcn_s_waitcnt(0xC47F); break;
+        default: break;
+    }
+}
+
 // row of element r of a 32x32 accumulator held by this lane: (r&3) + 8*(r>>2) + 4*(lane>>5)
 __device__ __forceinline__ int acc_row(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }
 
@@ -216,6 +231,7 @@ __global__ __launch_bounds__(256, 2) void conv1d_mfma_fwd_kernel(
 #pragma unroll
         for (int st = 0; st < NST; ++st) {
             ld(st + 1 < NST ? st + 1 : 0, a_n, b_n);
+            wait_lgkm_f((MC + 1) / 2 + (MT + 1) / 2);      // the reads just issued (pairs merge into ds_read2_b32) may fly
             // staging, one operation per step: x commits, then weight DMA pieces, then x loads
             if (st < XLOADS) {
                 if (do_next) commit_x(st, nxt);
