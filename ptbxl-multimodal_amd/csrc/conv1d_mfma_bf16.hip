@@ -356,15 +356,18 @@ __global__ __launch_bounds__(64 * WCO * WT) void conv1d_mfma_bf16_fwd_kernel(
             for (int i = 0; i < MT; ++i) b_c[i] = b_n[i];
         }
         ld_advance();
-        __syncthreads();      // image q&1 free again; image (q+1)&1 complete (vmcnt(0) + barrier)
+        // End of chunk: image q&1 is free again once everybody is here, and image (q+1)&1 is complete once every wave's
+        // DMA pieces and commits have landed.  __syncthreads() would ALSO wait (vmcnt(0)) for the x loads of flat chunk
+        // q+2 issued a few steps ago — an HBM round trip of 1-2 us in front of every barrier, half a chunk's time.  They
+        // are the NEWEST 4*XL vector-memory operations of this wave (vmcnt counts in issue order), so wait for everything
+        // older and let them fly; they are consumed by the commits of the next chunk.
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(4 * XL) : "memory");
         if (q == 0) ECG_STAMPB_AT(2);
         if (++cc == nchunks) {                     // tile complete: store it and go straight on
             cc = 0;
             ytile = y + ((size_t)cn * Cout + co0) * Lo + ctt * T_T;
             pt0 = ctt * T_T;
-            // nothing is in flight here (the barrier drained vmcnt); saying so keeps compiler-inserted waits for the
-            // staging registers out of the run of stores
-            __builtin_amdgcn_s_waitcnt(0x0F70);
+            // only the x loads of the chunk after next are in flight here; the epilogue does not touch their registers
 #pragma unroll
             for (int e = 0; e < 16 * MC; ++e) epilogue_item(e);
 #pragma unroll
