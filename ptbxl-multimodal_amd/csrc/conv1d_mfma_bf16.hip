@@ -105,7 +105,10 @@ __global__ void pack_weights_bf16_kernel(const float *__restrict__ w, u16 *__res
 //   * XH: the input itself is bf16 ([N][C_in][ldx] u16, rows zero-filled past L, ldx even) — the input-gradient
 //     conv reads the dY the BatchNorm backward wrote in bf16.  An item is then a PAIR of positions (2i-1, 2i) of four
 //     channels: four aligned 4-byte loads (half the bytes, half the loads of the fp32 input) feeding two LDS rows.
-template <int CO_T, int T_T, int WCO, int WT, bool STATS, bool XH = false>
+//   * WRES: layers with at most two 16-channel chunks (blocks 0 and 1 forward) keep their whole weight slice
+//     resident — image 0 holds chunk 0, image 1 chunk 1 (or chunk 0 again), loaded once per workgroup; only x tiles
+//     stream after that.
+template <int CO_T, int T_T, int WCO, int WT, bool STATS, bool XH = false, bool WRES = false>
 __global__ __launch_bounds__(64 * WCO * WT) void conv1d_mfma_bf16_fwd_kernel(
     const float *__restrict__ x, const u16 *__restrict__ wb, const float *__restrict__ bias,
     float *__restrict__ y, float *__restrict__ partials, int Cin, int Cout, int L, int Lo, int pad,
@@ -302,6 +305,10 @@ __global__ __launch_bounds__(64 * WCO * WT) void conv1d_mfma_bf16_fwd_kernel(
     // prologue: flat chunk 0 -> image 0; x of flat chunk 1 -> registers
 #pragma unroll
     for (int j = 0; j < DPW; ++j) dma_w(j, wbase, lds);
+    if (WRES) {               // weights of flat chunk 1 (chunk 1, or chunk 0 again for a one-chunk layer) -> image 1, for good
+#pragma unroll
+        for (int j = 0; j < DPW; ++j) dma_w(j, wbase + (size_t)(nchunks > 1 ? 1 : 0) * chunk_bytes, lds + IMGB);
+    }
 #pragma unroll
     for (int j = 0; j < XL; ++j) load_x(j);
 #pragma unroll
@@ -339,7 +346,7 @@ __global__ __launch_bounds__(64 * WCO * WT) void conv1d_mfma_bf16_fwd_kernel(
             wait_lgkm(MC + MT);
 #pragma unroll
             for (int o = k * OPS; o < (k + 1) * OPS; ++o) {      // weight DMA pieces first (longest latency), x commits, x loads;
-                if (o < DPW) dma_w(o, wnext, nxt);               // all UNCONDITIONAL: stages past the end restage valid data
+                if (o < DPW) { if (!WRES) dma_w(o, wnext, nxt); }   // all UNCONDITIONAL: stages past the end restage valid data
                 else if (o < DPW + XL) commit_x(o - DPW, nxt);
                 else if (o < NOPS) load_x(o - XL - DPW);
             }
@@ -450,7 +457,14 @@ static void launch_bf16(const void *x, int ldx, bool xh, const u16 *wb, const fl
     if (xh)         // bf16 input (the input-gradient conv: no bias, no statistics)
         hipLaunchKernelGGL((conv1d_mfma_bf16_fwd_kernel<CO_T, T_T, WCO, WT, false, true>), grid, block, 0, st,
                            xf, wb, bias, y, partials, Cin, Cout, L, Lo, pad, tiles_t, N, G, ldx);
-    else if (partials)
+    else if (Cin <= 2 * kCB) {          // at most two chunks: the weight slice stays resident in the two LDS images
+        if (partials)
+            hipLaunchKernelGGL((conv1d_mfma_bf16_fwd_kernel<CO_T, T_T, WCO, WT, true, false, true>), grid, block, 0, st,
+                               xf, wb, bias, y, partials, Cin, Cout, L, Lo, pad, tiles_t, N, G, ldx);
+        else
+            hipLaunchKernelGGL((conv1d_mfma_bf16_fwd_kernel<CO_T, T_T, WCO, WT, false, false, true>), grid, block, 0, st,
+                               xf, wb, bias, y, partials, Cin, Cout, L, Lo, pad, tiles_t, N, G, ldx);
+    } else if (partials)
         hipLaunchKernelGGL((conv1d_mfma_bf16_fwd_kernel<CO_T, T_T, WCO, WT, true>), grid, block, 0, st,
                            xf, wb, bias, y, partials, Cin, Cout, L, Lo, pad, tiles_t, N, G, ldx);
     else
