@@ -473,15 +473,11 @@ def main():
             run(wrapped, ListLoader(batch, spec["priming"]), opt, dev)
         run(wrapped, ListLoader(batch, spec["warmup"]), opt, dev)
         loader = ListLoader(batch, spec["steps"], record=True)
-        import gc
-        gc.collect()
-        gc.disable()                    # no collector pause inside the timed region (a 3 ms pause is 1.5 bf16 steps)
         barrier()
         t0 = time.perf_counter()
         last_loss = run(wrapped, loader, opt, dev)
         barrier()
         elapsed = time.perf_counter() - t0
-        gc.enable()
         if world > 1:
             t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
