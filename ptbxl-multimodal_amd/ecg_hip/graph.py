@@ -46,7 +46,9 @@ class GraphedTrainStep:
             self.running.zero_()
         torch.cuda.current_stream().wait_stream(side)
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
+        # capture on the stream the warm-up ran on: the AccumulateGrad nodes created there keep that stream, and
+        # a capture on another one makes autograd insert (and warn about) cross-stream synchronisation
+        with torch.cuda.graph(self.graph, stream=side):
             self._step_body()
 
     def _step_body(self):
