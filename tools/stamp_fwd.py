@@ -2,7 +2,8 @@
 """Where does a forward-conv workgroup spend its time?  Runs each block geometry through the diagnostic build
 (make -C ptbxl-multimodal_amd/csrc STAMP=1; ECG_HIP_LIB=.../libecg_hip_stamp.so) whose kernel stamps s_memtime at
 start / end of prologue / end of first chunk / end of main loop / end of epilogue, and prints per-phase medians
-in microseconds (s_memtime ticks at 100 MHz... no: at the shader clock; s_memrealtime at 100 MHz anchors it)."""
+in microseconds (s_memtime ticks at the shader clock; s_memrealtime, 100 MHz, anchors it).  --bf16 stamps the
+mixed-precision forward kernel, --long uses 12x5000 windows."""
 import ctypes
 import json
 import os
@@ -12,7 +13,6 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, "ptbxl-multimodal_amd")):
     sys.path.insert(0, p)
 os.environ.setdefault("ECG_HIP_LIB", os.path.join(ROOT, "ptbxl-multimodal_amd", "lib", "libecg_hip_stamp.so"))
-os.environ["ECG_HIP_FWD_PERSISTENT"] = "0"
 
 
 def main():
