@@ -82,7 +82,7 @@ def allreduce_flat_gradients(params, group=None, world=None):
 class FlatGradDDP(nn.Module):
     """Wrap a model so that `loss.backward()` leaves rank-averaged gradients in `.grad`."""
 
-    def __init__(self, module, process_group=None, broadcast_buffers=False):
+    def __init__(self, module, process_group=None, broadcast_buffers=False, exchange_single_rank=False):
         super().__init__()
         self.module = module
         self.process_group = process_group
@@ -90,7 +90,10 @@ class FlatGradDDP(nn.Module):
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self._params = [p for p in module.parameters() if p.requires_grad]
         self._pending = 0
-        if self.world > 1:
+        # exchange_single_rank: keep the hooks and the all-reduce for a ONE-rank group (identity; lets the RCCL path
+        # run on a one-GPU box, tools/rccl_selftest.py)
+        self._exchange = self.world > 1 or (bool(exchange_single_rank) and dist.is_initialized())
+        if self._exchange:
             broadcast_module_state(module, 0, process_group)
             for p in self._params:
                 p.register_post_accumulate_grad_hook(self._on_grad)
@@ -103,7 +106,7 @@ class FlatGradDDP(nn.Module):
 
     def forward(self, *args, **kwargs):
         self._pending = 0
-        if self.world > 1 and self.broadcast_buffers and self.module.training:
+        if self._exchange and self.broadcast_buffers and self.module.training:
             for b in self.module.buffers():
                 dist.broadcast(b.data, src=0, group=self.process_group)
         return self.module(*args, **kwargs)

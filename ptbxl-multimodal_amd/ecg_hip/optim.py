@@ -40,7 +40,7 @@ def flatten_tensors_(tensors):
 
 class FlatAdamW(torch.optim.Optimizer):
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2,
-                 process_group=None, world_size=None, overlap=True, early_params=8):
+                 process_group=None, world_size=None, overlap=True, early_params=8, exchange_single_rank=False):
         defaults = dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)
         super().__init__(params, defaults)
         if len(self.param_groups) != 1:
@@ -77,6 +77,11 @@ class FlatAdamW(torch.optim.Optimizer):
                                              and torch.distributed.is_initialized()):
                 world_size = torch.distributed.get_world_size(process_group)
         self.world_size = world_size
+        # `exchange_single_rank`: run the exchange (hooks, async all-reduces, waits) even when the group has ONE rank —
+        # the sum over one rank is the identity, so the step is unchanged bit for bit; it exists so that the RCCL
+        # code path can be executed on a one-GPU box (tools/rccl_selftest.py)
+        self._exchange = world_size > 1 or (bool(exchange_single_rank) and torch.distributed.is_available()
+                                            and torch.distributed.is_initialized())
         # ---- bucketed, backward-overlapped exchange (world > 1 only) -------------------------
         self._n_early = min(max(int(early_params), 0), len(self._params))
         self._split = sum(p.numel() for p in self._params[:self._n_early])      # flat offset of the late bucket
@@ -84,7 +89,7 @@ class FlatAdamW(torch.optim.Optimizer):
         self._late_work = None
         self._early_pending = 0
         self._early_work = None
-        self._overlap = bool(overlap) and world_size > 1 and 0 < self._n_early < len(self._params)
+        self._overlap = bool(overlap) and self._exchange and 0 < self._n_early < len(self._params)
         self._sync = True                 # False inside no_sync(): gradients accumulate locally, nothing is exchanged
         if self._overlap:
             self._late_total = len(self._params) - self._n_early
@@ -205,12 +210,12 @@ class FlatAdamW(torch.optim.Optimizer):
             self._early_work = None
             g = self.flat_grad
             self._gather(self._n_early, len(self._params))
-            if self.world_size > 1:
+            if self._exchange:
                 torch.distributed.all_reduce(g[self._split:], group=self.process_group)
             return g, 1.0 / self.world_size
         g = self.flat_grad
         self._gather(0, len(self._params))
-        if self.world_size > 1:
+        if self._exchange:
             torch.distributed.all_reduce(g, group=self.process_group)
             return g, 1.0 / self.world_size
         return g, 1.0

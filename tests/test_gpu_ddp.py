@@ -120,3 +120,22 @@ def test_bench_two_rank_line(tmp_path, launcher):
     assert r["exchange_exposed_ms_per_step"]["n"] == 5
     assert [a["value"] > 0 for a in d["also"]] == [True]          # N > 1: the multimodal leg only
     assert {row["op"] for row in d["layers"]} == {"fwd", "dgrad", "wgrad"} and len(d["layers"]) == 11
+
+
+def test_one_rank_rccl_exchange():
+    """The exchange code on RCCL itself: a one-rank `nccl` group (the most RCCL a one-GPU box can run) through the
+    hooked two-bucket all-reduce, the single all-reduce, FlatGradDDP + stock AdamW and no_sync() accumulation — each
+    bit-identical to the step without an exchange (tools/rccl_selftest.py)."""
+    import json
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "ECG_HIP_REHEARSE_ON_ONE_GPU"):
+        env.pop(k, None)
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "rccl_selftest.py"), "--steps", "10", "--port",
+                          str(_free_port())], env=env, capture_output=True, text=True, timeout=400)
+    assert res.returncode == 0, res.stderr[-3000:]
+    d = json.loads([ln for ln in res.stdout.splitlines() if ln.startswith("{")][-1])
+    assert d["ok"] and d["backend"] == "nccl" and d["world"] == 1 and d["ranks_seen_by_allreduce"] == 1
+    assert d["flat_adamw_hooked_exchange"] == {"overlap_hooks_active": True, "bit_identical_to_unexchanged_step": True}
+    for k in ("flat_adamw_single_allreduce", "flat_grad_ddp_stock_adamw", "no_sync_accumulation"):
+        assert d[k]["bit_identical_to_unexchanged_step"], k
+    assert d["allreduce_two_buckets_ms"]["floats"] == 719397
