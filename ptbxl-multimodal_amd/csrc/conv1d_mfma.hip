@@ -731,6 +731,7 @@ __global__ __launch_bounds__(256, 2) void conv1d_mfma_wgrad_dma_kernel(
     static_assert(NST >= 2 * XLOADS + DPW, "not enough steps to spread the staging over");
 
     __shared__ __attribute__((aligned(1024))) float lds[2 * IMG];
+    ECG_STAMP_AT(0);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int half = lane >> 5, l31 = lane & 31;
@@ -827,6 +828,7 @@ __global__ __launch_bounds__(256, 2) void conv1d_mfma_wgrad_dma_kernel(
         advance();                                      // stage 2
     }
     __syncthreads();
+    ECG_STAMP_AT(1);
 
     const int aoff = (wm0 + l31) * T_T, swz = (l31 & 15) << 2;
     for (int it = 0; it < total; ++it) {
@@ -858,6 +860,8 @@ __global__ __launch_bounds__(256, 2) void conv1d_mfma_wgrad_dma_kernel(
             // staging, one operation per step: x commits, x loads, then the dY DMA pieces.
             // UNCONDITIONAL (stage coordinates are clamped, the last stages restage a valid tile
             // nobody reads): under a branch hipcc puts s_waitcnt vmcnt(0) in front of every load.
+            // (Issuing the DMA pieces FIRST — 14 instead of 4 steps of slack before the barrier on the
+            // 32-channel tile — measured the same: the stage loop is not waiting for the DMA.)
             if (st < XLOADS) commit_x(st, nxt);
             else if (st < 2 * XLOADS) load_x(st - XLOADS);
             else if (st < 2 * XLOADS + DPW) dma_a(st - 2 * XLOADS, nxt);
@@ -879,7 +883,12 @@ __global__ __launch_bounds__(256, 2) void conv1d_mfma_wgrad_dma_kernel(
         dn = sn; dtt = stt;
         advance();
         __syncthreads();      // image it&1 free again; image (it+1)&1 complete (vmcnt(0) + barrier)
+        if (it == 0) ECG_STAMP_AT(2);
     }
+    ECG_STAMP_AT(3);
+#ifdef ECG_STAMP
+    if (g_stamps && threadIdx.x == 0) g_stamps[(size_t)blockIdx.x * 8 + 5] = (unsigned long long)total;
+#endif
 
     if (want_bias) {
 #pragma unroll
@@ -933,6 +942,10 @@ __global__ __launch_bounds__(256, 2) void conv1d_mfma_wgrad_dma_kernel(
         for (int i = 0; i < MC; ++i)
             slab[(size_t)S * wslab + (size_t)s * Cout + co0 + wm0 + 32 * i + l31] = bsum[i];
     }
+#ifdef ECG_STAMP
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+    ECG_STAMP_AT(4);
 }
 
 // conv1d_direct.hip: dw[i] = sum_s slab[s][i] in fixed order

@@ -30,6 +30,7 @@ def main():
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--batch", type=int, default=256)
     ap.add_argument("--port", type=int, default=29631)
+    ap.add_argument("--sweep", action="store_true", help="also time other early-bucket sizes")
     args = ap.parse_args()
 
     import torch
@@ -142,9 +143,9 @@ def main():
                                        "max": round(ms[-1], 4), "floats": int(flat.numel()), "n": steps}
 
     # 6. step time with and without the exchange (fresh models, same batch; one epoch of `steps` steps, one sync)
-    def timed(exchange):
+    def timed(exchange, **kw):
         model = fresh()
-        opt = FlatAdamW(model.parameters(), lr=1e-4, weight_decay=1e-4, exchange_single_rank=exchange)
+        opt = FlatAdamW(model.parameters(), lr=1e-4, weight_decay=1e-4, exchange_single_rank=exchange, **kw)
         train_one_epoch(model, Batches([(x, y)] * 15), opt, dev)
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         best = None
@@ -157,7 +158,10 @@ def main():
             best = t if best is None else min(best, t)
         return round(best, 4)
 
-    out["step_ms"] = {"no_exchange": timed(False), "one_rank_rccl_exchange": timed(True)}
+    out["step_ms"] = {"no_exchange": timed(False), "one_rank_rccl_exchange": timed(True),
+                      "one_rank_rccl_single_allreduce": timed(True, overlap=False)}
+    if args.sweep:
+        out["step_ms"].update({f"early_params_{n}": timed(True, early_params=n) for n in (2, 4, 12, 16)})
     dist.barrier(device_ids=[0])
     dist.destroy_process_group()
     ok = (out["ranks_seen_by_allreduce"] == 1 and out["flat_adamw_hooked_exchange"]["overlap_hooks_active"]

@@ -3,7 +3,8 @@
 (make -C ptbxl-multimodal_amd/csrc STAMP=1; ECG_HIP_LIB=.../libecg_hip_stamp.so) whose kernel stamps s_memtime at
 start / end of prologue / end of first chunk / end of main loop / end of epilogue, and prints per-phase medians
 in microseconds (s_memtime ticks at the shader clock; s_memrealtime, 100 MHz, anchors it).  --bf16 stamps the
-mixed-precision forward kernel, --long uses 12x5000 windows."""
+mixed-precision forward kernel, --long uses 12x5000 windows, --wgrad stamps the fp32 weight-gradient kernel (start / end of
+prologue / end of first stage / end of the stage loop / slab written; stages per workgroup in slot 5)."""
 import ctypes
 import json
 import os
@@ -13,6 +14,30 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, "ptbxl-multimodal_amd")):
     sys.path.insert(0, p)
 os.environ.setdefault("ECG_HIP_LIB", os.path.join(ROOT, "ptbxl-multimodal_amd", "lib", "libecg_hip_stamp.so"))
+
+
+def report(b, stamps, names, stages=False):
+    import numpy as np
+    s = stamps.cpu().numpy().reshape(-1, 8)
+    s = s[s[:, 0] != 0]
+    rt0, rt1 = s[:, 7].astype(np.float64), s[:, 6].astype(np.float64)      # s_memrealtime, 100 MHz
+    t = s[:, :5].astype(np.float64)
+    dur_ticks = t[:, 4] - t[:, 0]
+    clk = float(np.median(dur_ticks / np.maximum(rt1 - rt0, 1.0))) * 100e6     # s_memtime ticks per second
+    ph = np.diff(t, axis=1)
+    span_us = (rt1.max() - rt0.min()) / 100.0
+    out = {"block": b, "workgroups": int(len(s)), "clock_GHz_est": round(clk / 1e9, 3), "kernel_span_us": round(span_us, 1),
+           "start_spread_us": round((rt0.max() - rt0.min()) / 100.0, 2),
+           "end_spread_us": round((rt1.max() - rt1.min()) / 100.0, 2),
+           "median_us": {k: round(float(np.median(ph[:, i])) / clk * 1e6, 2) for i, k in
+                         enumerate(names)},
+           "p90_us": {k: round(float(np.percentile(ph[:, i], 90)) / clk * 1e6, 2) for i, k in
+                      enumerate(names)},
+           "wg_total_median_us": round(float(np.median(dur_ticks)) / clk * 1e6, 2)}
+    if stages:
+        out["stages_per_workgroup_median"] = int(np.median(s[:, 5]))
+        out["us_per_stage_median"] = round(float(np.median(ph[:, 2] / np.maximum(s[:, 5] - 1, 1))) / clk * 1e6, 3)
+    print(json.dumps(out))
 
 
 def main():
@@ -32,6 +57,22 @@ def main():
         w = torch.randn(co, ci, K, device=dev) * 0.05
         bias = torch.randn(co, device=dev)
         wf, _ = (F.conv1d_pack_bf16 if bf16 else F.conv1d_pack)(w, need_bwd=False)
+        if "--wgrad" in sys.argv:
+            ldy = L.query("ecg_conv1d_dy_row_stride", N, ci, co, Lc, K, pad, 0)
+            dy = torch.randn(N, co, ldy, device=dev)
+            dy[:, :, Lc:] = 0
+            dw, db = torch.empty(co, ci, K, device=dev), torch.empty(co, device=dev)
+            ws = torch.empty(L.query("ecg_conv1d_bwd_weight_ws_floats", N, ci, co, Lc, K, pad), device=dev)
+            stamps = torch.zeros(16384 * 8, dtype=torch.int64, device=dev)
+            for rep in range(3):
+                stamps.zero_()
+                setter(stamps.data_ptr())
+                L.call("ecg_conv1d_bwd_weight_bias_ld", L.f32(dy), ldy, L.f32(x), L.f32(dw), L.f32(db), L.f32(ws), N, ci, co,
+                       Lc, K, pad, L.stream())
+                torch.cuda.synchronize()
+            report(b, stamps, ["prologue", "first_stage", "other_stages", "exchange+slab"], stages=True)
+            Lc //= 2
+            continue
         y = torch.empty(N, co, Lc, device=dev)
         P = L.query("ecg_conv1d_fwd_bf16_stat_partials" if bf16 else "ecg_conv1d_fwd_stat_partials", N, ci, co, Lc, K, pad)
         part = torch.empty(co * P * 2, device=dev)
@@ -44,23 +85,7 @@ def main():
             else:
                 L.call("ecg_conv1d_fwd", L.f32(x), L.f32(wf), L.f32(bias), L.f32(y), L.f32(part), N, ci, co, Lc, K, pad, L.stream())
             torch.cuda.synchronize()
-        s = stamps.cpu().numpy().reshape(-1, 8)
-        s = s[s[:, 0] != 0]
-        rt0, rt1 = s[:, 7].astype(np.float64), s[:, 6].astype(np.float64)      # s_memrealtime, 100 MHz
-        t = s[:, :5].astype(np.float64)
-        dur_ticks = t[:, 4] - t[:, 0]
-        clk = float(np.median(dur_ticks / np.maximum(rt1 - rt0, 1.0))) * 100e6     # s_memtime ticks per second
-        ph = np.diff(t, axis=1)
-        span_us = (rt1.max() - rt0.min()) / 100.0
-        out = {"block": b, "workgroups": int(len(s)), "clock_GHz_est": round(clk / 1e9, 3), "kernel_span_us": round(span_us, 1),
-               "start_spread_us": round((rt0.max() - rt0.min()) / 100.0, 2),
-               "end_spread_us": round((rt1.max() - rt1.min()) / 100.0, 2),
-               "median_us": {k: round(float(np.median(ph[:, i])) / clk * 1e6, 2) for i, k in
-                             enumerate(["prologue", "first_chunk", "other_chunks", "epilogue"])},
-               "p90_us": {k: round(float(np.percentile(ph[:, i], 90)) / clk * 1e6, 2) for i, k in
-                          enumerate(["prologue", "first_chunk", "other_chunks", "epilogue"])},
-               "wg_total_median_us": round(float(np.median(dur_ticks)) / clk * 1e6, 2)}
-        print(json.dumps(out))
+        report(b, stamps, ["prologue", "first_chunk", "other_chunks", "epilogue"])
         Lc //= 2
 
 
