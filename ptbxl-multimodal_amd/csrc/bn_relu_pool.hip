@@ -23,6 +23,17 @@ __device__ __forceinline__ void ld_pair(const float *r, float &a, float &b) {
     }
 }
 
+// The pooling pair (t, t+1), t even, of row `row` of y: fp32 rows of stride ld, or (YH) bf16 rows of EVEN stride ld
+// (bf16 activation storage: one aligned dword holds the pair).
+template <bool AL8, bool YH>
+__device__ __forceinline__ void ld_pair_y(const float *y, size_t row, int ld, int t, float &a, float &b) {
+    if (YH) {
+        const unsigned v = *reinterpret_cast<const unsigned *>(reinterpret_cast<const unsigned short *>(y) + row * ld + t);
+        a = __uint_as_float(v << 16);
+        b = __uint_as_float(v & 0xFFFF0000u);
+    } else ld_pair<AL8>(y + row * ld + t, a, b);
+}
+
 // ---------------------------------------------------------------------------------------
 // statistics
 // ---------------------------------------------------------------------------------------
@@ -156,11 +167,11 @@ __global__ __launch_bounds__(kBlock) void bn_relu_pool_fwd_kernel(
 // Last block of the backbone: BatchNorm -> ReLU -> MaxPool(2) -> AdaptiveAvgPool1d(1) without
 // materialising the pooled tensor.  grid = (C, S2): a workgroup owns channel c and the samples of split s2, one wave
 // per (n, c) row at a time; g[row] = mean_j pooled[row][j].
-template <bool FIN>
+template <bool FIN, bool YH = false>
 __global__ __launch_bounds__(kBlock) void bn_relu_pool_gap_fwd_kernel(
     const float *__restrict__ y, const float *__restrict__ gamma, const float *__restrict__ beta,
     const float *__restrict__ mean, const float *__restrict__ invstd, float *__restrict__ g,
-    int N, int C, int L, int Lp, int S2, BnFin fin) {
+    int N, int C, int L, int Lp, int S2, BnFin fin, int ldy) {
     const int c = blockIdx.x, s2 = blockIdx.y;
     float mu, is;
     if (FIN) bn_finalize_block(fin, c, s2 == 0, mu, is);
@@ -170,10 +181,11 @@ __global__ __launch_bounds__(kBlock) void bn_relu_pool_gap_fwd_kernel(
     const int lane = threadIdx.x & 63;
     for (int n = n0 + (threadIdx.x >> 6); n < n1; n += 4) {
         const size_t row = (size_t)n * C + c;
-        const float *r = y + row * L;
         float a = 0.f;
         for (int j = lane; j < Lp; j += 64) {
-            float a0 = bn_apply1(r[2 * j], mu, sc, be), a1 = bn_apply1(r[2 * j + 1], mu, sc, be);
+            float r0, r1;
+            ld_pair_y<false, YH>(y, row, ldy, 2 * j, r0, r1);
+            float a0 = bn_apply1(r0, mu, sc, be), a1 = bn_apply1(r1, mu, sc, be);
             float m = a1 > a0 ? a1 : a0;
             a += m > 0.f ? m : 0.f;
         }
@@ -206,12 +218,12 @@ __device__ __forceinline__ bool pool_route(float y0, float y1, float mu, float s
 // otherwise da = dout (plain BatchNorm backward).  grid = (C, S).
 // bcast != 0 (FUSED only): dp[row][j] = g[row] * bcast for every j — the gradient of a global
 // average pool that was fused behind the max-pool (g = dG [N*C], bcast = 1/Lp).
-template <bool FUSED, bool AL8>
+template <bool FUSED, bool AL8, bool YH = false>
 __global__ __launch_bounds__(kBlock) void bn_bwd_reduce_kernel(
     const float *__restrict__ y, const float *__restrict__ g, const float *__restrict__ gamma,
     const float *__restrict__ beta, const float *__restrict__ mean,
     const float *__restrict__ invstd, float *__restrict__ partials, int N, int C, int L, int S,
-    float bcast) {
+    float bcast, int ldyy) {
     __shared__ float red[4][2];
     const int c = blockIdx.x, s = blockIdx.y, tl = threadIdx.x;
     const int n0 = (int)((long long)N * s / S), n1 = (int)((long long)N * (s + 1) / S);
@@ -235,12 +247,11 @@ __global__ __launch_bounds__(kBlock) void bn_bwd_reduce_kernel(
             const int ic = live[u] ? idx : tl;                     // clamp to this thread's first (valid) element
             const int nl = ic / per, j = ic - nl * per;
             const size_t row = (size_t)(n0 + nl) * C + c;
-            const float *r = y + row * L;
             if (FUSED) {
-                ld_pair<AL8>(r + 2 * j, y0[u], y1[u]);
+                ld_pair_y<AL8, YH>(y, row, ldyy, 2 * j, y0[u], y1[u]);
                 d[u] = bcast != 0.f ? g[row] * bcast : g[row * Lp + j];
             } else {
-                y0[u] = r[j]; y1[u] = 0.f;
+                y0[u] = y[row * ldyy + j]; y1[u] = 0.f;
                 d[u] = g[row * L + j];
             }
         }
@@ -395,11 +406,11 @@ __device__ __forceinline__ void store_n16(u16n *dst, const float *v) {
 
 // p [N][C][Lp] fp32 (may be NULL) and pb[g][c][pos][16] with pb[.., j + shift, s] = p[16g + s][c][j].
 // grid = (ceil(PX/256), C, G)
-template <bool FIN, bool AL8>
+template <bool FIN, bool AL8, bool YH = false>
 __global__ __launch_bounds__(kBlock) void bn_relu_pool_fwd_n16_kernel(
     const float *__restrict__ y, const float *__restrict__ gamma, const float *__restrict__ beta,
     const float *__restrict__ mean, const float *__restrict__ invstd, float *__restrict__ p,
-    u16n *__restrict__ pb, int N, int C, int L, int Lp, int PX, int shift, BnFin fin) {
+    u16n *__restrict__ pb, int N, int C, int L, int Lp, int PX, int shift, BnFin fin, int ldyy) {
     const int pos = blockIdx.x * kBlock + threadIdx.x, c = blockIdx.y, g = blockIdx.z;
     float mu, is;
     if (FIN) bn_finalize_block(fin, c, blockIdx.x == 0 && g == 0, mu, is);
@@ -412,7 +423,7 @@ __global__ __launch_bounds__(kBlock) void bn_relu_pool_fwd_n16_kernel(
     float y0[16], y1[16];
 #pragma unroll
     for (int s = 0; s < 16; ++s)                     // 16 unconditional, clamped pair loads in flight
-        ld_pair<AL8>(y + ((size_t)min(16 * g + s, N - 1) * C + c) * L + 2 * jc, y0[s], y1[s]);
+        ld_pair_y<AL8, YH>(y, (size_t)min(16 * g + s, N - 1) * C + c, ldyy, 2 * jc, y0[s], y1[s]);
     __builtin_amdgcn_sched_barrier(0);
     float v[16];
 #pragma unroll
@@ -430,13 +441,13 @@ __global__ __launch_bounds__(kBlock) void bn_relu_pool_fwd_n16_kernel(
 // dy [N][C][ldy] fp32 (may be NULL: the first layer has no input gradient) and dyb[g][c][t][16], t < PA, zero
 // past the row; the combine of the S reduce partials is folded in as in bn_bwd_dx_kernel.
 // grid = (ceil(PA/2/256), C, G); thread <-> output pair (2j, 2j+1) of the 16 samples of group g.
-template <bool AL8>
+template <bool AL8, bool YH = false>
 __global__ __launch_bounds__(kBlock) void bn_bwd_dx_n16_kernel(
     const float *__restrict__ y, const float *__restrict__ g_in, const float *__restrict__ gamma,
     const float *__restrict__ beta, const float *__restrict__ mean, const float *__restrict__ invstd,
     const float *__restrict__ partials, int S, double M, float *__restrict__ dgamma,
     float *__restrict__ dbeta, float *__restrict__ dy, int ldy, u16n *__restrict__ dyb, int PA, int N,
-    int C, int L, float bcast, int train, unsigned *__restrict__ dyh) {
+    int C, int L, float bcast, int train, unsigned *__restrict__ dyh, int ldyy) {
     __shared__ double red[4][2];
     __shared__ float kk[2];
     const int c = blockIdx.y, g = blockIdx.z, tl = threadIdx.x;
@@ -472,7 +483,8 @@ __global__ __launch_bounds__(kBlock) void bn_bwd_dx_n16_kernel(
 #pragma unroll
     for (int s = 0; s < 16; ++s) {                   // 48 unconditional, clamped loads in flight
         const size_t row = (size_t)min(16 * g + s, N - 1) * C + c;
-        if (AL8) ld_pair<true>(y + row * L + min(t0, L - 2), y0[s], y1[s]);      // (pad pairs read the row's last pair: unused)
+        if (YH) ld_pair_y<true, true>(y, row, ldyy, min(t0, (L - 1) & ~1), y0[s], y1[s]);   // (odd L: the last dword's high half is row padding, unused)
+        else if (AL8) ld_pair<true>(y + row * L + min(t0, L - 2), y0[s], y1[s]);      // (pad pairs read the row's last pair: unused)
         else { y0[s] = y[row * L + ta]; y1[s] = y[row * L + tb]; }
         d[s] = bcast != 0.f ? g_in[row] * bcast : (Lp > 0 ? g_in[row * Lp + jc] : 0.f);
     }
@@ -620,25 +632,29 @@ static int pool_fwd_impl(const BnFin *fin, const float *y, const float *gamma, c
 }
 
 static int pool_gap_fwd_impl(const BnFin *fin, const float *y, const float *gamma, const float *beta,
-                             const float *mean, const float *invstd, float *g, int N, int C, int L, hipStream_t st) {
+                             const float *mean, const float *invstd, float *g, int N, int C, int L, hipStream_t st,
+                             bool yh = false, int ldy = 0) {
     int rc = check_ncl("bn_relu_pool_gap_fwd", N, C, L);
     if (rc) return rc;
     ECG_REQUIRE(y && gamma && beta && mean && invstd && g, "bn_relu_pool_gap_fwd: null pointer");
     ECG_REQUIRE(L >= 2, "bn_relu_pool_gap_fwd: L=%d leaves an empty pooled row", L);
     int S2 = cdiv(4096, C);
     if (S2 > cdiv(N, 4)) S2 = cdiv(N, 4);          // four rows (one per wave) in flight per workgroup
-    if (fin)
+    if (yh)         // bf16 activation storage (train mode: always with the statistics combine)
+        hipLaunchKernelGGL((bn_relu_pool_gap_fwd_kernel<true, true>), dim3(C, S2), dim3(kBlock), 0, st, y, gamma, beta,
+                           mean, invstd, g, N, C, L, L / 2, S2, *fin, ldy);
+    else if (fin)
         hipLaunchKernelGGL(bn_relu_pool_gap_fwd_kernel<true>, dim3(C, S2), dim3(kBlock), 0, st, y, gamma, beta, mean,
-                           invstd, g, N, C, L, L / 2, S2, *fin);
+                           invstd, g, N, C, L, L / 2, S2, *fin, L);
     else
         hipLaunchKernelGGL(bn_relu_pool_gap_fwd_kernel<false>, dim3(C, S2), dim3(kBlock), 0, st, y, gamma, beta, mean,
-                           invstd, g, N, C, L, L / 2, S2, BnFin{});
+                           invstd, g, N, C, L, L / 2, S2, BnFin{}, L);
     return check_launch("bn_relu_pool_gap_fwd_kernel");
 }
 
 static int pool_fwd_n16_impl(const BnFin *fin, const float *y, const float *gamma, const float *beta,
                              const float *mean, const float *invstd, float *p, void *p_n16, int N, int C, int L,
-                             int PX, int shift, hipStream_t st) {
+                             int PX, int shift, hipStream_t st, bool yh = false, int ldy = 0) {
     int rc = check_ncl("bn_relu_pool_fwd_n16", N, C, L);
     if (rc) return rc;
     ECG_REQUIRE(y && gamma && beta && mean && invstd && p_n16, "bn_relu_pool_fwd_n16: null pointer");
@@ -651,8 +667,11 @@ static int pool_fwd_n16_impl(const BnFin *fin, const float *y, const float *gamm
     const BnFin f = fin ? *fin : BnFin{};
 #define ECG_POOLN(FIN, AL8) hipLaunchKernelGGL((bn_relu_pool_fwd_n16_kernel<FIN, AL8>), dim3(cdiv(PX, kBlock), C, G), \
                                                dim3(kBlock), 0, st, y, gamma, beta, mean, invstd, p,                   \
-                                               static_cast<u16n *>(p_n16), N, C, L, Lp, PX, shift, f)
-    if (fin) { if (al8) ECG_POOLN(true, true); else ECG_POOLN(true, false); }
+                                               static_cast<u16n *>(p_n16), N, C, L, Lp, PX, shift, f, L)
+    if (yh)
+        hipLaunchKernelGGL((bn_relu_pool_fwd_n16_kernel<true, true, true>), dim3(cdiv(PX, kBlock), C, G), dim3(kBlock), 0, st,
+                           y, gamma, beta, mean, invstd, p, static_cast<u16n *>(p_n16), N, C, L, Lp, PX, shift, f, ldy);
+    else if (fin) { if (al8) ECG_POOLN(true, true); else ECG_POOLN(true, false); }
     else { if (al8) ECG_POOLN(false, true); else ECG_POOLN(false, false); }
 #undef ECG_POOLN
     return check_launch("bn_relu_pool_fwd_n16_kernel");
@@ -695,6 +714,25 @@ ECG_API int ecg_bn_stats_relu_pool_fwd(const float *stat_partials, int P, long l
     return pool_fwd_n16_impl(&f, y, gamma, beta, mean, invstd, out, p_n16, N, C, L, PX, shift, as_stream(stream));
 }
 
+// the same for a y that ecg_conv1d_fwd_bf16_yh wrote as bf16 [N][C][ldy] (bf16 activation storage);
+// mode 1 (pool + global average) or 2 (pool -> fp32 out (may be NULL) + n16 copy) only
+ECG_API int ecg_bn_stats_relu_pool_fwd_yh(const float *stat_partials, int P, long long count, float *running_mean,
+                                          float *running_var, long long *num_batches_tracked, float momentum,
+                                          float eps, const void *y_bf16, int ldy, const float *gamma,
+                                          const float *beta, float *mean, float *invstd, float *out, void *p_n16,
+                                          int N, int C, int L, int PX, int shift, int mode, ecg_stream_t stream) {
+    const BnFin f{stat_partials, P, (double)count, mean, invstd, running_mean, running_var, num_batches_tracked,
+                  momentum, eps};
+    int rc = check_fin("bn_stats_relu_pool_fwd_yh", f, C);
+    if (rc) return rc;
+    ECG_REQUIRE(mode == 1 || mode == 2, "bn_stats_relu_pool_fwd_yh: mode %d", mode);
+    ECG_REQUIRE(y_bf16 && ldy >= L && ldy % 2 == 0 && (reinterpret_cast<uintptr_t>(y_bf16) & 3) == 0,
+                "bn_stats_relu_pool_fwd_yh: bf16 y needs an even row stride >= L and a 4-byte aligned base");
+    const float *y = static_cast<const float *>(y_bf16);
+    if (mode == 1) return pool_gap_fwd_impl(&f, y, gamma, beta, mean, invstd, out, N, C, L, as_stream(stream), true, ldy);
+    return pool_fwd_n16_impl(&f, y, gamma, beta, mean, invstd, out, p_n16, N, C, L, PX, shift, as_stream(stream), true, ldy);
+}
+
 ECG_API size_t ecg_bn_relu_pool_bwd_ws_floats(int N, int C, int L) {
     (void)L;
     return (size_t)C * stat_splits(N, C) * 2 + (size_t)C * 2;
@@ -711,10 +749,10 @@ static int bn_bwd_impl(const float *y, const float *g, const float *gamma, const
     const bool al8 = FUSED && pairs_aligned(y, L);
     if (al8)
         hipLaunchKernelGGL((bn_bwd_reduce_kernel<FUSED, true>), dim3(C, S), dim3(kBlock), 0, st, y, g, gamma,
-                           beta, mean, invstd, partials, N, C, L, S, bcast);
+                           beta, mean, invstd, partials, N, C, L, S, bcast, L);
     else
         hipLaunchKernelGGL((bn_bwd_reduce_kernel<FUSED, false>), dim3(C, S), dim3(kBlock), 0, st, y, g, gamma,
-                           beta, mean, invstd, partials, N, C, L, S, bcast);
+                           beta, mean, invstd, partials, N, C, L, S, bcast, L);
     int rc = check_launch("bn_bwd_reduce_kernel");
     if (rc) return rc;
     // dx pass with the combine of the reduce partials folded in (no finalize launch)
@@ -831,38 +869,57 @@ ECG_API int ecg_bn_relu_pool_gap_bwd(const float *y, const float *dg, const floa
 }
 
 // ---- mixed-precision producers (see the kernels above) -------------------------------------------------
+// y: fp32 [N][C][L], or (yh) bf16 [N][C][ldyy] with an even row stride
+static int bwd_n16_impl(const char *who, const float *y, bool yh, int ldyy, const float *dp, const float *gamma,
+                        const float *beta, const float *mean, const float *invstd, float *dy, int ldy, void *dy_n16,
+                        int PA, float *dgamma, float *dbeta, float *ws, int N, int C, int L, int train, int gap,
+                        void *dy_bf16, hipStream_t st) {
+    int rc = check_ncl(who, N, C, L);
+    if (rc) return rc;
+    ECG_REQUIRE(y && dp && gamma && beta && mean && invstd && dy_n16 && ws, "%s: null pointer", who);
+    ECG_REQUIRE(L >= 2, "%s: L=%d leaves an empty pooled row", who, L);
+    ECG_REQUIRE(PA >= L && PA % 2 == 0, "%s: PA=%d must be even and >= L=%d", who, PA, L);
+    ECG_REQUIRE(!dy || (ldy >= L && ldy <= PA), "%s: dY row stride %d outside [L, PA]", who, ldy);
+    ECG_REQUIRE((reinterpret_cast<uintptr_t>(dy_n16) & 15) == 0, "%s: n16 output must be 16-byte aligned", who);
+    ECG_REQUIRE((reinterpret_cast<uintptr_t>(dy_bf16) & 3) == 0, "%s: bf16 dY must be 4-byte aligned", who);
+    ECG_REQUIRE(!yh || (ldyy >= L && ldyy % 2 == 0 && (reinterpret_cast<uintptr_t>(y) & 3) == 0),
+                "%s: bf16 y needs an even row stride >= L and a 4-byte aligned base", who);
+    const float bcast = gap ? 1.0f / (float)(L / 2) : 0.f;
+    const int S = stat_splits(N, C);
+    const bool al8 = !yh && pairs_aligned(y, L);
+#define ECG_RED(AL8, YH) hipLaunchKernelGGL((bn_bwd_reduce_kernel<true, AL8, YH>), dim3(C, S), dim3(kBlock), 0, st, y, dp, \
+                                            gamma, beta, mean, invstd, ws, N, C, L, S, bcast, yh ? ldyy : L)
+    if (yh) ECG_RED(true, true);
+    else if (al8) ECG_RED(true, false);
+    else ECG_RED(false, false);
+#undef ECG_RED
+    rc = check_launch("bn_bwd_reduce_kernel");
+    if (rc) return rc;
+    const int G = cdiv(N, 16);
+#define ECG_DXN(AL8, YH) hipLaunchKernelGGL((bn_bwd_dx_n16_kernel<AL8, YH>), dim3(cdiv(PA / 2, kBlock), C, G), dim3(kBlock), \
+                                            0, st, y, dp, gamma, beta, mean, invstd, ws, S, (double)N * L, dgamma, dbeta, dy,  \
+                                            ldy, static_cast<u16n *>(dy_n16), PA, N, C, L, bcast, train,                       \
+                                            static_cast<unsigned *>(dy_bf16), yh ? ldyy : L)
+    if (yh) ECG_DXN(true, true);
+    else if (al8) ECG_DXN(true, false);
+    else ECG_DXN(false, false);
+#undef ECG_DXN
+    return check_launch("bn_bwd_dx_n16_kernel");
+}
+
 ECG_API int ecg_bn_relu_pool_bwd_n16(const float *y, const float *dp, const float *gamma, const float *beta,
                                      const float *mean, const float *invstd, float *dy, int ldy, void *dy_n16,
                                      int PA, float *dgamma, float *dbeta, float *ws, int N, int C, int L,
                                      int train, int gap, void *dy_bf16, ecg_stream_t stream) {
-    int rc = check_ncl("bn_relu_pool_bwd_n16", N, C, L);
-    if (rc) return rc;
-    ECG_REQUIRE(y && dp && gamma && beta && mean && invstd && dy_n16 && ws, "bn_relu_pool_bwd_n16: null pointer");
-    ECG_REQUIRE(L >= 2, "bn_relu_pool_bwd_n16: L=%d leaves an empty pooled row", L);
-    ECG_REQUIRE(PA >= L && PA % 2 == 0, "bn_relu_pool_bwd_n16: PA=%d must be even and >= L=%d", PA, L);
-    ECG_REQUIRE(!dy || (ldy >= L && ldy <= PA), "bn_relu_pool_bwd_n16: dY row stride %d outside [L, PA]", ldy);
-    ECG_REQUIRE((reinterpret_cast<uintptr_t>(dy_n16) & 15) == 0, "bn_relu_pool_bwd_n16: n16 output must be 16-byte aligned");
-    ECG_REQUIRE((reinterpret_cast<uintptr_t>(dy_bf16) & 3) == 0, "bn_relu_pool_bwd_n16: bf16 dY must be 4-byte aligned");
-    const float bcast = gap ? 1.0f / (float)(L / 2) : 0.f;
-    const int S = stat_splits(N, C);
-    hipStream_t st = as_stream(stream);
-    const bool al8 = pairs_aligned(y, L);
-    if (al8)
-        hipLaunchKernelGGL((bn_bwd_reduce_kernel<true, true>), dim3(C, S), dim3(kBlock), 0, st, y, dp, gamma, beta, mean,
-                           invstd, ws, N, C, L, S, bcast);
-    else
-        hipLaunchKernelGGL((bn_bwd_reduce_kernel<true, false>), dim3(C, S), dim3(kBlock), 0, st, y, dp, gamma, beta, mean,
-                           invstd, ws, N, C, L, S, bcast);
-    rc = check_launch("bn_bwd_reduce_kernel");
-    if (rc) return rc;
-    const int G = cdiv(N, 16);
-    if (al8)
-        hipLaunchKernelGGL(bn_bwd_dx_n16_kernel<true>, dim3(cdiv(PA / 2, kBlock), C, G), dim3(kBlock), 0, st, y, dp, gamma,
-                           beta, mean, invstd, ws, S, (double)N * L, dgamma, dbeta, dy, ldy, static_cast<u16n *>(dy_n16),
-                           PA, N, C, L, bcast, train, static_cast<unsigned *>(dy_bf16));
-    else
-        hipLaunchKernelGGL(bn_bwd_dx_n16_kernel<false>, dim3(cdiv(PA / 2, kBlock), C, G), dim3(kBlock), 0, st, y, dp, gamma,
-                           beta, mean, invstd, ws, S, (double)N * L, dgamma, dbeta, dy, ldy, static_cast<u16n *>(dy_n16),
-                           PA, N, C, L, bcast, train, static_cast<unsigned *>(dy_bf16));
-    return check_launch("bn_bwd_dx_n16_kernel");
+    return bwd_n16_impl("bn_relu_pool_bwd_n16", y, false, L, dp, gamma, beta, mean, invstd, dy, ldy, dy_n16, PA, dgamma,
+                        dbeta, ws, N, C, L, train, gap, dy_bf16, as_stream(stream));
+}
+
+// the same with y as ecg_conv1d_fwd_bf16_yh wrote it: bf16 [N][C][ldyy]
+ECG_API int ecg_bn_relu_pool_bwd_n16_yh(const void *y_bf16, int ldyy, const float *dp, const float *gamma,
+                                        const float *beta, const float *mean, const float *invstd, float *dy, int ldy,
+                                        void *dy_n16, int PA, float *dgamma, float *dbeta, float *ws, int N, int C,
+                                        int L, int train, int gap, void *dy_bf16, ecg_stream_t stream) {
+    return bwd_n16_impl("bn_relu_pool_bwd_n16_yh", static_cast<const float *>(y_bf16), true, ldyy, dp, gamma, beta, mean,
+                        invstd, dy, ldy, dy_n16, PA, dgamma, dbeta, ws, N, C, L, train, gap, dy_bf16, as_stream(stream));
 }

@@ -108,11 +108,14 @@ __global__ void pack_weights_bf16_kernel(const float *__restrict__ w, u16 *__res
 //   * WRES: layers with at most two 16-channel chunks (blocks 0 and 1 forward) keep their whole weight slice
 //     resident — image 0 holds chunk 0, image 1 chunk 1 (or chunk 0 again), loaded once per workgroup; only x tiles
 //     stream after that.
-template <int CO_T, int T_T, int WCO, int WT, bool STATS, bool XH = false, bool WRES = false>
+//   * YH: the OUTPUT is stored as bf16 ([N][C_out][ldyo] u16, row stride ldyo >= Lo) — bf16 activation storage of the
+//     train step: the BatchNorm passes then read half the bytes.  The statistics are taken over the ROUNDED values,
+//     i.e. exactly over the tensor the BatchNorm passes will read.
+template <int CO_T, int T_T, int WCO, int WT, bool STATS, bool XH = false, bool WRES = false, bool YH = false>
 __global__ __launch_bounds__(64 * WCO * WT) void conv1d_mfma_bf16_fwd_kernel(
     const float *__restrict__ x, const u16 *__restrict__ wb, const float *__restrict__ bias,
     float *__restrict__ y, float *__restrict__ partials, int Cin, int Cout, int L, int Lo, int pad,
-    int tiles_t, int N, int G, int ldx) {
+    int tiles_t, int N, int G, int ldx, int ldyo) {
     constexpr int NW = WCO * WT, NT = 64 * NW;
     static_assert(NW == 4 || NW == 8, "4 or 8 waves per workgroup");
     constexpr int KK = kKB;
@@ -274,22 +277,28 @@ __global__ __launch_bounds__(64 * WCO * WT) void conv1d_mfma_bf16_fwd_kernel(
     };
 
     // ---- epilogue of a finished tile: one (accumulator row r, channel group i) item per call ---------
-    float *ytile = y;                    // (n, co0, t0) of the finished tile
+    float *ytile = y;                    // (n, co0, t0) of the finished tile (YH: the same in u16 elements)
     int pt0 = 0;
-    const int ylane = (wco + 4 * half) * Lo + wt + l31;
+    const int ylane = (wco + 4 * half) * ldyo + wt + l31;
     auto epilogue_item = [&](int it) {
         const int i = it >> 4, r = it & 15;
         const int bi = __float_as_int(p_b[i]);
         const float blo = __int_as_float(__builtin_amdgcn_readlane(bi, r));
         const float bhi = __int_as_float(__builtin_amdgcn_readlane(bi, r + 32));
         const float bv = half ? bhi : blo;
-        float *yr = ytile + (32 * i + (r & 3) + 8 * (r >> 2)) * Lo + ylane;
+        const int yoff = (32 * i + (r & 3) + 8 * (r >> 2)) * ldyo + ylane;
+        float *yr = ytile + yoff;
+        u16 *yhr = reinterpret_cast<u16 *>(ytile) + yoff;
         float s = 0.f, q = 0.f;
 #pragma unroll
         for (int j = 0; j < MT; ++j) {
-            const float v = acc[i][j][r] + bv;
+            float v = acc[i][j][r] + bv;
             if (pt0 + wt + 32 * j + l31 < Lo) {
-                yr[32 * j] = v;
+                if (YH) {
+                    const u16 h = __builtin_bit_cast(u16, (__bf16)v);
+                    yhr[32 * j] = h;
+                    v = __uint_as_float((unsigned)h << 16);
+                } else yr[32 * j] = v;
                 if (STATS) { s += v; q = __fmaf_rn(v, v, q); }
             }
         }
@@ -372,7 +381,8 @@ __global__ __launch_bounds__(64 * WCO * WT) void conv1d_mfma_bf16_fwd_kernel(
         if (q == 0) ECG_STAMPB_AT(2);
         if (++cc == nchunks) {                     // tile complete: store it and go straight on
             cc = 0;
-            ytile = y + ((size_t)cn * Cout + co0) * Lo + ctt * T_T;
+            ytile = YH ? reinterpret_cast<float *>(reinterpret_cast<u16 *>(y) + ((size_t)cn * Cout + co0) * ldyo + ctt * T_T)
+                       : y + ((size_t)cn * Cout + co0) * ldyo + ctt * T_T;
             pt0 = ctt * T_T;
             // only the x loads of the chunk after next are in flight here; the epilogue does not touch their registers
 #pragma unroll
@@ -449,45 +459,44 @@ size_t bf16_packed_elems(int Cred, int Cout, int K) {       // reduction channel
 }
 
 template <int CO_T, int T_T, int WCO, int WT>
-static void launch_bf16(const void *x, int ldx, bool xh, const u16 *wb, const float *bias, float *y, float *partials,
-                        int N, int Cin, int Cout, int L, int Lo, int pad, int G, hipStream_t st) {
+static void launch_bf16(const void *x, int ldx, bool xh, const u16 *wb, const float *bias, float *y, int ldyo, bool yh,
+                        float *partials, int N, int Cin, int Cout, int L, int Lo, int pad, int G, hipStream_t st) {
     const int tiles_t = cdiv(Lo, T_T);
     dim3 grid((unsigned)((size_t)(Cout / CO_T) * G)), block(64 * WCO * WT);
     const float *xf = static_cast<const float *>(x);
-    if (xh)         // bf16 input (the input-gradient conv: no bias, no statistics)
-        hipLaunchKernelGGL((conv1d_mfma_bf16_fwd_kernel<CO_T, T_T, WCO, WT, false, true>), grid, block, 0, st,
-                           xf, wb, bias, y, partials, Cin, Cout, L, Lo, pad, tiles_t, N, G, ldx);
+#define ECG_BF(STATS, XH, WRES, YH)                                                                                    \
+    hipLaunchKernelGGL((conv1d_mfma_bf16_fwd_kernel<CO_T, T_T, WCO, WT, STATS, XH, WRES, YH>), grid, block, 0, st, xf, \
+                       wb, bias, y, partials, Cin, Cout, L, Lo, pad, tiles_t, N, G, ldx, ldyo)
+    if (yh) {       // bf16 activation storage (train-mode forward: always with statistics)
+        if (Cin <= 2 * kCB) ECG_BF(true, false, true, true);
+        else ECG_BF(true, false, false, true);
+    } else if (xh)  // bf16 input (the input-gradient conv: no bias, no statistics)
+        ECG_BF(false, true, false, false);
     else if (Cin <= 2 * kCB) {          // at most two chunks: the weight slice stays resident in the two LDS images
-        if (partials)
-            hipLaunchKernelGGL((conv1d_mfma_bf16_fwd_kernel<CO_T, T_T, WCO, WT, true, false, true>), grid, block, 0, st,
-                               xf, wb, bias, y, partials, Cin, Cout, L, Lo, pad, tiles_t, N, G, ldx);
-        else
-            hipLaunchKernelGGL((conv1d_mfma_bf16_fwd_kernel<CO_T, T_T, WCO, WT, false, false, true>), grid, block, 0, st,
-                               xf, wb, bias, y, partials, Cin, Cout, L, Lo, pad, tiles_t, N, G, ldx);
-    } else if (partials)
-        hipLaunchKernelGGL((conv1d_mfma_bf16_fwd_kernel<CO_T, T_T, WCO, WT, true>), grid, block, 0, st,
-                           xf, wb, bias, y, partials, Cin, Cout, L, Lo, pad, tiles_t, N, G, ldx);
-    else
-        hipLaunchKernelGGL((conv1d_mfma_bf16_fwd_kernel<CO_T, T_T, WCO, WT, false>), grid, block, 0, st,
-                           xf, wb, bias, y, partials, Cin, Cout, L, Lo, pad, tiles_t, N, G, ldx);
+        if (partials) ECG_BF(true, false, true, false);
+        else ECG_BF(false, false, true, false);
+    } else if (partials) ECG_BF(true, false, false, false);
+    else ECG_BF(false, false, false, false);
+#undef ECG_BF
 }
 
-// x: fp32 [N][Cin][L] (xh false, ldx ignored) or bf16 [N][Cin][ldx] with rows zero-filled past L (xh true)
-static int bf16_fwd_any(const void *x, int ldx, bool xh, const void *wb, const float *bias, float *y, float *partials,
-                        int N, int Cin, int Cout, int L, int K, int pad, hipStream_t st) {
+// x: fp32 [N][Cin][L] (xh false, ldx ignored) or bf16 [N][Cin][ldx] with rows zero-filled past L (xh true);
+// y: fp32 [N][Cout][ldyo] or (yh, with statistics) bf16 [N][Cout][ldyo]
+static int bf16_fwd_any(const void *x, int ldx, bool xh, const void *wb, const float *bias, float *y, int ldyo, bool yh,
+                        float *partials, int N, int Cin, int Cout, int L, int K, int pad, hipStream_t st) {
     const int Lo = L + 2 * pad - K + 1;
     const u16 *w = static_cast<const u16 *>(wb);
     const Bf16Cfg c = bf16_cfg(N, Cout, Lo);
-    if (c.co_t == 128) launch_bf16<128, 256, 2, 4>(x, ldx, xh, w, bias, y, partials, N, Cin, Cout, L, Lo, pad, c.G, st);
-    else if (c.co_t == 64 && c.t_t == 256) launch_bf16<64, 256, 1, 4>(x, ldx, xh, w, bias, y, partials, N, Cin, Cout, L, Lo, pad, c.G, st);
-    else if (c.co_t == 64) launch_bf16<64, 128, 2, 2>(x, ldx, xh, w, bias, y, partials, N, Cin, Cout, L, Lo, pad, c.G, st);
-    else launch_bf16<32, 256, 1, 4>(x, ldx, xh, w, bias, y, partials, N, Cin, Cout, L, Lo, pad, c.G, st);
+    if (c.co_t == 128) launch_bf16<128, 256, 2, 4>(x, ldx, xh, w, bias, y, ldyo, yh, partials, N, Cin, Cout, L, Lo, pad, c.G, st);
+    else if (c.co_t == 64 && c.t_t == 256) launch_bf16<64, 256, 1, 4>(x, ldx, xh, w, bias, y, ldyo, yh, partials, N, Cin, Cout, L, Lo, pad, c.G, st);
+    else if (c.co_t == 64) launch_bf16<64, 128, 2, 2>(x, ldx, xh, w, bias, y, ldyo, yh, partials, N, Cin, Cout, L, Lo, pad, c.G, st);
+    else launch_bf16<32, 256, 1, 4>(x, ldx, xh, w, bias, y, ldyo, yh, partials, N, Cin, Cout, L, Lo, pad, c.G, st);
     return check_launch("conv1d_mfma_bf16_fwd_kernel");
 }
 
 int bf16_fwd(const float *x, const void *wb, const float *bias, float *y, float *partials, int N,
              int Cin, int Cout, int L, int K, int pad, hipStream_t st) {
-    return bf16_fwd_any(x, L, false, wb, bias, y, partials, N, Cin, Cout, L, K, pad, st);
+    return bf16_fwd_any(x, L, false, wb, bias, y, L + 2 * pad - K + 1, false, partials, N, Cin, Cout, L, K, pad, st);
 }
 
 int bf16_pack(const float *w, void *wb_fwd, void *wb_bwd, int Co, int Ci, int K, hipStream_t st) {
@@ -606,6 +615,22 @@ ECG_API int ecg_conv1d_fwd_bf16(const float *x, const void *wb_fwd, const float 
     return bf16_fwd(x, wb_fwd, bias, y, stat_partials, N, C_in, C_out, L, K, pad, as_stream(stream));
 }
 
+// Train-mode forward with bf16 ACTIVATION STORAGE: y is written as bf16 [N][C_out][ldy] (ldy >= Lo, even), the
+// BatchNorm statistics partials (layout as ecg_conv1d_fwd_bf16) are taken over the rounded values.  The consumers are
+// ecg_bn_stats_relu_pool_fwd_yh and ecg_bn_relu_pool_bwd_n16_yh.
+ECG_API int ecg_conv1d_fwd_bf16_yh(const float *x, const void *wb_fwd, const float *bias, void *y_bf16, int ldy,
+                                   float *stat_partials, int N, int C_in, int C_out, int L, int K, int pad,
+                                   ecg_stream_t stream) {
+    int rc = check_bf16_shape("conv1d_fwd_bf16_yh", N, C_in, C_out, L, K, pad);
+    if (rc) return rc;
+    ECG_REQUIRE(x && wb_fwd && y_bf16 && stat_partials, "conv1d_fwd_bf16_yh: null pointer");
+    ECG_REQUIRE(bf16_fwd_supported(C_in, C_out, K, pad), "conv1d_fwd_bf16_yh: needs C_in %% 4 == 0, C_out %% 32 == 0");
+    ECG_REQUIRE(ldy >= L + 2 * pad - K + 1 && ldy % 2 == 0 && (reinterpret_cast<uintptr_t>(y_bf16) & 3) == 0,
+                "conv1d_fwd_bf16_yh: needs an even row stride >= Lo and a 4-byte aligned y");
+    return bf16_fwd_any(x, L, false, wb_fwd, bias, static_cast<float *>(y_bf16), ldy, true, stat_partials, N, C_in, C_out,
+                        L, K, pad, as_stream(stream));
+}
+
 // input gradient from a dY that is itself bf16: [N][C_out][ldy] u16, rows zero-filled from Lo to ldy, ldy even
 // (ecg_bn_relu_pool_bwd_n16 writes it that way) — half the bytes of the fp32 dY on both sides
 ECG_API int ecg_conv1d_bwd_data_bf16h(const void *dy_bf16, int ldy, const void *wb_bwd, float *dx, int N, int C_in,
@@ -617,7 +642,8 @@ ECG_API int ecg_conv1d_bwd_data_bf16h(const void *dy_bf16, int ldy, const void *
     ECG_REQUIRE(bf16_fwd_supported(C_out, C_in, K, padb), "conv1d_bwd_data_bf16h: needs C_out %% 4 == 0, C_in %% 32 == 0");
     ECG_REQUIRE(ldy >= Lo && ldy % 2 == 0 && (padb & 1) == 1 && (reinterpret_cast<uintptr_t>(dy_bf16) & 3) == 0,
                 "conv1d_bwd_data_bf16h: needs an even row stride >= Lo, odd K-1-pad and a 4-byte aligned dY");
-    return bf16_fwd_any(dy_bf16, ldy, true, wb_bwd, nullptr, dx, nullptr, N, C_out, C_in, Lo, K, padb, as_stream(stream));
+    return bf16_fwd_any(dy_bf16, ldy, true, wb_bwd, nullptr, dx, L, false, nullptr, N, C_out, C_in, Lo, K, padb,
+                        as_stream(stream));
 }
 
 ECG_API int ecg_conv1d_bwd_data_bf16(const float *dy, const void *wb_bwd, float *dx, int N, int C_in,

@@ -162,6 +162,16 @@ class conv_precision:
         return False
 
 
+_bf16_activation_storage = True
+
+
+def set_bf16_activation_storage(on):
+    """bf16 mode only: store the conv output y of a training ConvBlock as bf16 (what torch.autocast does) — the
+    BatchNorm passes are HBM-bound and y is their largest operand.  On by default; off keeps y in fp32."""
+    global _bf16_activation_storage
+    _bf16_activation_storage = bool(on)
+
+
 def conv1d_pack_bf16(w, need_bwd=True):
     Co, Ci, K = w.shape
     nf = _query("ecg_conv1d_bf16_packed_elems", Ci, Co, K)
@@ -362,15 +372,28 @@ class ConvBlockFn(torch.autograd.Function):
                       _f32(beta), _f32(running_mean), _f32(running_var), float(eps), _f32(g),
                       N, Ci, Co, Lin, K, pad, _st())
                 return g, None
-        if bf16:
-            y, partials, P = conv1d_forward_bf16_raw(x, w_fwd, b, Co, K, pad, want_stats=use_batch)
-        else:
-            y, partials, P = conv1d_forward_raw(x, w_fwd, b, Co, K, pad, want_stats=use_batch)
-        N, _, Lo = y.shape
+        N, Ci, Lin = x.shape
+        Lo = Lin + 2 * pad - K + 1
         p_n16, PX, shift = None, 0, 0
         if not gap and bf16 and need_grad and next_geom is not None and Lo >= 2:
             # mixed precision: p also as the next conv's weight-gradient operand (bf16, n16 layout)
             PX, shift = _query("ecg_conv1d_n16_positions", Lo // 2, next_geom[0], next_geom[1], 1), next_geom[1]
+        # bf16 activation storage: only when both consumers of y are the kernels that read it (the fused
+        # statistics + pool pass in its n16 / gap form now, the n16 BatchNorm backward later)
+        ldyh = 0
+        if (bf16 and _bf16_activation_storage and use_batch and need_grad and Lo >= 2 and (gap or PX) and (sup & 4)
+                and _query("ecg_conv1d_n16_positions", Lin, K, pad, 0)):
+            ldyh = (Lo + 7) & ~7
+        if ldyh:
+            y = torch.empty(N, Co, ldyh, dtype=torch.bfloat16, device=x.device)
+            P = _query("ecg_conv1d_fwd_bf16_stat_partials", N, Ci, Co, Lin, K, pad)
+            partials = _empty(x, Co * P * 2)
+            _call("ecg_conv1d_fwd_bf16_yh", _f32(x), L.ptr(w_fwd), _f32(b), L.ptr(y), ldyh, _f32(partials), N, Ci, Co, Lin,
+                  K, pad, _st())
+        elif bf16:
+            y, partials, P = conv1d_forward_bf16_raw(x, w_fwd, b, Co, K, pad, want_stats=use_batch)
+        else:
+            y, partials, P = conv1d_forward_raw(x, w_fwd, b, Co, K, pad, want_stats=use_batch)
         if PX:
             p_n16 = torch.empty(((N + 15) // 16) * Co * PX * 16, dtype=torch.bfloat16, device=x.device)
             ctx.mark_non_differentiable(p_n16)
@@ -382,10 +405,15 @@ class ConvBlockFn(torch.autograd.Function):
             rm, rv, cnt = (running_mean, running_var, nbt) if training else (None, None, None)
             if cnt is not None and cnt.dtype != torch.int64:
                 raise L.EcgHipError("num_batches_tracked must be int64")
-            mean, invstd = _empty(y, Co), _empty(y, Co)
-            _call("ecg_bn_stats_relu_pool_fwd", _f32(partials), P, N * Lo, _f32(rm), _f32(rv), L.ptr(cnt),
-                  _bn_momentum(momentum, nbt), float(eps), _f32(y), _f32(gamma), _f32(beta), _f32(mean), _f32(invstd),
-                  _f32(p), L.ptr(p_n16), N, Co, Lo, PX, shift, mode, _st())
+            mean, invstd = _empty(x, Co), _empty(x, Co)
+            if ldyh:
+                _call("ecg_bn_stats_relu_pool_fwd_yh", _f32(partials), P, N * Lo, _f32(rm), _f32(rv), L.ptr(cnt),
+                      _bn_momentum(momentum, nbt), float(eps), L.ptr(y), ldyh, _f32(gamma), _f32(beta), _f32(mean),
+                      _f32(invstd), _f32(p), L.ptr(p_n16), N, Co, Lo, PX, shift, mode, _st())
+            else:
+                _call("ecg_bn_stats_relu_pool_fwd", _f32(partials), P, N * Lo, _f32(rm), _f32(rv), L.ptr(cnt),
+                      _bn_momentum(momentum, nbt), float(eps), _f32(y), _f32(gamma), _f32(beta), _f32(mean), _f32(invstd),
+                      _f32(p), L.ptr(p_n16), N, Co, Lo, PX, shift, mode, _st())
         else:
             mean, invstd = bn_eval_stats(running_mean, running_var, eps)
             if gap:      # last block: AdaptiveAvgPool1d(1) folded in, the pooled tensor never exists
@@ -401,15 +429,16 @@ class ConvBlockFn(torch.autograd.Function):
         ctx.w_bwd, ctx.pad, ctx.batch_stats, ctx.gap = w_bwd, pad, use_batch, gap
         ctx.sink_keys = (_key(w), _key(b), _key(gamma), _key(beta))
         ctx.x_n16 = x_n16 if bf16 else None
+        ctx.ldyh, ctx.Lo = ldyh, Lo
         return p, p_n16
 
     @staticmethod
     def backward(ctx, dp, _dp_n16=None):
         x, w, y, gamma, beta, mean, invstd = ctx.saved_tensors
+        N, Co, Lo = y.shape[0], y.shape[1], ctx.Lo          # (y may be bf16 with padded rows: ctx.ldyh)
         if dp is None:          # (only possible with set_materialize_grads(False): p unused downstream)
-            dp = torch.zeros(y.shape[0], y.shape[1], *(() if ctx.gap else (y.shape[2] // 2,)), device=y.device)
+            dp = torch.zeros(N, Co, *(() if ctx.gap else (Lo // 2,)), device=y.device)
         dp = _contig(dp)
-        N, Co, Lo = y.shape
         Ci, Lin, K = x.shape[1], x.shape[2], w.shape[2]
         need_dx = ctx.needs_input_grad[0]
         kw, kb, kg, kbe = ctx.sink_keys
@@ -428,9 +457,14 @@ class ConvBlockFn(torch.autograd.Function):
             dy = _empty(y, N, Co, Lo) if (need_dx and not dyh_ok) else None
             dyh = torch.empty(N * Co * PA, dtype=torch.bfloat16, device=y.device) if dyh_ok else None
             dyb = torch.empty(G * Co * PA * 16, dtype=torch.bfloat16, device=y.device)
-            _call("ecg_bn_relu_pool_bwd_n16", _f32(y), _f32(dp), _f32(gamma), _f32(beta), _f32(mean), _f32(invstd),
-                  _f32(dy), Lo, L.ptr(dyb), PA, _f32(dgamma), _f32(dbeta), _f32(ws), N, Co, Lo,
-                  1 if ctx.batch_stats else 0, 1 if ctx.gap else 0, L.ptr(dyh), _st())
+            if ctx.ldyh:        # y was stored as bf16 [N][Co][ldyh]
+                _call("ecg_bn_relu_pool_bwd_n16_yh", L.ptr(y), ctx.ldyh, _f32(dp), _f32(gamma), _f32(beta), _f32(mean),
+                      _f32(invstd), _f32(dy), Lo, L.ptr(dyb), PA, _f32(dgamma), _f32(dbeta), _f32(ws), N, Co, Lo,
+                      1 if ctx.batch_stats else 0, 1 if ctx.gap else 0, L.ptr(dyh), _st())
+            else:
+                _call("ecg_bn_relu_pool_bwd_n16", _f32(y), _f32(dp), _f32(gamma), _f32(beta), _f32(mean), _f32(invstd),
+                      _f32(dy), Lo, L.ptr(dyb), PA, _f32(dgamma), _f32(dbeta), _f32(ws), N, Co, Lo,
+                      1 if ctx.batch_stats else 0, 1 if ctx.gap else 0, L.ptr(dyh), _st())
             xb = ctx.x_n16
             PX = _query("ecg_conv1d_n16_positions", Lin, K, ctx.pad, 1)
             if xb is None or xb.numel() != G * Ci * PX * 16:

@@ -485,8 +485,9 @@ def test_short_training_run_reduces_loss():
     assert set(out) == {"auroc_macro", "auprc_macro", "f1_macro", "bce_loss"} and np.isfinite(out["bce_loss"])
 
 
+@pytest.mark.parametrize("act_bf16", [True, False])
 @pytest.mark.parametrize("B,T", [(8, 5000), (19, 1000)])
-def test_bf16_mixed_precision_train_step_config5(B, T):
+def test_bf16_mixed_precision_train_step_config5(B, T, act_bf16):
     """BASELINE.json config 5 shape family: ECGCNN(num_labels=1) (AF binary), long windows, bf16
     conv operands.  No fp32-level parity is claimed: the step must track the fp32 CPU oracle at
     bf16 accuracy (the reference has no mixed precision to compare with).  B=19: a ragged group of 16 samples in
@@ -499,10 +500,14 @@ def test_bf16_mixed_precision_train_step_config5(B, T):
     R.seed_all(42)
     ref = R.RefECGCNN(num_labels=1).train()
     x, y = R.synthetic_batch(B, T, 1)
-    with hipF.conv_precision("bf16"):
-        logits = model(x.to(DEV))
-        loss = hipF.binary_cross_entropy_with_logits(logits, y.to(DEV))
-        loss.backward()
+    hipF.set_bf16_activation_storage(act_bf16)        # conv outputs kept as bf16 (default) or as fp32
+    try:
+        with hipF.conv_precision("bf16"):
+            logits = model(x.to(DEV))
+            loss = hipF.binary_cross_entropy_with_logits(logits, y.to(DEV))
+            loss.backward()
+    finally:
+        hipF.set_bf16_activation_storage(True)
     assert hipF.get_conv_precision() == "fp32"
     rl = ref(x)
     rloss = torch.nn.functional.binary_cross_entropy_with_logits(rl, y)

@@ -707,6 +707,82 @@ def test_bn_relu_pool_n16_producers_match_the_plain_passes(hip, oracle, shape):
         assert np.array_equal(_unpack_n16(dyb, G, C, PA), want)
 
 
+# (N, Ci, Co, L): every forward tile plan (32x256, 64x256, 64x128, 128x256), resident and streamed weights, odd rows
+# (row stride > L, last dword half padding), ragged sample groups
+@pytest.mark.parametrize("case", [(19, 12, 32, 300), (5, 32, 64, 257), (18, 64, 128, 125), (3, 128, 256, 77),
+                                  (2, 64, 128, 300), (2, 128, 256, 520)])
+@pytest.mark.parametrize("gap", [False, True])
+def test_bf16_activation_storage_equals_the_fp32_passes_on_the_rounded_tensor(hip, case, gap):
+    """bf16 activation storage (the conv output y of a training block kept as bf16): the conv's bf16 output is the
+    nearest-even rounding of its fp32 output, its statistics are those of the ROUNDED tensor, and the BatchNorm
+    passes that read the bf16 tensor give BIT-IDENTICAL results to the fp32-input passes run on that rounded tensor
+    (pooled output, n16 copy, mean / invstd / running statistics / counter; dY operands, dgamma, dbeta)."""
+    from ecg_hip import _lib as L
+    N, Ci, Co, Lin = case
+    Lo, Lp, G = Lin, Lin // 2, (N + 15) // 16
+    rng = np.random.default_rng(sum(case))
+    x = dev(rng.standard_normal((N, Ci, Lin)).astype(np.float32))
+    w = dev((rng.standard_normal((Co, Ci, 15)) / np.sqrt(Ci * 15)).astype(np.float32))
+    b = dev(rng.standard_normal(Co).astype(np.float32))
+    gamma, beta = dev((rng.random(Co) + 0.5).astype(np.float32)), dev(rng.standard_normal(Co).astype(np.float32) * 0.3)
+    wb_fwd, _ = hip.conv1d_pack_bf16(w, need_bwd=False)
+    y32, part32, P = hip.conv1d_forward_bf16_raw(x, wb_fwd, b, Co, 15, 7, want_stats=True)
+    ldy = (Lo + 7) & ~7
+    yh = torch.full((N, Co, ldy), float("nan"), dtype=torch.bfloat16, device="cuda")     # row padding stays NaN: must be ignored
+    part = torch.empty(Co * P * 2, device="cuda")
+    L.call("ecg_conv1d_fwd_bf16_yh", L.f32(x), L.ptr(wb_fwd), L.f32(b), L.ptr(yh), ldy, L.f32(part), N, Ci, Co, Lin, 15, 7,
+           L.stream())
+    yr = y32.to(torch.bfloat16)                       # nearest-even
+    assert torch.equal(yh[:, :, :Lo], yr)
+    assert bool(torch.isnan(yh[:, :, Lo:].float()).all())
+    yr32 = yr.to(torch.float32).contiguous()
+    # statistics of the rounded tensor (double reference)
+    st = part.view(Co, P, 2).double().sum(dim=1).cpu().numpy()
+    ref = yr32.double()
+    np.testing.assert_allclose(st[:, 0], ref.sum(dim=(0, 2)).cpu().numpy(), rtol=1e-5, atol=1e-3)
+    np.testing.assert_allclose(st[:, 1], (ref * ref).sum(dim=(0, 2)).cpu().numpy(), rtol=1e-5)
+    # forward pass: fp32 kernel on the rounded tensor with the SAME partials vs the bf16-input kernel
+    PX = L.query("ecg_conv1d_n16_positions", Lp, 15, 7, 1)
+    outs = []
+    for use_h in (False, True):
+        rm, rv = torch.zeros(Co, device="cuda"), torch.ones(Co, device="cuda")
+        nbt = torch.zeros((), dtype=torch.int64, device="cuda")
+        mean, invstd = torch.empty(Co, device="cuda"), torch.empty(Co, device="cuda")
+        out = torch.empty(N, Co, device="cuda") if gap else torch.empty(N, Co, Lp, device="cuda")
+        pb = None if gap else torch.full((G * Co * PX * 16,), 7.0, dtype=torch.bfloat16, device="cuda")
+        head = [L.f32(part), P, N * Lo, L.f32(rm), L.f32(rv), L.ptr(nbt), 0.1, 1e-5]
+        tail = [L.f32(gamma), L.f32(beta), L.f32(mean), L.f32(invstd), L.f32(out), L.ptr(pb), N, Co, Lo, 0 if gap else PX,
+                0 if gap else 7, 1 if gap else 2, L.stream()]
+        if use_h:
+            L.call("ecg_bn_stats_relu_pool_fwd_yh", *head, L.ptr(yh), ldy, *tail)
+        else:
+            L.call("ecg_bn_stats_relu_pool_fwd", *head, L.f32(yr32), *tail)
+        outs.append((out, pb, mean, invstd, rm, rv, nbt))
+    for a, c in zip(*outs):
+        assert (a is None and c is None) or torch.equal(a, c)
+    mean, invstd = outs[1][2], outs[1][3]
+    # backward pass
+    PA = L.query("ecg_conv1d_n16_positions", Lo, 15, 7, 0)
+    dp = dev(rng.standard_normal((N, Co) if gap else (N, Co, Lp)).astype(np.float32))
+    ws = torch.empty(L.query("ecg_bn_relu_pool_bwd_ws_floats", N, Co, Lo), device="cuda")
+    outs = []
+    for use_h in (False, True):
+        dy, dg, db = torch.empty(N, Co, Lo, device="cuda"), torch.empty(Co, device="cuda"), torch.empty(Co, device="cuda")
+        dyb = torch.full((G * Co * PA * 16,), 7.0, dtype=torch.bfloat16, device="cuda")
+        dyh = torch.full((N * Co * PA,), 7.0, dtype=torch.bfloat16, device="cuda")
+        tail = [L.f32(dp), L.f32(gamma), L.f32(beta), L.f32(mean), L.f32(invstd), L.f32(dy), Lo, L.ptr(dyb), PA, L.f32(dg),
+                L.f32(db), L.f32(ws), N, Co, Lo, 1, 1 if gap else 0, L.ptr(dyh), L.stream()]
+        if use_h:
+            L.call("ecg_bn_relu_pool_bwd_n16_yh", L.ptr(yh), ldy, *tail)
+        else:
+            L.call("ecg_bn_relu_pool_bwd_n16", L.f32(yr32), *tail)
+        outs.append((dy, dg, db, dyb, dyh))
+    for a, c in zip(*outs):
+        assert torch.equal(a, c)
+    with pytest.raises(L.EcgHipError, match="even row stride"):
+        L.call("ecg_bn_relu_pool_bwd_n16_yh", L.ptr(yh), Lo | 1, *tail)
+
+
 @pytest.mark.parametrize("case", [(19, 12, 32, 300), (37, 64, 128, 125), (16, 32, 64, 64)])
 def test_bf16_weight_grad_on_packed_operands_equals_the_packing_entry_point(hip, oracle, case):
     from ecg_hip import _lib as L
