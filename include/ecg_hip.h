@@ -162,23 +162,30 @@ int ecg_bn_relu_pool_bwd_n16(const float *y, const float *dp, const float *gamma
  * input gradient that reads a bf16 dY (ldy even, K-1-pad odd): half the bytes of the fp32 dY on both sides. */
 int ecg_conv1d_bwd_data_bf16h(const void *dy_bf16, int ldy, const void *wb_bwd, float *dx, int N, int C_in,
                               int C_out, int L, int K, int pad, ecg_stream_t stream);
-/* bf16 ACTIVATION STORAGE for the mixed-precision train step: the conv output y is stored as bf16
- * [N][C][ldy] (ldy even, >= L) and read as such by the BatchNorm passes — they are HBM-bound, y is their largest
- * operand.  ecg_conv1d_fwd_bf16_yh takes the BatchNorm statistics over the ROUNDED values (the tensor the passes read);
- * ecg_bn_stats_relu_pool_fwd_yh = ecg_bn_stats_relu_pool_fwd modes 1 / 2 on such a y; ecg_bn_relu_pool_bwd_n16_yh =
- * ecg_bn_relu_pool_bwd_n16 on such a y.  (torch.autocast stores the conv output the same way.) */
-int ecg_conv1d_fwd_bf16_yh(const float *x, const void *wb_fwd, const float *bias, void *y_bf16, int ldy,
-                           float *stat_partials, int N, int C_in, int C_out, int L, int K, int pad,
+/* bf16 ACTIVATION STORAGE for the mixed-precision train step (what torch.autocast stores too): the tensors BETWEEN the
+ * kernels of a training block chain are kept as bf16 — the BatchNorm passes are HBM-bound and these are their operands.
+ *   y   conv output:            bf16 [N][C][ldy], ldy even >= L (ecg_conv1d_fwd_bf16_yh; the BatchNorm statistics are
+ *       taken over the ROUNDED values, i.e. over the tensor the passes read)
+ *   p   pooled activation:      bf16 [N][C][ldp], rows zero-filled from L/2 to ldp (ecg_bn_stats_relu_pool_fwd_yh, mode 2,
+ *       p_bf16 non-NULL; the fp32 `out` may then be NULL) — read by the next block's ecg_conv1d_fwd_bf16_yh (x_bf16 != 0)
+ *   dp  gradient of p:          bf16 [N][C][ldp] (ecg_conv1d_bwd_data_bf16hh of the next block) — read by
+ *       ecg_bn_relu_pool_bwd_n16_yh (dp_bf16 != 0)
+ * ecg_bn_stats_relu_pool_fwd_yh = ecg_bn_stats_relu_pool_fwd modes 1 / 2 and ecg_bn_relu_pool_bwd_n16_yh =
+ * ecg_bn_relu_pool_bwd_n16 on such tensors: bit-identical to the fp32-input passes run on the rounded values. */
+int ecg_conv1d_fwd_bf16_yh(const void *x, int x_bf16, int ldx, const void *wb_fwd, const float *bias, void *y_bf16,
+                           int ldy, float *stat_partials, int N, int C_in, int C_out, int L, int K, int pad,
                            ecg_stream_t stream);
 int ecg_bn_stats_relu_pool_fwd_yh(const float *stat_partials, int P, long long count, float *running_mean,
                                   float *running_var, long long *num_batches_tracked, float momentum, float eps,
                                   const void *y_bf16, int ldy, const float *gamma, const float *beta, float *mean,
-                                  float *invstd, float *out, void *p_n16, int N, int C, int L, int PX, int shift,
-                                  int mode, ecg_stream_t stream);
-int ecg_bn_relu_pool_bwd_n16_yh(const void *y_bf16, int ldyy, const float *dp, const float *gamma,
+                                  float *invstd, float *out, void *p_n16, void *p_bf16, int ldp, int N, int C, int L,
+                                  int PX, int shift, int mode, ecg_stream_t stream);
+int ecg_bn_relu_pool_bwd_n16_yh(const void *y_bf16, int ldyy, const void *dp, int dp_bf16, int ldp, const float *gamma,
                                 const float *beta, const float *mean, const float *invstd, float *dy, int ldy,
                                 void *dy_n16, int PA, float *dgamma, float *dbeta, float *ws, int N, int C, int L,
                                 int train, int gap, void *dy_bf16, ecg_stream_t stream);
+int ecg_conv1d_bwd_data_bf16hh(const void *dy_bf16, int ldy, const void *wb_bwd, void *dx_bf16, int ldx, int N,
+                               int C_in, int C_out, int L, int K, int pad, ecg_stream_t stream);
 size_t ecg_conv1d_bwd_weight_bf16_packed_ws_floats(int N, int C_in, int C_out, int L, int K, int pad);
 int ecg_conv1d_bwd_weight_bias_bf16_packed(const void *dy_n16, const void *x_n16, float *dw, float *db,
                                            float *ws, int N, int C_in, int C_out, int L, int K, int pad,

@@ -218,12 +218,12 @@ __device__ __forceinline__ bool pool_route(float y0, float y1, float mu, float s
 // otherwise da = dout (plain BatchNorm backward).  grid = (C, S).
 // bcast != 0 (FUSED only): dp[row][j] = g[row] * bcast for every j — the gradient of a global
 // average pool that was fused behind the max-pool (g = dG [N*C], bcast = 1/Lp).
-template <bool FUSED, bool AL8, bool YH = false>
+template <bool FUSED, bool AL8, bool YH = false, bool DH = false>
 __global__ __launch_bounds__(kBlock) void bn_bwd_reduce_kernel(
     const float *__restrict__ y, const float *__restrict__ g, const float *__restrict__ gamma,
     const float *__restrict__ beta, const float *__restrict__ mean,
     const float *__restrict__ invstd, float *__restrict__ partials, int N, int C, int L, int S,
-    float bcast, int ldyy) {
+    float bcast, int ldyy, int ldp) {
     __shared__ float red[4][2];
     const int c = blockIdx.x, s = blockIdx.y, tl = threadIdx.x;
     const int n0 = (int)((long long)N * s / S), n1 = (int)((long long)N * (s + 1) / S);
@@ -249,7 +249,9 @@ __global__ __launch_bounds__(kBlock) void bn_bwd_reduce_kernel(
             const size_t row = (size_t)(n0 + nl) * C + c;
             if (FUSED) {
                 ld_pair_y<AL8, YH>(y, row, ldyy, 2 * j, y0[u], y1[u]);
-                d[u] = bcast != 0.f ? g[row] * bcast : g[row * Lp + j];
+                if (DH)         // dp is bf16 [N][C][ldp] (the next block's input gradient, written as bf16)
+                    d[u] = __uint_as_float((unsigned)reinterpret_cast<const unsigned short *>(g)[row * ldp + j] << 16);
+                else d[u] = bcast != 0.f ? g[row] * bcast : g[row * Lp + j];
             } else {
                 y0[u] = y[row * ldyy + j]; y1[u] = 0.f;
                 d[u] = g[row * L + j];
@@ -410,7 +412,8 @@ template <bool FIN, bool AL8, bool YH = false>
 __global__ __launch_bounds__(kBlock) void bn_relu_pool_fwd_n16_kernel(
     const float *__restrict__ y, const float *__restrict__ gamma, const float *__restrict__ beta,
     const float *__restrict__ mean, const float *__restrict__ invstd, float *__restrict__ p,
-    u16n *__restrict__ pb, int N, int C, int L, int Lp, int PX, int shift, BnFin fin, int ldyy) {
+    u16n *__restrict__ pb, int N, int C, int L, int Lp, int PX, int shift, BnFin fin, int ldyy,
+    u16n *__restrict__ ph, int ldp) {
     const int pos = blockIdx.x * kBlock + threadIdx.x, c = blockIdx.y, g = blockIdx.z;
     float mu, is;
     if (FIN) bn_finalize_block(fin, c, blockIdx.x == 0 && g == 0, mu, is);
@@ -434,6 +437,10 @@ __global__ __launch_bounds__(kBlock) void bn_relu_pool_fwd_n16_kernel(
         const bool live = in_row && 16 * g + s < N;
         v[s] = live ? m : 0.f;
         if (live && p) p[((size_t)(16 * g + s) * C + c) * Lp + j] = m;
+        // ph: p once more as bf16 [N][C][ldp] with the rows zero-filled from Lp to ldp — the NEXT conv's forward input
+        // (it reads half the bytes of the fp32 p, which is then not written at all)
+        if (ph && 16 * g + s < N && j >= 0 && j < ldp)
+            ph[((size_t)(16 * g + s) * C + c) * ldp + j] = __builtin_bit_cast(u16n, (__bf16)v[s]);
     }
     store_n16(pb + (((size_t)g * C + c) * PX + pos) * 16, v);
 }
@@ -441,13 +448,13 @@ __global__ __launch_bounds__(kBlock) void bn_relu_pool_fwd_n16_kernel(
 // dy [N][C][ldy] fp32 (may be NULL: the first layer has no input gradient) and dyb[g][c][t][16], t < PA, zero
 // past the row; the combine of the S reduce partials is folded in as in bn_bwd_dx_kernel.
 // grid = (ceil(PA/2/256), C, G); thread <-> output pair (2j, 2j+1) of the 16 samples of group g.
-template <bool AL8, bool YH = false>
+template <bool AL8, bool YH = false, bool DH = false>
 __global__ __launch_bounds__(kBlock) void bn_bwd_dx_n16_kernel(
     const float *__restrict__ y, const float *__restrict__ g_in, const float *__restrict__ gamma,
     const float *__restrict__ beta, const float *__restrict__ mean, const float *__restrict__ invstd,
     const float *__restrict__ partials, int S, double M, float *__restrict__ dgamma,
     float *__restrict__ dbeta, float *__restrict__ dy, int ldy, u16n *__restrict__ dyb, int PA, int N,
-    int C, int L, float bcast, int train, unsigned *__restrict__ dyh, int ldyy) {
+    int C, int L, float bcast, int train, unsigned *__restrict__ dyh, int ldyy, int ldp) {
     __shared__ double red[4][2];
     __shared__ float kk[2];
     const int c = blockIdx.y, g = blockIdx.z, tl = threadIdx.x;
@@ -486,7 +493,8 @@ __global__ __launch_bounds__(kBlock) void bn_bwd_dx_n16_kernel(
         if (YH) ld_pair_y<true, true>(y, row, ldyy, min(t0, (L - 1) & ~1), y0[s], y1[s]);   // (odd L: the last dword's high half is row padding, unused)
         else if (AL8) ld_pair<true>(y + row * L + min(t0, L - 2), y0[s], y1[s]);      // (pad pairs read the row's last pair: unused)
         else { y0[s] = y[row * L + ta]; y1[s] = y[row * L + tb]; }
-        d[s] = bcast != 0.f ? g_in[row] * bcast : (Lp > 0 ? g_in[row * Lp + jc] : 0.f);
+        if (DH) d[s] = __uint_as_float((unsigned)reinterpret_cast<const unsigned short *>(g_in)[row * ldp + jc] << 16);
+        else d[s] = bcast != 0.f ? g_in[row] * bcast : (Lp > 0 ? g_in[row * Lp + jc] : 0.f);
     }
     __builtin_amdgcn_sched_barrier(0);
     float v0[16], v1[16];
@@ -654,7 +662,8 @@ static int pool_gap_fwd_impl(const BnFin *fin, const float *y, const float *gamm
 
 static int pool_fwd_n16_impl(const BnFin *fin, const float *y, const float *gamma, const float *beta,
                              const float *mean, const float *invstd, float *p, void *p_n16, int N, int C, int L,
-                             int PX, int shift, hipStream_t st, bool yh = false, int ldy = 0) {
+                             int PX, int shift, hipStream_t st, bool yh = false, int ldy = 0, void *p_bf16 = nullptr,
+                             int ldp = 0) {
     int rc = check_ncl("bn_relu_pool_fwd_n16", N, C, L);
     if (rc) return rc;
     ECG_REQUIRE(y && gamma && beta && mean && invstd && p_n16, "bn_relu_pool_fwd_n16: null pointer");
@@ -667,10 +676,13 @@ static int pool_fwd_n16_impl(const BnFin *fin, const float *y, const float *gamm
     const BnFin f = fin ? *fin : BnFin{};
 #define ECG_POOLN(FIN, AL8) hipLaunchKernelGGL((bn_relu_pool_fwd_n16_kernel<FIN, AL8>), dim3(cdiv(PX, kBlock), C, G), \
                                                dim3(kBlock), 0, st, y, gamma, beta, mean, invstd, p,                   \
-                                               static_cast<u16n *>(p_n16), N, C, L, Lp, PX, shift, f, L)
+                                               static_cast<u16n *>(p_n16), N, C, L, Lp, PX, shift, f, L, nullptr, 0)
+    ECG_REQUIRE(!p_bf16 || (yh && ldp >= Lp && ldp % 2 == 0 && ldp <= PX - shift),
+                "bn_relu_pool_fwd_n16: the bf16 copy of p needs an even row stride in [L/2, PX - shift]");
     if (yh)
         hipLaunchKernelGGL((bn_relu_pool_fwd_n16_kernel<true, true, true>), dim3(cdiv(PX, kBlock), C, G), dim3(kBlock), 0, st,
-                           y, gamma, beta, mean, invstd, p, static_cast<u16n *>(p_n16), N, C, L, Lp, PX, shift, f, ldy);
+                           y, gamma, beta, mean, invstd, p, static_cast<u16n *>(p_n16), N, C, L, Lp, PX, shift, f, ldy,
+                           static_cast<u16n *>(p_bf16), ldp);
     else if (fin) { if (al8) ECG_POOLN(true, true); else ECG_POOLN(true, false); }
     else { if (al8) ECG_POOLN(false, true); else ECG_POOLN(false, false); }
 #undef ECG_POOLN
@@ -715,12 +727,14 @@ ECG_API int ecg_bn_stats_relu_pool_fwd(const float *stat_partials, int P, long l
 }
 
 // the same for a y that ecg_conv1d_fwd_bf16_yh wrote as bf16 [N][C][ldy] (bf16 activation storage);
-// mode 1 (pool + global average) or 2 (pool -> fp32 out (may be NULL) + n16 copy) only
+// mode 1 (pool + global average) or 2 (pool -> fp32 out (may be NULL) + n16 copy + (p_bf16 non-NULL) p as bf16
+// [N][C][ldp], rows zero-filled from L/2 to ldp: the next conv's forward input) only
 ECG_API int ecg_bn_stats_relu_pool_fwd_yh(const float *stat_partials, int P, long long count, float *running_mean,
                                           float *running_var, long long *num_batches_tracked, float momentum,
                                           float eps, const void *y_bf16, int ldy, const float *gamma,
                                           const float *beta, float *mean, float *invstd, float *out, void *p_n16,
-                                          int N, int C, int L, int PX, int shift, int mode, ecg_stream_t stream) {
+                                          void *p_bf16, int ldp, int N, int C, int L, int PX, int shift, int mode,
+                                          ecg_stream_t stream) {
     const BnFin f{stat_partials, P, (double)count, mean, invstd, running_mean, running_var, num_batches_tracked,
                   momentum, eps};
     int rc = check_fin("bn_stats_relu_pool_fwd_yh", f, C);
@@ -730,7 +744,8 @@ ECG_API int ecg_bn_stats_relu_pool_fwd_yh(const float *stat_partials, int P, lon
                 "bn_stats_relu_pool_fwd_yh: bf16 y needs an even row stride >= L and a 4-byte aligned base");
     const float *y = static_cast<const float *>(y_bf16);
     if (mode == 1) return pool_gap_fwd_impl(&f, y, gamma, beta, mean, invstd, out, N, C, L, as_stream(stream), true, ldy);
-    return pool_fwd_n16_impl(&f, y, gamma, beta, mean, invstd, out, p_n16, N, C, L, PX, shift, as_stream(stream), true, ldy);
+    return pool_fwd_n16_impl(&f, y, gamma, beta, mean, invstd, out, p_n16, N, C, L, PX, shift, as_stream(stream), true, ldy,
+                             p_bf16, ldp);
 }
 
 ECG_API size_t ecg_bn_relu_pool_bwd_ws_floats(int N, int C, int L) {
@@ -749,10 +764,10 @@ static int bn_bwd_impl(const float *y, const float *g, const float *gamma, const
     const bool al8 = FUSED && pairs_aligned(y, L);
     if (al8)
         hipLaunchKernelGGL((bn_bwd_reduce_kernel<FUSED, true>), dim3(C, S), dim3(kBlock), 0, st, y, g, gamma,
-                           beta, mean, invstd, partials, N, C, L, S, bcast, L);
+                           beta, mean, invstd, partials, N, C, L, S, bcast, L, 0);
     else
         hipLaunchKernelGGL((bn_bwd_reduce_kernel<FUSED, false>), dim3(C, S), dim3(kBlock), 0, st, y, g, gamma,
-                           beta, mean, invstd, partials, N, C, L, S, bcast, L);
+                           beta, mean, invstd, partials, N, C, L, S, bcast, L, 0);
     int rc = check_launch("bn_bwd_reduce_kernel");
     if (rc) return rc;
     // dx pass with the combine of the reduce partials folded in (no finalize launch)
@@ -870,7 +885,8 @@ ECG_API int ecg_bn_relu_pool_gap_bwd(const float *y, const float *dg, const floa
 
 // ---- mixed-precision producers (see the kernels above) -------------------------------------------------
 // y: fp32 [N][C][L], or (yh) bf16 [N][C][ldyy] with an even row stride
-static int bwd_n16_impl(const char *who, const float *y, bool yh, int ldyy, const float *dp, const float *gamma,
+static int bwd_n16_impl(const char *who, const float *y, bool yh, int ldyy, const float *dp, bool dh, int ldp,
+                        const float *gamma,
                         const float *beta, const float *mean, const float *invstd, float *dy, int ldy, void *dy_n16,
                         int PA, float *dgamma, float *dbeta, float *ws, int N, int C, int L, int train, int gap,
                         void *dy_bf16, hipStream_t st) {
@@ -884,25 +900,29 @@ static int bwd_n16_impl(const char *who, const float *y, bool yh, int ldyy, cons
     ECG_REQUIRE((reinterpret_cast<uintptr_t>(dy_bf16) & 3) == 0, "%s: bf16 dY must be 4-byte aligned", who);
     ECG_REQUIRE(!yh || (ldyy >= L && ldyy % 2 == 0 && (reinterpret_cast<uintptr_t>(y) & 3) == 0),
                 "%s: bf16 y needs an even row stride >= L and a 4-byte aligned base", who);
+    ECG_REQUIRE(!dh || (yh && !gap && ldp >= L / 2), "%s: a bf16 dp needs a bf16 y, no global average pool and a row stride >= L/2",
+                who);
     const float bcast = gap ? 1.0f / (float)(L / 2) : 0.f;
     const int S = stat_splits(N, C);
     const bool al8 = !yh && pairs_aligned(y, L);
-#define ECG_RED(AL8, YH) hipLaunchKernelGGL((bn_bwd_reduce_kernel<true, AL8, YH>), dim3(C, S), dim3(kBlock), 0, st, y, dp, \
-                                            gamma, beta, mean, invstd, ws, N, C, L, S, bcast, yh ? ldyy : L)
-    if (yh) ECG_RED(true, true);
-    else if (al8) ECG_RED(true, false);
-    else ECG_RED(false, false);
+#define ECG_RED(AL8, YH, DH) hipLaunchKernelGGL((bn_bwd_reduce_kernel<true, AL8, YH, DH>), dim3(C, S), dim3(kBlock), 0, st, y, \
+                                                dp, gamma, beta, mean, invstd, ws, N, C, L, S, bcast, yh ? ldyy : L, ldp)
+    if (dh) ECG_RED(true, true, true);
+    else if (yh) ECG_RED(true, true, false);
+    else if (al8) ECG_RED(true, false, false);
+    else ECG_RED(false, false, false);
 #undef ECG_RED
     rc = check_launch("bn_bwd_reduce_kernel");
     if (rc) return rc;
     const int G = cdiv(N, 16);
-#define ECG_DXN(AL8, YH) hipLaunchKernelGGL((bn_bwd_dx_n16_kernel<AL8, YH>), dim3(cdiv(PA / 2, kBlock), C, G), dim3(kBlock), \
-                                            0, st, y, dp, gamma, beta, mean, invstd, ws, S, (double)N * L, dgamma, dbeta, dy,  \
-                                            ldy, static_cast<u16n *>(dy_n16), PA, N, C, L, bcast, train,                       \
-                                            static_cast<unsigned *>(dy_bf16), yh ? ldyy : L)
-    if (yh) ECG_DXN(true, true);
-    else if (al8) ECG_DXN(true, false);
-    else ECG_DXN(false, false);
+#define ECG_DXN(AL8, YH, DH) hipLaunchKernelGGL((bn_bwd_dx_n16_kernel<AL8, YH, DH>), dim3(cdiv(PA / 2, kBlock), C, G),        \
+                                                dim3(kBlock), 0, st, y, dp, gamma, beta, mean, invstd, ws, S, (double)N * L,  \
+                                                dgamma, dbeta, dy, ldy, static_cast<u16n *>(dy_n16), PA, N, C, L, bcast,     \
+                                                train, static_cast<unsigned *>(dy_bf16), yh ? ldyy : L, ldp)
+    if (dh) ECG_DXN(true, true, true);
+    else if (yh) ECG_DXN(true, true, false);
+    else if (al8) ECG_DXN(true, false, false);
+    else ECG_DXN(false, false, false);
 #undef ECG_DXN
     return check_launch("bn_bwd_dx_n16_kernel");
 }
@@ -911,15 +931,17 @@ ECG_API int ecg_bn_relu_pool_bwd_n16(const float *y, const float *dp, const floa
                                      const float *mean, const float *invstd, float *dy, int ldy, void *dy_n16,
                                      int PA, float *dgamma, float *dbeta, float *ws, int N, int C, int L,
                                      int train, int gap, void *dy_bf16, ecg_stream_t stream) {
-    return bwd_n16_impl("bn_relu_pool_bwd_n16", y, false, L, dp, gamma, beta, mean, invstd, dy, ldy, dy_n16, PA, dgamma,
+    return bwd_n16_impl("bn_relu_pool_bwd_n16", y, false, L, dp, false, 0, gamma, beta, mean, invstd, dy, ldy, dy_n16, PA, dgamma,
                         dbeta, ws, N, C, L, train, gap, dy_bf16, as_stream(stream));
 }
 
-// the same with y as ecg_conv1d_fwd_bf16_yh wrote it: bf16 [N][C][ldyy]
-ECG_API int ecg_bn_relu_pool_bwd_n16_yh(const void *y_bf16, int ldyy, const float *dp, const float *gamma,
-                                        const float *beta, const float *mean, const float *invstd, float *dy, int ldy,
-                                        void *dy_n16, int PA, float *dgamma, float *dbeta, float *ws, int N, int C,
-                                        int L, int train, int gap, void *dy_bf16, ecg_stream_t stream) {
-    return bwd_n16_impl("bn_relu_pool_bwd_n16_yh", static_cast<const float *>(y_bf16), true, ldyy, dp, gamma, beta, mean,
-                        invstd, dy, ldy, dy_n16, PA, dgamma, dbeta, ws, N, C, L, train, gap, dy_bf16, as_stream(stream));
+// the same with y as ecg_conv1d_fwd_bf16_yh wrote it: bf16 [N][C][ldyy]; dp fp32 [N][C][L/2] ([N][C] with gap), or
+// (dp_bf16 != 0, no gap) bf16 [N][C][ldp] as ecg_conv1d_bwd_data_bf16hh of the next block wrote it
+ECG_API int ecg_bn_relu_pool_bwd_n16_yh(const void *y_bf16, int ldyy, const void *dp, int dp_bf16, int ldp,
+                                        const float *gamma, const float *beta, const float *mean, const float *invstd,
+                                        float *dy, int ldy, void *dy_n16, int PA, float *dgamma, float *dbeta, float *ws,
+                                        int N, int C, int L, int train, int gap, void *dy_bf16, ecg_stream_t stream) {
+    return bwd_n16_impl("bn_relu_pool_bwd_n16_yh", static_cast<const float *>(y_bf16), true, ldyy,
+                        static_cast<const float *>(dp), dp_bf16 != 0, ldp, gamma, beta, mean, invstd, dy, ldy, dy_n16, PA,
+                        dgamma, dbeta, ws, N, C, L, train, gap, dy_bf16, as_stream(stream));
 }

@@ -467,7 +467,11 @@ static void launch_bf16(const void *x, int ldx, bool xh, const u16 *wb, const fl
 #define ECG_BF(STATS, XH, WRES, YH)                                                                                    \
     hipLaunchKernelGGL((conv1d_mfma_bf16_fwd_kernel<CO_T, T_T, WCO, WT, STATS, XH, WRES, YH>), grid, block, 0, st, xf, \
                        wb, bias, y, partials, Cin, Cout, L, Lo, pad, tiles_t, N, G, ldx, ldyo)
-    if (yh) {       // bf16 activation storage (train-mode forward: always with statistics)
+    if (yh && xh) { // bf16 in, bf16 out: the train-mode forward of an inner block (statistics), or its input gradient
+        if (!partials) ECG_BF(false, true, false, true);
+        else if (Cin <= 2 * kCB) ECG_BF(true, true, true, true);
+        else ECG_BF(true, true, false, true);
+    } else if (yh) { // bf16 activation storage (train-mode forward: always with statistics)
         if (Cin <= 2 * kCB) ECG_BF(true, false, true, true);
         else ECG_BF(true, false, false, true);
     } else if (xh)  // bf16 input (the input-gradient conv: no bias, no statistics)
@@ -618,17 +622,21 @@ ECG_API int ecg_conv1d_fwd_bf16(const float *x, const void *wb_fwd, const float 
 // Train-mode forward with bf16 ACTIVATION STORAGE: y is written as bf16 [N][C_out][ldy] (ldy >= Lo, even), the
 // BatchNorm statistics partials (layout as ecg_conv1d_fwd_bf16) are taken over the rounded values.  The consumers are
 // ecg_bn_stats_relu_pool_fwd_yh and ecg_bn_relu_pool_bwd_n16_yh.
-ECG_API int ecg_conv1d_fwd_bf16_yh(const float *x, const void *wb_fwd, const float *bias, void *y_bf16, int ldy,
-                                   float *stat_partials, int N, int C_in, int C_out, int L, int K, int pad,
-                                   ecg_stream_t stream) {
+// x: fp32 [N][C_in][L] (x_bf16 == 0, ldx ignored) or bf16 [N][C_in][ldx] with rows zero-filled from L to ldx, ldx even,
+// pad odd (x_bf16 != 0: the previous block's ecg_bn_stats_relu_pool_fwd_yh wrote it that way).
+ECG_API int ecg_conv1d_fwd_bf16_yh(const void *x, int x_bf16, int ldx, const void *wb_fwd, const float *bias,
+                                   void *y_bf16, int ldy, float *stat_partials, int N, int C_in, int C_out, int L, int K,
+                                   int pad, ecg_stream_t stream) {
     int rc = check_bf16_shape("conv1d_fwd_bf16_yh", N, C_in, C_out, L, K, pad);
     if (rc) return rc;
     ECG_REQUIRE(x && wb_fwd && y_bf16 && stat_partials, "conv1d_fwd_bf16_yh: null pointer");
     ECG_REQUIRE(bf16_fwd_supported(C_in, C_out, K, pad), "conv1d_fwd_bf16_yh: needs C_in %% 4 == 0, C_out %% 32 == 0");
     ECG_REQUIRE(ldy >= L + 2 * pad - K + 1 && ldy % 2 == 0 && (reinterpret_cast<uintptr_t>(y_bf16) & 3) == 0,
                 "conv1d_fwd_bf16_yh: needs an even row stride >= Lo and a 4-byte aligned y");
-    return bf16_fwd_any(x, L, false, wb_fwd, bias, static_cast<float *>(y_bf16), ldy, true, stat_partials, N, C_in, C_out,
-                        L, K, pad, as_stream(stream));
+    ECG_REQUIRE(!x_bf16 || (ldx >= L && ldx % 2 == 0 && (pad & 1) == 1 && (reinterpret_cast<uintptr_t>(x) & 3) == 0),
+                "conv1d_fwd_bf16_yh: a bf16 x needs an even row stride >= L, odd pad and a 4-byte aligned base");
+    return bf16_fwd_any(x, x_bf16 ? ldx : L, x_bf16 != 0, wb_fwd, bias, static_cast<float *>(y_bf16), ldy, true,
+                        stat_partials, N, C_in, C_out, L, K, pad, as_stream(stream));
 }
 
 // input gradient from a dY that is itself bf16: [N][C_out][ldy] u16, rows zero-filled from Lo to ldy, ldy even
@@ -644,6 +652,23 @@ ECG_API int ecg_conv1d_bwd_data_bf16h(const void *dy_bf16, int ldy, const void *
                 "conv1d_bwd_data_bf16h: needs an even row stride >= Lo, odd K-1-pad and a 4-byte aligned dY");
     return bf16_fwd_any(dy_bf16, ldy, true, wb_bwd, nullptr, dx, L, false, nullptr, N, C_out, C_in, Lo, K, padb,
                         as_stream(stream));
+}
+
+// ... and writes dx itself as bf16 [N][C_in][ldx] (ldx even, >= L; the row padding is left unwritten): the dp that the
+// previous block's ecg_bn_relu_pool_bwd_n16_yh reads
+ECG_API int ecg_conv1d_bwd_data_bf16hh(const void *dy_bf16, int ldy, const void *wb_bwd, void *dx_bf16, int ldx, int N,
+                                       int C_in, int C_out, int L, int K, int pad, ecg_stream_t stream) {
+    int rc = check_bf16_shape("conv1d_bwd_data_bf16hh", N, C_in, C_out, L, K, pad);
+    if (rc) return rc;
+    ECG_REQUIRE(dy_bf16 && wb_bwd && dx_bf16, "conv1d_bwd_data_bf16hh: null pointer");
+    const int Lo = L + 2 * pad - K + 1, padb = K - 1 - pad;
+    ECG_REQUIRE(bf16_fwd_supported(C_out, C_in, K, padb), "conv1d_bwd_data_bf16hh: needs C_out %% 4 == 0, C_in %% 32 == 0");
+    ECG_REQUIRE(ldy >= Lo && ldy % 2 == 0 && (padb & 1) == 1 && (reinterpret_cast<uintptr_t>(dy_bf16) & 3) == 0,
+                "conv1d_bwd_data_bf16hh: needs an even row stride >= Lo, odd K-1-pad and a 4-byte aligned dY");
+    ECG_REQUIRE(ldx >= L && ldx % 2 == 0 && (reinterpret_cast<uintptr_t>(dx_bf16) & 3) == 0,
+                "conv1d_bwd_data_bf16hh: needs an even dx row stride >= L and a 4-byte aligned dx");
+    return bf16_fwd_any(dy_bf16, ldy, true, wb_bwd, nullptr, static_cast<float *>(dx_bf16), ldx, true, nullptr, N, C_out,
+                        C_in, Lo, K, padb, as_stream(stream));
 }
 
 ECG_API int ecg_conv1d_bwd_data_bf16(const float *dy, const void *wb_bwd, float *dx, int N, int C_in,

@@ -342,6 +342,10 @@ class ConvBlockFn(torch.autograd.Function):
         previous block), kept for backward."""
         x, w = _contig(x), _contig(w)
         Co, _, K = w.shape
+        x_len = None
+        if isinstance(x_n16, tuple):          # the carry of conv_block_chain: (n16 operand, true row length of a bf16 x)
+            x_n16, x_len = x_n16
+        x_h = x.dtype == torch.bfloat16       # bf16 activation storage: x is the previous block's p, bf16 [N][C][ldx]
         use_batch = training or running_mean is None
         # grad mode is always off INSIDE forward and needs_input_grad ignores torch.no_grad(): the caller
         # samples torch.is_grad_enabled() and hands it in, so that inference takes the one-launch kernel
@@ -373,6 +377,11 @@ class ConvBlockFn(torch.autograd.Function):
                       N, Ci, Co, Lin, K, pad, _st())
                 return g, None
         N, Ci, Lin = x.shape
+        ldx = 0
+        if x_h:
+            ldx, Lin = Lin, x_len
+            if not (bf16 and use_batch and need_grad and _bf16_chain_ok(Ci, Co, K, pad, Lin)):
+                raise L.EcgHipError("ConvBlock: a bf16 activation arrived at a block that cannot consume it")
         Lo = Lin + 2 * pad - K + 1
         p_n16, PX, shift = None, 0, 0
         if not gap and bf16 and need_grad and next_geom is not None and Lo >= 2:
@@ -384,12 +393,18 @@ class ConvBlockFn(torch.autograd.Function):
         if (bf16 and _bf16_activation_storage and use_batch and need_grad and Lo >= 2 and (gap or PX) and (sup & 4)
                 and _query("ecg_conv1d_n16_positions", Lin, K, pad, 0)):
             ldyh = (Lo + 7) & ~7
+        # ... and p itself as bf16 [N][Co][ldp] (instead of fp32) when the next block is one that reads it: its forward
+        # conv then reads half the bytes, and its input gradient comes back as bf16 of the same shape
+        ldp = 0
+        if (ldyh and PX and len(next_geom) >= 4 and next_geom[3]
+                and _bf16_chain_ok(Co, next_geom[2], next_geom[0], next_geom[1], Lo // 2)):
+            ldp = (Lo // 2 + 7) & ~7
         if ldyh:
             y = torch.empty(N, Co, ldyh, dtype=torch.bfloat16, device=x.device)
             P = _query("ecg_conv1d_fwd_bf16_stat_partials", N, Ci, Co, Lin, K, pad)
             partials = _empty(x, Co * P * 2)
-            _call("ecg_conv1d_fwd_bf16_yh", _f32(x), L.ptr(w_fwd), _f32(b), L.ptr(y), ldyh, _f32(partials), N, Ci, Co, Lin,
-                  K, pad, _st())
+            _call("ecg_conv1d_fwd_bf16_yh", L.ptr(x), 1 if x_h else 0, ldx, L.ptr(w_fwd), _f32(b), L.ptr(y), ldyh,
+                  _f32(partials), N, Ci, Co, Lin, K, pad, _st())
         elif bf16:
             y, partials, P = conv1d_forward_bf16_raw(x, w_fwd, b, Co, K, pad, want_stats=use_batch)
         else:
@@ -398,7 +413,10 @@ class ConvBlockFn(torch.autograd.Function):
             p_n16 = torch.empty(((N + 15) // 16) * Co * PX * 16, dtype=torch.bfloat16, device=x.device)
             ctx.mark_non_differentiable(p_n16)
             ctx.set_materialize_grads(False)     # no zero-filled "gradient" for the n16 by-product (41 MB fill)
-        p = _empty(x, N, Co) if gap else _empty(x, N, Co, Lo // 2)
+        if ldp:
+            p, p_f32 = torch.empty(N, Co, ldp, dtype=torch.bfloat16, device=x.device), None
+        else:
+            p = p_f32 = _empty(x, N, Co) if gap else _empty(x, N, Co, Lo // 2)
         mode = 1 if gap else (2 if PX else 0)
         if use_batch:
             # statistics combine + BN-apply + ReLU + pool in ONE launch (ecg_bn_finalize folded into the streaming pass)
@@ -409,7 +427,8 @@ class ConvBlockFn(torch.autograd.Function):
             if ldyh:
                 _call("ecg_bn_stats_relu_pool_fwd_yh", _f32(partials), P, N * Lo, _f32(rm), _f32(rv), L.ptr(cnt),
                       _bn_momentum(momentum, nbt), float(eps), L.ptr(y), ldyh, _f32(gamma), _f32(beta), _f32(mean),
-                      _f32(invstd), _f32(p), L.ptr(p_n16), N, Co, Lo, PX, shift, mode, _st())
+                      _f32(invstd), _f32(p_f32), L.ptr(p_n16), L.ptr(p) if ldp else None, ldp, N, Co, Lo, PX, shift, mode,
+                      _st())
             else:
                 _call("ecg_bn_stats_relu_pool_fwd", _f32(partials), P, N * Lo, _f32(rm), _f32(rv), L.ptr(cnt),
                       _bn_momentum(momentum, nbt), float(eps), _f32(y), _f32(gamma), _f32(beta), _f32(mean), _f32(invstd),
@@ -429,7 +448,7 @@ class ConvBlockFn(torch.autograd.Function):
         ctx.w_bwd, ctx.pad, ctx.batch_stats, ctx.gap = w_bwd, pad, use_batch, gap
         ctx.sink_keys = (_key(w), _key(b), _key(gamma), _key(beta))
         ctx.x_n16 = x_n16 if bf16 else None
-        ctx.ldyh, ctx.Lo = ldyh, Lo
+        ctx.ldyh, ctx.Lo, ctx.Lin, ctx.ldp = ldyh, Lo, Lin, ldp
         return p, p_n16
 
     @staticmethod
@@ -437,9 +456,13 @@ class ConvBlockFn(torch.autograd.Function):
         x, w, y, gamma, beta, mean, invstd = ctx.saved_tensors
         N, Co, Lo = y.shape[0], y.shape[1], ctx.Lo          # (y may be bf16 with padded rows: ctx.ldyh)
         if dp is None:          # (only possible with set_materialize_grads(False): p unused downstream)
-            dp = torch.zeros(N, Co, *(() if ctx.gap else (Lo // 2,)), device=y.device)
+            dp = (torch.zeros(N, Co, ctx.ldp, dtype=torch.bfloat16, device=y.device) if ctx.ldp else
+                  torch.zeros(N, Co, *(() if ctx.gap else (Lo // 2,)), device=y.device))
         dp = _contig(dp)
-        Ci, Lin, K = x.shape[1], x.shape[2], w.shape[2]
+        if ctx.ldp and (dp.dtype != torch.bfloat16 or dp.shape[2] != ctx.ldp):
+            raise L.EcgHipError("ConvBlock backward: the gradient of a bf16 activation must be bf16 of the same shape")
+        Ci, Lin, K = x.shape[1], ctx.Lin, w.shape[2]
+        x_h = x.dtype == torch.bfloat16
         need_dx = ctx.needs_input_grad[0]
         kw, kb, kg, kbe = ctx.sink_keys
         dgamma, dbeta = _grad_out(kg, y, Co), _grad_out(kbe, y, Co)
@@ -458,9 +481,9 @@ class ConvBlockFn(torch.autograd.Function):
             dyh = torch.empty(N * Co * PA, dtype=torch.bfloat16, device=y.device) if dyh_ok else None
             dyb = torch.empty(G * Co * PA * 16, dtype=torch.bfloat16, device=y.device)
             if ctx.ldyh:        # y was stored as bf16 [N][Co][ldyh]
-                _call("ecg_bn_relu_pool_bwd_n16_yh", L.ptr(y), ctx.ldyh, _f32(dp), _f32(gamma), _f32(beta), _f32(mean),
-                      _f32(invstd), _f32(dy), Lo, L.ptr(dyb), PA, _f32(dgamma), _f32(dbeta), _f32(ws), N, Co, Lo,
-                      1 if ctx.batch_stats else 0, 1 if ctx.gap else 0, L.ptr(dyh), _st())
+                _call("ecg_bn_relu_pool_bwd_n16_yh", L.ptr(y), ctx.ldyh, L.ptr(dp), 1 if ctx.ldp else 0, ctx.ldp,
+                      _f32(gamma), _f32(beta), _f32(mean), _f32(invstd), _f32(dy), Lo, L.ptr(dyb), PA, _f32(dgamma),
+                      _f32(dbeta), _f32(ws), N, Co, Lo, 1 if ctx.batch_stats else 0, 1 if ctx.gap else 0, L.ptr(dyh), _st())
             else:
                 _call("ecg_bn_relu_pool_bwd_n16", _f32(y), _f32(dp), _f32(gamma), _f32(beta), _f32(mean), _f32(invstd),
                       _f32(dy), Lo, L.ptr(dyb), PA, _f32(dgamma), _f32(dbeta), _f32(ws), N, Co, Lo,
@@ -468,6 +491,8 @@ class ConvBlockFn(torch.autograd.Function):
             xb = ctx.x_n16
             PX = _query("ecg_conv1d_n16_positions", Lin, K, ctx.pad, 1)
             if xb is None or xb.numel() != G * Ci * PX * 16:
+                if x_h:
+                    raise L.EcgHipError("ConvBlock backward: a bf16 input came without its n16 operand")
                 xb = torch.empty(G * Ci * PX * 16, dtype=torch.bfloat16, device=y.device)
                 _call("ecg_pack_n16", _f32(x), L.ptr(xb), N, Ci, Lin, Lin, PX, ctx.pad, _st())
             dw, db = _grad_out(kw, x, Co, Ci, K), _grad_out(kb, x, Co)
@@ -477,7 +502,10 @@ class ConvBlockFn(torch.autograd.Function):
             dx = None
             if need_dx:
                 dx = torch.empty_like(x)
-                if dyh_ok:
+                if x_h:         # the previous block's dp, bf16 [N][Ci][ldx] like x itself (x_h implies dyh_ok)
+                    _call("ecg_conv1d_bwd_data_bf16hh", L.ptr(dyh), PA, L.ptr(ctx.w_bwd), L.ptr(dx), x.shape[2], N, Ci, Co,
+                          Lin, K, ctx.pad, _st())
+                elif dyh_ok:
                     _call("ecg_conv1d_bwd_data_bf16h", L.ptr(dyh), PA, L.ptr(ctx.w_bwd), _f32(dx), N, Ci, Co, Lin, K,
                           ctx.pad, _st())
                 else:
@@ -709,16 +737,33 @@ def conv_block(x, conv, bn, gap=False, packed=None):
     return conv_block_chain(x, conv, bn, gap, packed)[0]
 
 
-def conv_block_chain(x, conv, bn, gap=False, packed=None, x_n16=None, next_conv=None):
-    """conv_block for a chain of blocks: returns (p, p_n16).  In bf16 mode p_n16 is p in the layout the NEXT conv's
-    weight gradient reads (next_conv given), and x_n16 is this block's input in that layout (the previous block's
-    p_n16): the mixed-precision train step then needs no packing pass except for the network input."""
+def _bf16_chain_ok(Ci, Co, K, pad, Lin):
+    """Can a training block of this geometry take its input as bf16 [N][Ci][ld] and hand its input gradient back in the
+    same form?  Needs the bf16 forward, input-gradient and weight-gradient kernels, position-pair staging on both sides
+    (odd pad, odd K-1-pad) and the n16 BatchNorm backward."""
+    Lo = Lin + 2 * pad - K + 1
+    return bool(_bf16_activation_storage and (_query("ecg_conv1d_bf16_supported", Ci, Co, K, pad) & 7) == 7
+                and (pad & 1) and ((K - 1 - pad) & 1) and Lo >= 2 and _query("ecg_conv1d_n16_positions", Lin, K, pad, 0))
+
+
+def conv_block_chain(x, conv, bn, gap=False, packed=None, x_n16=None, next_conv=None, next_bn=None):
+    """conv_block for a chain of blocks: returns (p, carry).  In bf16 mode the carry holds p in the layout the NEXT
+    conv's weight gradient reads (next_conv given) — hand it to the next call as `x_n16` — so the mixed-precision train
+    step needs no packing pass except for the network input; with bf16 activation storage p itself is then a bf16
+    tensor [N][C][ld] (rows zero-filled past the pooled length, which travels in the carry) that only the next block of
+    the chain may consume."""
     geom = None
     if next_conv is not None and _conv_precision == "bf16":
-        geom = (next_conv.kernel_size[0], next_conv.padding[0])
-    return ConvBlockFn.apply(x, conv.weight, conv.bias, bn.weight, bn.bias, bn.running_mean,
-                             bn.running_var, bn.num_batches_tracked, bn.training, bn.momentum,
-                             bn.eps, conv.padding[0], gap, packed, torch.is_grad_enabled(), x_n16, geom)
+        geom = (next_conv.kernel_size[0], next_conv.padding[0], next_conv.out_channels,
+                bool(next_bn is not None and (next_bn.training or next_bn.running_mean is None)))
+    p, p_n16 = ConvBlockFn.apply(x, conv.weight, conv.bias, bn.weight, bn.bias, bn.running_mean,
+                                 bn.running_var, bn.num_batches_tracked, bn.training, bn.momentum,
+                                 bn.eps, conv.padding[0], gap, packed, torch.is_grad_enabled(), x_n16, geom)
+    if p.dtype == torch.bfloat16:
+        x_len = x_n16[1] if isinstance(x_n16, tuple) else x.shape[2]
+        Lo = x_len + 2 * conv.padding[0] - conv.kernel_size[0] + 1
+        return p, (p_n16, Lo // 2)
+    return p, p_n16
 
 
 class TailFn(torch.autograd.Function):

@@ -67,7 +67,8 @@ def fused_forward(packer, backbone, gap, x, x_demo, proj, head, mlp0=None, mlp2=
     for i, blk in enumerate(blocks):
         last = i == len(blocks) - 1
         x, xn = hipF.conv_block_chain(x, blk.net[0], blk.net[1], gap=last, packed=packs[i], x_n16=xn,
-                                      next_conv=None if last else blocks[i + 1].net[0])
+                                      next_conv=None if last else blocks[i + 1].net[0],
+                                      next_bn=None if last else blocks[i + 1].net[1])
     return hipF.tail(x, x_demo, proj, head, mlp0, mlp2, film_gen, transposed=transposed)
 
 

@@ -713,9 +713,9 @@ def test_bn_relu_pool_n16_producers_match_the_plain_passes(hip, oracle, shape):
                                   (2, 64, 128, 300), (2, 128, 256, 520)])
 @pytest.mark.parametrize("gap", [False, True])
 def test_bf16_activation_storage_equals_the_fp32_passes_on_the_rounded_tensor(hip, case, gap):
-    """bf16 activation storage (the conv output y of a training block kept as bf16): the conv's bf16 output is the
+    """bf16 activation storage (y, p and dp of a training block chain kept as bf16): the conv's bf16 output is the
     nearest-even rounding of its fp32 output, its statistics are those of the ROUNDED tensor, and the BatchNorm
-    passes that read the bf16 tensor give BIT-IDENTICAL results to the fp32-input passes run on that rounded tensor
+    passes that read / write the bf16 tensors give BIT-IDENTICAL results to the fp32 passes run on the rounded values
     (pooled output, n16 copy, mean / invstd / running statistics / counter; dY operands, dgamma, dbeta)."""
     from ecg_hip import _lib as L
     N, Ci, Co, Lin = case
@@ -730,8 +730,8 @@ def test_bf16_activation_storage_equals_the_fp32_passes_on_the_rounded_tensor(hi
     ldy = (Lo + 7) & ~7
     yh = torch.full((N, Co, ldy), float("nan"), dtype=torch.bfloat16, device="cuda")     # row padding stays NaN: must be ignored
     part = torch.empty(Co * P * 2, device="cuda")
-    L.call("ecg_conv1d_fwd_bf16_yh", L.f32(x), L.ptr(wb_fwd), L.f32(b), L.ptr(yh), ldy, L.f32(part), N, Ci, Co, Lin, 15, 7,
-           L.stream())
+    L.call("ecg_conv1d_fwd_bf16_yh", L.f32(x), 0, 0, L.ptr(wb_fwd), L.f32(b), L.ptr(yh), ldy, L.f32(part), N, Ci, Co, Lin,
+           15, 7, L.stream())
     yr = y32.to(torch.bfloat16)                       # nearest-even
     assert torch.equal(yh[:, :, :Lo], yr)
     assert bool(torch.isnan(yh[:, :, Lo:].float()).all())
@@ -743,6 +743,7 @@ def test_bf16_activation_storage_equals_the_fp32_passes_on_the_rounded_tensor(hi
     np.testing.assert_allclose(st[:, 1], (ref * ref).sum(dim=(0, 2)).cpu().numpy(), rtol=1e-5)
     # forward pass: fp32 kernel on the rounded tensor with the SAME partials vs the bf16-input kernel
     PX = L.query("ecg_conv1d_n16_positions", Lp, 15, 7, 1)
+    ldp = (Lp + 7) & ~7
     outs = []
     for use_h in (False, True):
         rm, rv = torch.zeros(Co, device="cuda"), torch.ones(Co, device="cuda")
@@ -751,36 +752,103 @@ def test_bf16_activation_storage_equals_the_fp32_passes_on_the_rounded_tensor(hi
         out = torch.empty(N, Co, device="cuda") if gap else torch.empty(N, Co, Lp, device="cuda")
         pb = None if gap else torch.full((G * Co * PX * 16,), 7.0, dtype=torch.bfloat16, device="cuda")
         head = [L.f32(part), P, N * Lo, L.f32(rm), L.f32(rv), L.ptr(nbt), 0.1, 1e-5]
-        tail = [L.f32(gamma), L.f32(beta), L.f32(mean), L.f32(invstd), L.f32(out), L.ptr(pb), N, Co, Lo, 0 if gap else PX,
-                0 if gap else 7, 1 if gap else 2, L.stream()]
+        mid = [L.f32(gamma), L.f32(beta), L.f32(mean), L.f32(invstd), L.f32(out), L.ptr(pb)]
+        tail = [N, Co, Lo, 0 if gap else PX, 0 if gap else 7, 1 if gap else 2, L.stream()]
         if use_h:
-            L.call("ecg_bn_stats_relu_pool_fwd_yh", *head, L.ptr(yh), ldy, *tail)
+            L.call("ecg_bn_stats_relu_pool_fwd_yh", *head, L.ptr(yh), ldy, *mid, None, 0, *tail)
         else:
-            L.call("ecg_bn_stats_relu_pool_fwd", *head, L.f32(yr32), *tail)
+            L.call("ecg_bn_stats_relu_pool_fwd", *head, L.f32(yr32), *mid, *tail)
         outs.append((out, pb, mean, invstd, rm, rv, nbt))
     for a, c in zip(*outs):
         assert (a is None and c is None) or torch.equal(a, c)
-    mean, invstd = outs[1][2], outs[1][3]
+    out, pb, mean, invstd = outs[1][:4]
+    if not gap:
+        # p as bf16 [N][Co][ldp] INSTEAD of the fp32 p: the rounding of p, rows zero-filled past Lp; same n16 copy
+        ph = torch.full((N, Co, ldp), float("nan"), dtype=torch.bfloat16, device="cuda")
+        pb2 = torch.full_like(pb, 7.0)
+        rm, rv = torch.zeros(Co, device="cuda"), torch.ones(Co, device="cuda")
+        L.call("ecg_bn_stats_relu_pool_fwd_yh", L.f32(part), P, N * Lo, L.f32(rm), L.f32(rv), None, 0.1, 1e-5, L.ptr(yh), ldy,
+               L.f32(gamma), L.f32(beta), L.f32(mean), L.f32(invstd), None, L.ptr(pb2), L.ptr(ph), ldp, N, Co, Lo, PX, 7, 2,
+               L.stream())
+        assert torch.equal(ph[:, :, :Lp], out.to(torch.bfloat16)) and float(ph[:, :, Lp:].float().abs().sum()) == 0.0
+        assert torch.equal(pb, pb2)
+        with pytest.raises(L.EcgHipError, match="even row stride"):
+            L.call("ecg_bn_stats_relu_pool_fwd_yh", L.f32(part), P, N * Lo, L.f32(rm), L.f32(rv), None, 0.1, 1e-5, L.ptr(yh),
+                   ldy, L.f32(gamma), L.f32(beta), L.f32(mean), L.f32(invstd), None, L.ptr(pb2), L.ptr(ph), PX, N, Co, Lo,
+                   PX, 7, 2, L.stream())
     # backward pass
     PA = L.query("ecg_conv1d_n16_positions", Lo, 15, 7, 0)
     dp = dev(rng.standard_normal((N, Co) if gap else (N, Co, Lp)).astype(np.float32))
     ws = torch.empty(L.query("ecg_bn_relu_pool_bwd_ws_floats", N, Co, Lo), device="cuda")
-    outs = []
-    for use_h in (False, True):
+
+    def backward(which, dp_t, dp_h=None):
         dy, dg, db = torch.empty(N, Co, Lo, device="cuda"), torch.empty(Co, device="cuda"), torch.empty(Co, device="cuda")
         dyb = torch.full((G * Co * PA * 16,), 7.0, dtype=torch.bfloat16, device="cuda")
         dyh = torch.full((N * Co * PA,), 7.0, dtype=torch.bfloat16, device="cuda")
-        tail = [L.f32(dp), L.f32(gamma), L.f32(beta), L.f32(mean), L.f32(invstd), L.f32(dy), Lo, L.ptr(dyb), PA, L.f32(dg),
+        tail = [L.f32(gamma), L.f32(beta), L.f32(mean), L.f32(invstd), L.f32(dy), Lo, L.ptr(dyb), PA, L.f32(dg),
                 L.f32(db), L.f32(ws), N, Co, Lo, 1, 1 if gap else 0, L.ptr(dyh), L.stream()]
-        if use_h:
-            L.call("ecg_bn_relu_pool_bwd_n16_yh", L.ptr(yh), ldy, *tail)
+        if which == "f32":
+            L.call("ecg_bn_relu_pool_bwd_n16", L.f32(yr32), L.f32(dp_t), *tail)
+        elif dp_h is None:
+            L.call("ecg_bn_relu_pool_bwd_n16_yh", L.ptr(yh), ldy, L.f32(dp_t), 0, 0, *tail)
         else:
-            L.call("ecg_bn_relu_pool_bwd_n16", L.f32(yr32), *tail)
-        outs.append((dy, dg, db, dyb, dyh))
-    for a, c in zip(*outs):
+            L.call("ecg_bn_relu_pool_bwd_n16_yh", L.ptr(yh), ldy, L.ptr(dp_h), 1, dp_h.shape[2], *tail)
+        torch.cuda.synchronize()
+        return dy, dg, db, dyb, dyh
+
+    for a, c in zip(backward("f32", dp), backward("yh", dp)):
         assert torch.equal(a, c)
+    if not gap:         # dp itself as bf16 [N][Co][ldp] (row padding NaN: must be ignored)
+        dph = torch.full((N, Co, ldp), float("nan"), dtype=torch.bfloat16, device="cuda")
+        dph[:, :, :Lp] = dp.to(torch.bfloat16)
+        dpr = dph[:, :, :Lp].to(torch.float32).contiguous()
+        for a, c in zip(backward("f32", dpr), backward("yh", None, dph)):
+            assert torch.equal(a, c)
     with pytest.raises(L.EcgHipError, match="even row stride"):
-        L.call("ecg_bn_relu_pool_bwd_n16_yh", L.ptr(yh), Lo | 1, *tail)
+        L.call("ecg_bn_relu_pool_bwd_n16_yh", L.ptr(yh), Lo | 1, L.f32(dp), 0, 0, L.f32(gamma), L.f32(beta), L.f32(mean),
+               L.f32(invstd), None, Lo, L.ptr(torch.empty(G * Co * PA * 16, dtype=torch.bfloat16, device="cuda")), PA, None,
+               None, L.f32(ws), N, Co, Lo, 1, 1 if gap else 0, None, L.stream())
+
+
+@pytest.mark.parametrize("case", [(5, 32, 64, 257), (18, 64, 128, 125), (3, 128, 256, 77), (2, 64, 128, 300),
+                                  (2, 128, 256, 520), (19, 32, 32, 300)])
+def test_bf16_conv_on_bf16_activations_equals_the_fp32_io_kernels(hip, case):
+    """Inner blocks of the bf16 chain: the forward conv reading its input as bf16 [N][Ci][ldx] (zero-filled rows) gives
+    the same bf16 y and the same statistics partials as the fp32-input kernel on those values, and the input gradient
+    written as bf16 [N][Ci][ldx] is the rounding of the fp32-output kernel's result."""
+    from ecg_hip import _lib as L
+    N, Ci, Co, Lin = case
+    Lo = Lin
+    rng = np.random.default_rng(sum(case) + 1)
+    ldx, ldy = (Lin + 7) & ~7, (Lo + 7) & ~7
+    xh = torch.zeros(N, Ci, ldx, dtype=torch.bfloat16, device="cuda")
+    xh[:, :, :Lin] = dev(rng.standard_normal((N, Ci, Lin)).astype(np.float32)).to(torch.bfloat16)
+    xr = xh[:, :, :Lin].to(torch.float32).contiguous()
+    w = dev((rng.standard_normal((Co, Ci, 15)) / np.sqrt(Ci * 15)).astype(np.float32))
+    b = dev(rng.standard_normal(Co).astype(np.float32))
+    wb_fwd, wb_bwd = hip.conv1d_pack_bf16(w, need_bwd=True)
+    P = L.query("ecg_conv1d_fwd_bf16_stat_partials", N, Ci, Co, Lin, 15, 7)
+    res = []
+    for use_h in (False, True):
+        y = torch.zeros(N, Co, ldy, dtype=torch.bfloat16, device="cuda")
+        part = torch.empty(Co * P * 2, device="cuda")
+        L.call("ecg_conv1d_fwd_bf16_yh", L.ptr(xh) if use_h else L.f32(xr), 1 if use_h else 0, ldx, L.ptr(wb_fwd), L.f32(b),
+               L.ptr(y), ldy, L.f32(part), N, Ci, Co, Lin, 15, 7, L.stream())
+        res.append((y, part))
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+    # input gradient: dY bf16 [N][Co][PA] -> dx fp32 (existing entry point) vs dx bf16 [N][Ci][ldx]
+    PA = L.query("ecg_conv1d_n16_positions", Lo, 15, 7, 0)
+    dyh = torch.zeros(N, Co, PA, dtype=torch.bfloat16, device="cuda")
+    dyh[:, :, :Lo] = dev(rng.standard_normal((N, Co, Lo)).astype(np.float32)).to(torch.bfloat16)
+    dx32 = torch.empty(N, Ci, Lin, device="cuda")
+    L.call("ecg_conv1d_bwd_data_bf16h", L.ptr(dyh), PA, L.ptr(wb_bwd), L.f32(dx32), N, Ci, Co, Lin, 15, 7, L.stream())
+    dxh = torch.full((N, Ci, ldx), 3.0, dtype=torch.bfloat16, device="cuda")
+    L.call("ecg_conv1d_bwd_data_bf16hh", L.ptr(dyh), PA, L.ptr(wb_bwd), L.ptr(dxh), ldx, N, Ci, Co, Lin, 15, 7, L.stream())
+    assert torch.equal(dxh[:, :, :Lin], dx32.to(torch.bfloat16))
+    assert bool((dxh[:, :, Lin:].float() == 3.0).all())            # the row padding is not written
+    with pytest.raises(L.EcgHipError, match="even dx row stride"):
+        L.call("ecg_conv1d_bwd_data_bf16hh", L.ptr(dyh), PA, L.ptr(wb_bwd), L.ptr(dxh), Lin | 1, N, Ci, Co, Lin, 15, 7,
+               L.stream())
 
 
 @pytest.mark.parametrize("case", [(19, 12, 32, 300), (37, 64, 128, 125), (16, 32, 64, 64)])
