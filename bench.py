@@ -45,7 +45,12 @@ CONV_ENTRY = {"ecg_conv1d_fwd": (FWD, "f32"), "ecg_conv1d_fwd_bf16": (FWD, "bf16
               "ecg_conv1d_bwd_data": (DGRAD, "f32"), "ecg_conv1d_bwd_data_ld": (DGRAD, "f32"),
               "ecg_conv1d_bwd_data_bf16": (DGRAD, "bf16"), "ecg_conv1d_bwd_data_bf16h": (DGRAD, "bf16"),
               "ecg_conv1d_bwd_weight_bias": (WGRAD, "f32"), "ecg_conv1d_bwd_weight_bias_ld": (WGRAD, "f32"),
-              "ecg_conv1d_bwd_weight_bias_bf16": (WGRAD, "bf16"), "ecg_conv1d_bwd_weight_bias_bf16_packed": (WGRAD, "bf16")}
+              "ecg_conv1d_bwd_weight_bias_bf16": (WGRAD, "bf16"), "ecg_conv1d_bwd_weight_bias_bf16_packed": (WGRAD, "bf16"),
+              "ecg_conv1d_fwd_bf16_yh": (FWD, "bf16"), "ecg_conv1d_bwd_data_bf16hh": (DGRAD, "bf16")}
+# bytes per element of the two activation operands an entry point streams (reduction-side tensor, result-side tensor);
+# everything not listed reads and writes fp32.  ecg_conv1d_fwd_bf16_yh reads fp32 only for the network input (x_bf16 = 0).
+IO_BYTES = {"ecg_conv1d_bwd_data_bf16h": (4, 2), "ecg_conv1d_bwd_weight_bias_bf16_packed": (2, 2),
+            "ecg_conv1d_bwd_data_bf16hh": (2, 2)}
 
 
 # ------------------------------------------------------------------------------------------------
@@ -187,7 +192,10 @@ def layer_table(timings):
         N, ci, co, Lc, K, pad = sig[-6:]
         Lo = Lc + 2 * pad - K + 1
         flops = 2.0 * N * co * ci * K * Lo
-        abytes = 4.0 * N * (Lc * ci + Lo * co) + 4.0 * co * ci * K
+        bx, by = IO_BYTES.get(name, (4, 4))
+        if name == "ecg_conv1d_fwd_bf16_yh":
+            bx, by = (2 if sig[0] else 4), 2
+        abytes = float(N) * (bx * Lc * ci + by * Lo * co) + 4.0 * co * ci * K
         avg = sum(ms) / len(ms)
         peak = PEAK_BF16_TFLOPS if dt == "bf16" else PEAK_F32_TFLOPS
         ach = flops / (avg * 1e-3) / 1e12
@@ -390,7 +398,8 @@ def main():
     ap.add_argument("--labels", type=int, default=5, help="output labels (1 = the AF-binary shape of BASELINE config 5)")
     ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32",
                     help="f32 (default, the parity path) or bf16 = opt-in mixed precision of BASELINE config 5: "
-                         "bf16 conv operands in forward/input-grad/weight-grad, fp32 accumulate, fp32 everything else")
+                         "bf16 conv operands in forward/input-grad/weight-grad and bf16 storage of the tensors between the kernels of a "
+                         "block chain (y, p, dp); fp32 accumulate, BatchNorm arithmetic, parameters, tail, optimizer")
     ap.add_argument("--graph", action="store_true",
                     help="replay the whole step as one captured hipGraph (ecg_hip.graph.GraphedTrainStep); single GPU only")
     ap.add_argument("--cpu-seconds", type=float, default=14.0)
@@ -513,7 +522,8 @@ def main():
                          f"{'bf16 conv operands' if bf16 else 'fp32'}, batch {B}/GPU, global batch {B * world}"),
             "value": round(value, 1), "unit": "windows/s", "ms_per_step": round(1e3 * elapsed / spec["steps"], 4),
             "step_ms": step_ms, "value_at_median_step": round(world * B / (step_ms["median"] * 1e-3), 1),
-            "dtype": "f32" if not bf16 else "bf16 conv operands (fwd, input-grad, weight-grad) / f32 accumulate, activations, BN, tail, optimizer",
+            "dtype": "f32" if not bf16 else ("bf16 conv operands (fwd, input-grad, weight-grad) and inter-kernel activation storage (y, p, dp) / "
+                                             "f32 accumulate, BN arithmetic, parameters, tail, optimizer"),
             "optimizer": "torch.optim.AdamW (stock, foreach)" if stock else "ecg_hip.optim.FlatAdamW (one launch)",
             "loop": "hipGraph replay of the whole step (GraphedTrainStep)" if graph else "src.training loop API, eager",
             "final_loss": round(float(last_loss), 6),

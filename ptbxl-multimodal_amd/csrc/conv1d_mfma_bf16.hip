@@ -112,7 +112,7 @@ __global__ void pack_weights_bf16_kernel(const float *__restrict__ w, u16 *__res
 //     train step: the BatchNorm passes then read half the bytes.  The statistics are taken over the ROUNDED values,
 //     i.e. exactly over the tensor the BatchNorm passes will read.
 template <int CO_T, int T_T, int WCO, int WT, bool STATS, bool XH = false, bool WRES = false, bool YH = false>
-__global__ __launch_bounds__(64 * WCO * WT) void conv1d_mfma_bf16_fwd_kernel(
+__global__ __launch_bounds__(64 * WCO * WT) __attribute__((amdgpu_waves_per_eu(2))) void conv1d_mfma_bf16_fwd_kernel(
     const float *__restrict__ x, const u16 *__restrict__ wb, const float *__restrict__ bias,
     float *__restrict__ y, float *__restrict__ partials, int Cin, int Cout, int L, int Lo, int pad,
     int tiles_t, int N, int G, int ldx, int ldyo) {
