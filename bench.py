@@ -480,6 +480,25 @@ def main():
 
         if spec["priming"] > 0:
             run(wrapped, ListLoader(batch, spec["priming"]), opt, dev)
+        exchange_mode = None
+        if world > 1 and not stock:
+            # Calibrate the exchange on THIS node (outside the timed region): hooked two-bucket all-reduces under backward
+            # vs one all-reduce in step().  Every rank times both; the decision is taken on the max over ranks, which
+            # the all-reduce makes identical everywhere.
+            cal = {}
+            for mode in (True, False):
+                opt.set_overlap(mode)
+                run(wrapped, ListLoader(batch, 3), opt, dev)
+                barrier()
+                t0 = time.perf_counter()
+                run(wrapped, ListLoader(batch, 10), opt, dev)
+                barrier()
+                t = torch.tensor([(time.perf_counter() - t0) / 10], dtype=torch.float64, device=dev)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                cal["overlapped" if mode else "single"] = round(t.item() * 1e3, 4)
+            exchange_mode = "overlapped" if cal["overlapped"] <= cal["single"] else "single"
+            opt.set_overlap(exchange_mode == "overlapped")
+            exchange_mode = {"mode": exchange_mode, "calibration_ms_per_step": cal}
         run(wrapped, ListLoader(batch, spec["warmup"]), opt, dev)
         loader = ListLoader(batch, spec["steps"], record=True)
         barrier()
@@ -536,6 +555,8 @@ def main():
         if exch:
             torch.cuda.synchronize()
             res["exchange_exposed_ms_per_step"] = percentiles([a.elapsed_time(b) for a, b in exch])
+        if exchange_mode:
+            res["exchange"] = exchange_mode
         extra = None
         if world > 1 and not stock:
             # RCCL sanity on real gradients: exchange once by hand and compare checksums
@@ -604,6 +625,8 @@ def main():
                             "ranks_seen_by_allreduce": int(ones.item()), **(rccl_extra or {})}
             if "exchange_exposed_ms_per_step" in primary:
                 line["rccl"]["exchange_exposed_ms_per_step"] = primary["exchange_exposed_ms_per_step"]
+            if "exchange" in primary:
+                line["rccl"]["exchange"] = primary["exchange"]
             if args.n1_value:
                 line["efficiency_vs_n1"] = round(primary["value"] / (world * args.n1_value), 4)
     if rank == 0:

@@ -91,6 +91,7 @@ class FlatAdamW(torch.optim.Optimizer):
         self._early_work = None
         self._overlap = bool(overlap) and self._exchange and 0 < self._n_early < len(self._params)
         self._sync = True                 # False inside no_sync(): gradients accumulate locally, nothing is exchanged
+        self._overlap_active = self._overlap          # set_overlap(): the hooks stay registered, this switches them
         if self._overlap:
             self._late_total = len(self._params) - self._n_early
             for p in self._params[self._n_early:]:
@@ -133,6 +134,18 @@ class FlatAdamW(torch.optim.Optimizer):
             else:
                 dst.copy_(p.grad.reshape(-1))
 
+    def set_overlap(self, on):
+        """Switch between the bucketed exchange issued from the backward hooks (True; needs `overlap=True` at
+        construction) and ONE all-reduce of the whole flat gradient in step() (False).  Which is faster depends on the
+        node: the hooked all-reduces hide under the backward of the early blocks, but RCCL's kernel then shares the
+        CUs with conv launches that are sized to fill the chip in exactly one round (measured on one rank: +55 us per
+        step hooked, +4 us single).  Call it between steps, on every rank alike; returns the mode now in force."""
+        if self._late_work is not None or self._early_work is not None:
+            raise RuntimeError("FlatAdamW.set_overlap: an exchange is in flight (call it between steps)")
+        self._overlap_active = bool(on) and self._overlap
+        self._late_pending = self._early_pending = 0
+        return self._overlap_active
+
     def no_sync(self):
         """Context manager for gradient accumulation over several backward passes per step (as
         DistributedDataParallel.no_sync): inside it the hooked exchange is off and gradients only accumulate
@@ -159,7 +172,7 @@ class FlatAdamW(torch.optim.Optimizer):
     def _on_late_grad(self, _param):
         """Autograd hook: when the last gradient of the late bucket lands, gather that bucket into
         the flat gradient and start its all-reduce; backward of the early blocks keeps running."""
-        if not self._sync:
+        if not self._sync or not self._overlap_active:
             return
         if self._late_work is not None:
             self._refuse_second_exchange()
@@ -173,7 +186,7 @@ class FlatAdamW(torch.optim.Optimizer):
             self._late_work = torch.distributed.all_reduce(late, group=self.process_group, async_op=True)
 
     def _on_early_grad(self, _param):
-        if not self._sync:
+        if not self._sync or not self._overlap_active:
             return
         if self._early_work is not None:
             self._refuse_second_exchange()

@@ -153,9 +153,29 @@ def _worker_overlap(rank, world, port, out_dir):
         both = [torch.empty_like(local) for _ in range(world)]
         dist.all_gather(both, local)
         assert torch.allclose(flat, both[0] + both[1], rtol=0, atol=0)
+    # set_overlap(False): the hooks stay quiet, step() exchanges everything in one collective — same summed gradient;
+    # and back again (what bench.py's per-node calibration does between steps)
+    for mode in (False, True):
+        assert opt.set_overlap(mode) is mode
+        opt.zero_grad()
+        torch.nn.functional.binary_cross_entropy_with_logits(model(*batch[:-1]), batch[-1]).backward()
+        assert (opt._late_work is not None) is mode
+        local = torch.cat([p.grad.reshape(-1) for p in model.parameters()]).clone()
+        flat, scale = opt.reduce_gradients()
+        both = [torch.empty_like(local) for _ in range(world)]
+        dist.all_gather(both, local)
+        assert scale == 0.5 and torch.equal(flat, both[0] + both[1])
+    opt.zero_grad()
+    torch.nn.functional.binary_cross_entropy_with_logits(model(*batch[:-1]), batch[-1]).backward()
+    try:
+        opt.set_overlap(False)                       # an exchange is in flight
+        raise AssertionError("set_overlap accepted a switch with an all-reduce in flight")
+    except RuntimeError as e:
+        assert "in flight" in str(e)
+    opt.reduce_gradients()
     # overlap=False gives the same flat gradient through one collective
     opt2 = FlatAdamW(model.parameters(), lr=1e-4, overlap=False)
-    assert not opt2._overlap
+    assert not opt2._overlap and opt2.set_overlap(True) is False
     dist.barrier()
     dist.destroy_process_group()
 

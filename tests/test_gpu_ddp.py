@@ -118,6 +118,7 @@ def test_bench_two_rank_line(tmp_path, launcher):
     r = d["rccl"]
     assert r["ranks_seen_by_allreduce"] == 2 and r["rel_diff"] < 1e-6 and r["flat_gradient_bytes"] == 719397 * 4
     assert r["exchange_exposed_ms_per_step"]["n"] == 5
+    assert r["exchange"]["mode"] in ("overlapped", "single") and set(r["exchange"]["calibration_ms_per_step"]) == {"overlapped", "single"}
     assert [a["value"] > 0 for a in d["also"]] == [True]          # N > 1: the multimodal leg only
     assert {row["op"] for row in d["layers"]} == {"fwd", "dgrad", "wgrad"} and len(d["layers"]) == 11
 
