@@ -887,7 +887,10 @@ __global__ __launch_bounds__(256, 2) void conv1d_mfma_wgrad_dma_kernel(
     }
     ECG_STAMP_AT(3);
 #ifdef ECG_STAMP
-    if (g_stamps && threadIdx.x == 0) g_stamps[(size_t)blockIdx.x * 8 + 5] = (unsigned long long)total;
+    if (g_stamps && threadIdx.x == 0)          // stages | HW_ID (cu / sh / se) << 16 | XCC_ID << 48: which workgroups share a CU
+        g_stamps[(size_t)blockIdx.x * 8 + 5] = (unsigned long long)(total & 0xFFFF) |
+            ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) << 16) |
+            ((unsigned long long)(__builtin_amdgcn_s_getreg((31 << 11) | 20) & 0xF) << 48);
 #endif
 
     if (want_bias) {

@@ -19,7 +19,8 @@ os.environ.setdefault("ECG_HIP_LIB", os.path.join(ROOT, "ptbxl-multimodal_amd", 
 def report(b, stamps, names, stages=False):
     import numpy as np
     s = stamps.cpu().numpy().reshape(-1, 8)
-    s = s[s[:, 0] != 0]
+    order = np.nonzero(s[:, 0] != 0)[0]                 # blockIdx of every stamped workgroup
+    s = s[order]
     rt0, rt1 = s[:, 7].astype(np.float64), s[:, 6].astype(np.float64)      # s_memrealtime, 100 MHz
     t = s[:, :5].astype(np.float64)
     dur_ticks = t[:, 4] - t[:, 0]
@@ -35,8 +36,27 @@ def report(b, stamps, names, stages=False):
                       enumerate(names)},
            "wg_total_median_us": round(float(np.median(dur_ticks)) / clk * 1e6, 2)}
     if stages:
-        out["stages_per_workgroup_median"] = int(np.median(s[:, 5]))
-        out["us_per_stage_median"] = round(float(np.median(ph[:, 2] / np.maximum(s[:, 5] - 1, 1))) / clk * 1e6, 3)
+        nst = (s[:, 5] & 0xFFFF).astype(np.float64)
+        out["stages_per_workgroup_median"] = int(np.median(nst))
+        out["us_per_stage_median"] = round(float(np.median(ph[:, 2] / np.maximum(nst - 1, 1))) / clk * 1e6, 3)
+        # which workgroups share a CU (HW_ID bits: cu 8-11, sh 12, se 13-15 (+ XCC)), and does launch order decide who is
+        # favoured?  end time of the earlier-numbered / later-numbered workgroup of each co-resident pair
+        hw = (s[:, 5] >> 16).astype(np.int64)
+        cu_key = ((hw >> 8) & 0xFF) | (((s[:, 5] >> 48) & 0xF).astype(np.int64) << 8)
+        end_us = (rt1 - rt0.min()) / 100.0
+        first, second, gaps = [], [], []
+        for key in np.unique(cu_key):
+            idx = np.nonzero(cu_key == key)[0]
+            if len(idx) == 2:
+                a, c = (idx[0], idx[1]) if order[idx[0]] < order[idx[1]] else (idx[1], idx[0])
+                first.append(end_us[a]); second.append(end_us[c]); gaps.append(int(order[c] - order[a]))
+        if first:
+            first, second = np.array(first), np.array(second)
+            out["cu_pairs"] = {"pairs": int(len(first)), "end_us_lower_blockidx_median": round(float(np.median(first)), 1),
+                               "end_us_higher_blockidx_median": round(float(np.median(second)), 1),
+                               "lower_ends_first_share": round(float((first < second).mean()), 3),
+                               "abs_gap_us_median": round(float(np.median(np.abs(first - second))), 1),
+                               "blockidx_distance_counts": {str(k): int(v) for k, v in zip(*np.unique(gaps, return_counts=True))}}
     print(json.dumps(out))
 
 
