@@ -525,6 +525,39 @@ def test_bf16_mixed_precision_train_step_config5(B, T, act_bf16):
         assert rel < 0.2 and cos > 0.98, (k, rel, cos)
 
 
+@pytest.mark.parametrize("frozen", [None, 1, 2, 3])
+def test_bf16_chain_with_a_frozen_batchnorm_or_an_input_gradient(frozen):
+    """bf16 activation storage hands bf16 tensors from block to block only when the consumer is a training block that
+    reads them; a block whose BatchNorm is in eval mode (frozen statistics) — or the caller asking for the gradient
+    of the input — must get / give fp32 tensors.  Gradients agree with the fp32-storage run at bf16 accuracy."""
+    from ecg_hip import functional as hipF
+    from src.models.ecg_cnn import ECGCNN
+    from src.utils.seed import set_seed
+    x0, y = R.synthetic_batch(6, 1000, 5)
+    res = []
+    for act in (True, False):
+        set_seed(3)
+        model = ECGCNN(num_labels=5).to(DEV).train()
+        if frozen is not None:
+            model.backbone[frozen].net[1].eval()
+        x = x0.to(DEV).requires_grad_(frozen is None)
+        hipF.set_bf16_activation_storage(act)
+        try:
+            with hipF.conv_precision("bf16"):
+                loss = hipF.binary_cross_entropy_with_logits(model(x), y.to(DEV))
+                loss.backward()
+        finally:
+            hipF.set_bf16_activation_storage(True)
+        g = torch.cat([p.grad.reshape(-1) for k, p in model.named_parameters() if ".net.0.bias" not in k])
+        res.append((loss.item(), g, x.grad))
+    assert abs(res[0][0] - res[1][0]) < 5e-3
+    cos = torch.nn.functional.cosine_similarity(res[0][1], res[1][1], dim=0).item()
+    assert cos > 0.99, cos
+    if frozen is None:
+        assert res[0][2].dtype == torch.float32 and res[0][2].shape == x0.shape
+        assert torch.nn.functional.cosine_similarity(res[0][2].reshape(-1), res[1][2].reshape(-1), dim=0).item() > 0.98
+
+
 def test_graphed_train_step_matches_eager():
     """A captured hipGraph of the whole step (fwd + BCE + bwd + FlatAdamW with a device-side step
     counter) replays to the same parameters as the eager loop."""
