@@ -79,7 +79,7 @@ def main():
     shutil.copy(stats, os.path.join(PROF, f"{TAG}_kernel_stats.csv"))
     steps = 20 + 5 + 5          # timed + warm-up + the instrumented pass of bench.py (--priming 0)
     summ = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "prof_summary.py"),
-                           os.path.dirname(stats), str(steps), "40"], capture_output=True, text=True).stdout
+                           stats, str(steps), "40"], capture_output=True, text=True).stdout
     open(os.path.join(PROF, f"{TAG}_kernel_stats_summary.txt"), "w").write(
         f"# rocprofv3 --kernel-trace --stats -- python3 bench.py --no-cpu-baseline --no-also --steps 20 --warmup 5 --priming 0  ({steps} steps incl. warm-up and the instrumented pass)\n" + summ)
 

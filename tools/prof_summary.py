@@ -1,15 +1,18 @@
 #!/usr/bin/env python3
 """Summarise a rocprofv3 --kernel-trace --stats run: per-kernel time per step, plus gaps.
-usage: tools/prof_summary.py <dir with *_kernel_stats.csv> <steps in the run> [top]"""
+usage: tools/prof_summary.py <dir with *_kernel_stats.csv | one *_kernel_stats.csv> <steps in the run> [top]
+A directory may hold several runs (gpurun merges every call's files into the same local folder): the NEWEST
+*_kernel_stats.csv is taken, and the kernel trace with the same process prefix."""
 import csv
 import glob
+import os
 import sys
 
 
 def main():
     d, steps = sys.argv[1], float(sys.argv[2])
     top = int(sys.argv[3]) if len(sys.argv) > 3 else 30
-    f = glob.glob(d + "/**/*_kernel_stats.csv", recursive=True)[0]
+    f = d if os.path.isfile(d) else sorted(glob.glob(d + "/**/*_kernel_stats.csv", recursive=True), key=os.path.getmtime)[-1]
     rows = list(csv.DictReader(open(f)))
     tot = sum(float(r["TotalDurationNs"]) for r in rows)
     print(f"kernel time per step: {tot / 1e6 / steps:.3f} ms over {sum(int(r['Calls']) for r in rows) / steps:.1f} launches/step")
@@ -17,7 +20,7 @@ def main():
         name = r["Name"].replace("void ecg::", "").replace("ecg::", "")[:64]
         print(f"{name:64s} calls/step={int(r['Calls']) / steps:5.1f} avg_us={float(r['AverageNs']) / 1e3:8.1f} "
               f"us/step={float(r['TotalDurationNs']) / 1e3 / steps:8.1f} {float(r['Percentage']):5.1f}%")
-    tr = glob.glob(d + "/**/*_kernel_trace.csv", recursive=True)
+    tr = [t for t in [f.replace("_kernel_stats.csv", "_kernel_trace.csv")] if os.path.exists(t)]
     if tr:
         # the conv kernels serve several layers each: split every kernel's dispatches into layers by duration
         # (clusters within +-12 %), so that a layer's average can be read against bench.py's per-entry-point time
