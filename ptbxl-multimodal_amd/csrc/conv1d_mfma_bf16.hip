@@ -38,6 +38,13 @@ constexpr int kCB = 16;      // input channels per MFMA (its K dimension)
 
 __device__ __forceinline__ int acc_row_b(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }
 
+// s_waitcnt vmcnt(N) with lgkmcnt / expcnt left at "no wait"
+template <int N>
+__device__ __forceinline__ void wait_vm() {
+    static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit counter");
+    __builtin_amdgcn_s_waitcnt(((N >> 4) << 14) | 0x0F70 | (N & 15));
+}
+
 // s_waitcnt lgkmcnt(n) with vmcnt / expcnt left at "no wait" (n is a compile-time constant after unrolling)
 __device__ __forceinline__ void wait_lgkm(int n) {
     switch (n) {
@@ -356,7 +363,14 @@ __global__ __launch_bounds__(64 * WCO * WT) __attribute__((amdgpu_waves_per_eu(2
 #pragma unroll
             for (int o = k * OPS; o < (k + 1) * OPS; ++o) {      // weight DMA pieces first (longest latency), x commits, x loads;
                 if (o < DPW) { if (!WRES) dma_w(o, wnext, nxt); }   // all UNCONDITIONAL: stages past the end restage valid data
-                else if (o < DPW + XL) commit_x(o - DPW, nxt);
+                else if (o < DPW + XL) {
+                    // The commits need the x loads of the PREVIOUS chunk; the only vector-memory operations issued since
+                    // are this chunk's DPW weight DMA pieces (vmcnt counts in issue order).  Left alone, hipcc puts
+                    // s_waitcnt vmcnt(0) here (it loses the count over the loop's back edge): every wave then waits
+                    // for the L2 round trip of the DMA pieces it issued a few taps ago, in the middle of the chunk.
+                    if (o == DPW) wait_vm<WRES ? 0 : DPW>();
+                    commit_x(o - DPW, nxt);
+                }
                 else if (o < NOPS) load_x(o - XL - DPW);
             }
             __builtin_amdgcn_sched_barrier(0);
