@@ -37,8 +37,12 @@ __device__ __forceinline__ void ld_pair_y(const float *y, size_t row, int ld, in
 // ---------------------------------------------------------------------------------------
 // statistics
 // ---------------------------------------------------------------------------------------
+// Workgroups of the streaming passes: 2048 = 256 CUs x 8 resident 256-thread workgroups, i.e. exactly one round (every
+// workgroup pays the folded statistics combine once, none waits for a slot).  Measured per train step at B=256 12x1000:
+// 1024: +9 us, 1536: -3, 2048: -10, 2560: +6, 3072: +3, 4096: 0 (round 1's value), 8192: +42.
+constexpr int kStreamBlocks = 2048;
 static int stat_splits(int N, int C) {
-    int s = cdiv(1024, C);
+    int s = cdiv(1024, C);             // (2048 measured the same, 512 slower)
     if (s > N) s = N;
     if (s < 1) s = 1;
     return s;
@@ -407,7 +411,8 @@ __device__ __forceinline__ void store_n16(u16n *dst, const float *v) {
 }
 
 // p [N][C][Lp] fp32 (may be NULL) and pb[g][c][pos][16] with pb[.., j + shift, s] = p[16g + s][c][j].
-// grid = (ceil(PX/256), C, G)
+// grid = (ceil(PX/256), C, G)  (an item loop over one round of resident workgroups, as the fp32 passes use, measured
+// SLOWER here: 38.0 vs 34.1 us at 12x5000 — these kernels keep 16-32 loads per lane in flight and want the parallelism)
 template <bool FIN, bool AL8, bool YH = false>
 __global__ __launch_bounds__(kBlock) void bn_relu_pool_fwd_n16_kernel(
     const float *__restrict__ y, const float *__restrict__ gamma, const float *__restrict__ beta,
@@ -627,7 +632,7 @@ static int pool_fwd_impl(const BnFin *fin, const float *y, const float *gamma, c
     const int Lp = L / 2;
     if (Lp == 0 && !fin) return ECG_OK;   // MaxPool1d(2) of a length-1 row is empty
     ECG_REQUIRE(p || Lp == 0, "bn_relu_pool_fwd: null output");
-    int S2 = cdiv(4096, C);
+    int S2 = cdiv(kStreamBlocks, C);
     if (S2 > N) S2 = N;
     const bool al8 = pairs_aligned(y, L);
     const BnFin f = fin ? *fin : BnFin{};
@@ -646,7 +651,7 @@ static int pool_gap_fwd_impl(const BnFin *fin, const float *y, const float *gamm
     if (rc) return rc;
     ECG_REQUIRE(y && gamma && beta && mean && invstd && g, "bn_relu_pool_gap_fwd: null pointer");
     ECG_REQUIRE(L >= 2, "bn_relu_pool_gap_fwd: L=%d leaves an empty pooled row", L);
-    int S2 = cdiv(4096, C);
+    int S2 = cdiv(kStreamBlocks, C);
     if (S2 > cdiv(N, 4)) S2 = cdiv(N, 4);          // four rows (one per wave) in flight per workgroup
     if (yh)         // bf16 activation storage (train mode: always with the statistics combine)
         hipLaunchKernelGGL((bn_relu_pool_gap_fwd_kernel<true, true>), dim3(C, S2), dim3(kBlock), 0, st, y, gamma, beta,
@@ -772,7 +777,7 @@ static int bn_bwd_impl(const float *y, const float *g, const float *gamma, const
     if (rc) return rc;
     // dx pass with the combine of the reduce partials folded in (no finalize launch)
     const int Lh = (ldy + 1) / 2;
-    int S2 = cdiv(4096, C);            // ~4096 blocks: enough to keep every CU streaming
+    int S2 = cdiv(kStreamBlocks, C);            // one round of resident workgroups
     if (S2 > N) S2 = N;
     if (pairs_aligned(y, L) && L >= 2)
         hipLaunchKernelGGL((bn_bwd_dx_kernel<FUSED, true>), dim3(C, S2), dim3(kBlock), 0, st, y, g, gamma, beta, mean,
