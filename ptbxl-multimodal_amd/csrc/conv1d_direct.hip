@@ -365,6 +365,37 @@ __global__ __launch_bounds__(256) void pack_weights_grouped_kernel(PackArgs a) {
     const int nco = min(kPackCo, pr.Co - co0), nci = min(kPackCi, pr.Ci - ci0);
     const int K = pr.K, run = nci * K, ld = kPackCi * kPackKMax + 1;        // run: contiguous source floats per co row
     const int tid = threadIdx.x;
+    if (K == 15 && nco == kPackCo && nci == kPackCi) {
+        // the model's own case (full 16 x 16 tiles, 15 taps): the same three passes with compile-time divisors — the
+        // generic loops below spend most of their time in runtime integer division
+        constexpr int KC = 15, RUN = kPackCi * KC;
+        const float *src = pr.w + ((size_t)co0 * pr.Ci + ci0) * KC;
+        static_assert((kPackCo * RUN) % 256 == 0, "whole passes");
+#pragma unroll
+        for (int it = 0; it < kPackCo * RUN / 256; ++it) {
+            const int e = tid + 256 * it;
+            const int co = e / RUN, r = e - co * RUN;
+            tile[co * ld + r] = src[(size_t)co * pr.Ci * KC + r];
+        }
+        __syncthreads();
+        if (pr.w_fwd) {
+#pragma unroll
+            for (int it = 0; it < kPackCo * RUN / 256; ++it) {
+                const int e = tid + 256 * it;
+                const int co = e % kPackCo, r = e / kPackCo, k = r / kPackCi, ci = r - k * kPackCi;
+                pr.w_fwd[((size_t)k * pr.Ci + ci0 + ci) * pr.Co + co0 + co] = tile[co * ld + ci * KC + k];
+            }
+        }
+        if (pr.w_bwd) {
+#pragma unroll
+            for (int it = 0; it < kPackCo * RUN / 256; ++it) {
+                const int e = tid + 256 * it;
+                const int ci = e % kPackCi, r = e / kPackCi, co = r % kPackCo, k = r / kPackCo;
+                pr.w_bwd[((size_t)(KC - 1 - k) * pr.Co + co0 + co) * pr.Ci + ci0 + ci] = tile[co * ld + ci * KC + k];
+            }
+        }
+        return;
+    }
     for (int e = tid; e < nco * run; e += 256) {
         const int co = e / run, r = e - co * run;
         tile[co * ld + r] = pr.w[((size_t)(co0 + co) * pr.Ci + ci0) * K + r];
