@@ -9,18 +9,20 @@ Primary workload (BASELINE.json configs[1], the configuration the metric is quot
 ECGCNN(5), 12x1000 fp32 synthetic windows, batch 256 PER GPU (weak scaling), inputs resident in HBM,
 driven through the reference's own loop API (src.training.loop.train_one_epoch) with the flat AdamW;
 with N > 1 the gradient exchange is one RCCL all-reduce of the flat 2.9 MB gradient per step (two
-buckets issued from backward hooks).  Rank 0 prints ONE JSON line.
+buckets issued from backward hooks, or one all-reduce in step(): calibrated on the node, `rccl.exchange`).
+Rank 0 prints ONE JSON line.
 
 Protocol per leg: `--priming` untimed steps (allocator, lazy module loading, clock ramp), W untimed
 warm-up steps, then EXACTLY K steps between barrier + synchronize (max over ranks) -> `value`,
-`ms_per_step`; one HIP event per step boundary on the launch stream -> `step_ms` median / p10 / p90.
-A second, event-instrumented pass (events around every ABI launch) prices every conv entry point of
+`ms_per_step` (nothing but the steps is in that region); the same K steps once more with one HIP event per step
+boundary on the launch stream -> `step_ms` median / p10 / p90.
+A third, event-instrumented pass (events around every ABI launch) prices every conv entry point of
 every layer against its roof -> `roofline` (the dominant entry point) and `layers`.
 
 `also` carries the other configurations of BASELINE.json, each measured the same way with its own
 roofline: ECGMultimodal (configs[2]/[3]), the headline with the stock torch.optim.AdamW the reference
 scripts construct (scripts/03_train_ecg_baseline.py:130-133), and configs[4] (ECGCNN(1), 12x5000,
-batch 256) in fp32 and with bf16 conv operands.  The CPU baseline (oracle/ref_models.py, stock torch
+batch 256) in fp32 and in the opt-in bf16 mode.  The CPU baseline (oracle/ref_models.py, stock torch
 CPU ops: "port") runs LAST so that its thread pool cannot disturb a GPU leg.
 """
 import argparse
@@ -500,7 +502,10 @@ def main():
             opt.set_overlap(exchange_mode == "overlapped")
             exchange_mode = {"mode": exchange_mode, "calibration_ms_per_step": cal}
         run(wrapped, ListLoader(batch, spec["warmup"]), opt, dev)
-        loader = ListLoader(batch, spec["steps"], record=True)
+        # The timed region carries NO per-step events: an event record between two steps is a barrier packet with a
+        # timestamp and costs 2-7 us of idle front end per step (A/B on one box: 1.6514 / 1.6552 ms with, 1.6498 / 1.6482
+        # without).  The per-step distribution comes from a second pass of the same K steps right after it.
+        loader = ListLoader(batch, spec["steps"])
         barrier()
         t0 = time.perf_counter()
         last_loss = run(wrapped, loader, opt, dev)
@@ -510,6 +515,9 @@ def main():
             t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = t.item()
+        loader = ListLoader(batch, spec["steps"], record=True)
+        run(wrapped, loader, opt, dev)
+        torch.cuda.synchronize()
         step_ms = percentiles(loader.step_ms())
 
         # instrumented pass (HIP events around every ABI launch on the launch stream); always eager
