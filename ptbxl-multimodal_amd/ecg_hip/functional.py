@@ -336,10 +336,12 @@ class ConvBlockFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, b, gamma, beta, running_mean, running_var, nbt, training, momentum,
                 eps, pad, gap=False, packed=None, grad_enabled=True, x_n16=None, next_geom=None):
-        """Returns (p, p_n16).  p_n16 is None except in bf16 mode when `next_geom` = (K, pad) of the conv that
-        consumes p is given: then the BN+ReLU+pool pass also writes p in the bf16 "n16" layout that conv's weight
-        gradient reads (no packing pass later).  `x_n16` is this block's own input in that layout (from the
-        previous block), kept for backward."""
+        """Returns (p, p_n16).  p_n16 is None except in bf16 mode when `next_geom` = (K, pad[, C_out, trains]) of the
+        conv block that consumes p is given: then the BN+ReLU+pool pass also writes p in the bf16 "n16" layout that
+        conv's weight gradient reads (no packing pass later).  `x_n16` is this block's own input in that layout (from
+        the previous block), kept for backward — or the carry of conv_block_chain, (n16 tensor, true row length),
+        when x itself arrives as a bf16 [N][C][ld] activation.  With bf16 activation storage and a next block that
+        trains (all four fields of next_geom), p is returned as bf16 [N][C_out][ldp] instead of fp32."""
         x, w = _contig(x), _contig(w)
         Co, _, K = w.shape
         x_len = None
