@@ -252,7 +252,7 @@ __global__ __launch_bounds__(256) void tail_bwd_chain_kernel(TailBwdArgs a) {
 
 // ---------------------------------------------------------------------------------------
 // grouped weight gradient: for each problem p, dW_p[o][i] = sum_m G_p[m][o] X_p[m][i],
-// db_p[o] = sum_m G_p[m][o].  32x32 output tile per workgroup, 2x2 outputs per thread.
+// db_p[o] = sum_m G_p[m][o].  32x32 output tile per workgroup.
 // ---------------------------------------------------------------------------------------
 constexpr int kMaxProb = 8;
 struct WgProb {
@@ -265,8 +265,16 @@ struct WgArgs {
     int count, M;
 };
 
+// One 32 x 32 output tile per workgroup on the fp32 matrix core (v_mfma_f32_32x32x2_f32: an exact fp32 fma chain over
+// the samples, two per instruction).  The four waves split the samples into four contiguous ranges and are summed
+// through LDS in wave order (fixed order: deterministic).  Operands come straight from global memory — lane (o | i, k)
+// holds G[m + k][o0 + o] and X[m + k][i0 + i], 128 contiguous bytes per half wave — in batches of 16 instructions whose
+// loads are all in flight before the first MFMA issues: the kernel is a latency chain (72 workgroups for the whole
+// tail), the VALU version with its 32-sample LDS chunks took 12.4 us at B = 256, this one takes ~6.
+typedef float f32x16t __attribute__((ext_vector_type(16)));
 __global__ __launch_bounds__(256) void linear_wgrad_grouped_kernel(WgArgs a) {
-    __shared__ float Gs[32][33], Xs[32][33];
+    __shared__ float red[3][16][64];
+    __shared__ float bred[4][32];
     int pi = 0;
 #pragma unroll
     for (int q = 1; q < kMaxProb; ++q)
@@ -274,53 +282,52 @@ __global__ __launch_bounds__(256) void linear_wgrad_grouped_kernel(WgArgs a) {
     const WgProb pr = a.p[pi];
     const int tile = blockIdx.x - pr.tile0;
     const int o0 = (tile / pr.tiles_i) * 32, i0 = (tile % pr.tiles_i) * 32;
-    const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;   // thread owns o = 2ty..2ty+1, i = 2tx..2tx+1
-    float acc[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, half = lane >> 5;
+    const int steps = (a.M + 1) >> 1, per = (steps + 3) >> 2;           // MFMA steps (2 samples each) in all / per wave
+    const int s_begin = wave * per, s_end = min(steps, s_begin + per);
+    const bool ok_o = o0 + l31 < pr.Out, ok_i = i0 + l31 < pr.In;
+    const float *gp = pr.G + min(o0 + l31, pr.Out - 1), *xp = pr.X + min(i0 + l31, pr.In - 1);
+    f32x16t acc;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc[q] = 0.f;
     float bacc = 0.f;
-    // the next 32-sample chunk is loaded into registers while the current one is consumed
-    float gr[4], xr[4];
-    auto fetch = [&](int m0) {
+    constexpr int kBatch = 16;
+    for (int s0 = s_begin; s0 < s_end; s0 += kBatch) {
+        float gv[kBatch], xv[kBatch];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int e = tid + 256 * r, mm = e >> 5, cc = e & 31;
-            const int m = min(m0 + mm, a.M - 1);
-            const float gv = pr.G[(size_t)m * pr.Out + min(o0 + cc, pr.Out - 1)];
-            const float xv = pr.X[(size_t)m * pr.In + min(i0 + cc, pr.In - 1)];
-            gr[r] = (m0 + mm < a.M && o0 + cc < pr.Out) ? gv : 0.f;
-            xr[r] = (m0 + mm < a.M && i0 + cc < pr.In) ? xv : 0.f;
+        for (int u = 0; u < kBatch; ++u) {                  // unconditional, clamped loads; masked below
+            const int m = 2 * (s0 + u) + half, mc = min(m, a.M - 1);
+            gv[u] = gp[(size_t)mc * pr.Out];
+            xv[u] = xp[(size_t)mc * pr.In];
         }
-    };
-    fetch(0);
-    for (int m0 = 0; m0 < a.M; m0 += 32) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int e = tid + 256 * r, mm = e >> 5, cc = e & 31;
-            Gs[mm][cc] = gr[r];
-            Xs[mm][cc] = xr[r];
+        for (int u = 0; u < kBatch; ++u) {
+            const bool live = (s0 + u < s_end) && (2 * (s0 + u) + half < a.M);
+            const float g = (live && ok_o) ? gv[u] : 0.f, x = (live && ok_i) ? xv[u] : 0.f;
+            bacc += g;
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(g, x, acc, 0, 0, 0);
         }
-        __syncthreads();
-        if (m0 + 32 < a.M) fetch(m0 + 32);
-#pragma unroll 8
-        for (int k = 0; k < 32; ++k) {
-            const float g0 = Gs[k][2 * ty], g1 = Gs[k][2 * ty + 1];
-            const float x0 = Xs[k][2 * tx], x1 = Xs[k][2 * tx + 1];
-            acc[0][0] = __fmaf_rn(g0, x0, acc[0][0]); acc[0][1] = __fmaf_rn(g0, x1, acc[0][1]);
-            acc[1][0] = __fmaf_rn(g1, x0, acc[1][0]); acc[1][1] = __fmaf_rn(g1, x1, acc[1][1]);
-        }
-        if (i0 == 0 && tid < 32) {
-#pragma unroll 8
-            for (int k = 0; k < 32; ++k) bacc += Gs[k][tid];
-        }
-        __syncthreads();
     }
+    bacc += __shfl_xor(bacc, 32, 64);                       // the two samples of a step
+    if (wave > 0) {
 #pragma unroll
-    for (int u = 0; u < 2; ++u)
+        for (int q = 0; q < 16; ++q) red[wave - 1][q][lane] = acc[q];
+    }
+    if (half == 0) bred[wave][l31] = bacc;
+    __syncthreads();
+    if (wave == 0) {
 #pragma unroll
-        for (int v = 0; v < 2; ++v) {
-            const int o = o0 + 2 * ty + u, i = i0 + 2 * tx + v;
-            if (o < pr.Out && i < pr.In) pr.dW[(size_t)o * pr.In + i] = acc[u][v];
+        for (int w = 0; w < 3; ++w)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc[q] += red[w][q][lane];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {                      // D[row = o][col = i]: row (q & 3) + 8 (q >> 2) + 4 half, col l31
+            const int o = o0 + (q & 3) + 8 * (q >> 2) + 4 * half, i = i0 + l31;
+            if (o < pr.Out && i < pr.In) pr.dW[(size_t)o * pr.In + i] = acc[q];
         }
-    if (i0 == 0 && tid < 32 && pr.db && o0 + tid < pr.Out) pr.db[o0 + tid] = bacc;
+        if (i0 == 0 && half == 0 && pr.db && ok_o)
+            pr.db[o0 + l31] = ((bred[0][l31] + bred[1][l31]) + bred[2][l31]) + bred[3][l31];
+    }
 }
 
 __global__ void transpose_kernel(const float *__restrict__ w, float *__restrict__ wT, int rows,

@@ -77,11 +77,11 @@ def main():
         shutil.copy(f, os.path.join(PROF, os.path.basename(f)))
     stats = newest(os.path.join(OUT, f"prof_{TAG}", "**", "*_kernel_stats.csv"))
     shutil.copy(stats, os.path.join(PROF, f"{TAG}_kernel_stats.csv"))
-    steps = 20 + 5 + 5          # timed + warm-up + the instrumented pass of bench.py (--priming 0)
+    steps = 20 + 20 + 5 + 5     # timed + its per-step-event repeat + warm-up + the instrumented pass of bench.py (--priming 0)
     summ = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "prof_summary.py"),
                            stats, str(steps), "40"], capture_output=True, text=True).stdout
     open(os.path.join(PROF, f"{TAG}_kernel_stats_summary.txt"), "w").write(
-        f"# rocprofv3 --kernel-trace --stats -- python3 bench.py --no-cpu-baseline --no-also --steps 20 --warmup 5 --priming 0  ({steps} steps incl. warm-up and the instrumented pass)\n" + summ)
+        f"# rocprofv3 --kernel-trace --stats -- python3 bench.py --no-cpu-baseline --no-also --steps 20 --warmup 5 --priming 0  ({steps} steps incl. warm-up, the per-step-event repeat and the instrumented pass)\n" + summ)
 
     fetch = per_entry(os.path.join(OUT, f"pmc_fetch_{TAG}"))
     write = per_entry(os.path.join(OUT, f"pmc_write_{TAG}"))
