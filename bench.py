@@ -487,20 +487,8 @@ def main():
             # Calibrate the exchange on THIS node (outside the timed region): hooked two-bucket all-reduces under backward
             # vs one all-reduce in step().  Every rank times both; the decision is taken on the max over ranks, which
             # the all-reduce makes identical everywhere.
-            cal = {}
-            for mode in (True, False):
-                opt.set_overlap(mode)
-                run(wrapped, ListLoader(batch, 3), opt, dev)
-                barrier()
-                t0 = time.perf_counter()
-                run(wrapped, ListLoader(batch, 10), opt, dev)
-                barrier()
-                t = torch.tensor([(time.perf_counter() - t0) / 10], dtype=torch.float64, device=dev)
-                dist.all_reduce(t, op=dist.ReduceOp.MAX)
-                cal["overlapped" if mode else "single"] = round(t.item() * 1e3, 4)
-            exchange_mode = "overlapped" if cal["overlapped"] <= cal["single"] else "single"
-            opt.set_overlap(exchange_mode == "overlapped")
-            exchange_mode = {"mode": exchange_mode, "calibration_ms_per_step": cal}
+            cal = opt.calibrate_overlap(lambda n: run(wrapped, ListLoader(batch, n), opt, dev), steps=10, warm=3)
+            exchange_mode = {"mode": cal["mode"], "calibration_ms_per_step": cal["ms_per_step"]}
         run(wrapped, ListLoader(batch, spec["warmup"]), opt, dev)
         # The timed region carries NO per-step events: an event record between two steps is a barrier packet with a
         # timestamp and costs 2-7 us of idle front end per step (A/B on one box: 1.6514 / 1.6552 ms with, 1.6498 / 1.6482

@@ -146,6 +146,38 @@ class FlatAdamW(torch.optim.Optimizer):
         self._late_pending = self._early_pending = 0
         return self._overlap_active
 
+    def calibrate_overlap(self, run_steps, steps=10, warm=3):
+        """Pick the faster exchange form ON THIS NODE: `run_steps(n)` must run n complete train steps (forward,
+        backward, step()) with this optimizer.  Both forms are timed (wall clock around `steps` steps after `warm`
+        untimed ones, device synchronised); the decision is taken on the MAX over ranks, which the all-reduce makes
+        identical everywhere, so every rank ends up in the same mode.  Returns {"mode", "ms_per_step": {...}}.
+        A no-op ({"mode": "single"}) when there is nothing to choose (one rank, or overlap=False at construction)."""
+        import time
+        if not self._overlap:
+            return {"mode": "single", "ms_per_step": {}}
+        dist = torch.distributed
+        dev = self.flat_param.device
+        res = {}
+        for mode in (True, False):
+            self.set_overlap(mode)
+            run_steps(warm)
+            if dev.type == "cuda":
+                torch.cuda.synchronize(dev)
+            if dev.type == "cuda" and dist.get_backend(self.process_group) == "nccl":
+                dist.barrier(group=self.process_group, device_ids=[dev.index])
+            else:
+                dist.barrier(group=self.process_group)
+            t0 = time.perf_counter()
+            run_steps(steps)
+            if dev.type == "cuda":
+                torch.cuda.synchronize(dev)
+            t = torch.tensor([(time.perf_counter() - t0) / steps], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.process_group)
+            res["overlapped" if mode else "single"] = round(t.item() * 1e3, 4)
+        mode = "overlapped" if res["overlapped"] <= res["single"] else "single"
+        self.set_overlap(mode == "overlapped")
+        return {"mode": mode, "ms_per_step": res}
+
     def no_sync(self):
         """Context manager for gradient accumulation over several backward passes per step (as
         DistributedDataParallel.no_sync): inside it the hooked exchange is off and gradients only accumulate

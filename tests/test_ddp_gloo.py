@@ -173,9 +173,22 @@ def _worker_overlap(rank, world, port, out_dir):
     except RuntimeError as e:
         assert "in flight" in str(e)
     opt.reduce_gradients()
+    # calibrate_overlap: both forms timed on this "node", the same decision on every rank
+    def run_steps(n):
+        for _ in range(n):
+            opt.zero_grad()
+            torch.nn.functional.binary_cross_entropy_with_logits(model(*batch[:-1]), batch[-1]).backward()
+            opt.step()
+    cal = opt.calibrate_overlap(run_steps, steps=2, warm=1)
+    assert cal["mode"] in ("overlapped", "single") and set(cal["ms_per_step"]) == {"overlapped", "single"}
+    assert opt._overlap_active is (cal["mode"] == "overlapped")
+    flags = [torch.zeros(1) for _ in range(world)]
+    dist.all_gather(flags, torch.tensor([1.0 if cal["mode"] == "overlapped" else 0.0]))
+    assert flags[0].item() == flags[1].item()
     # overlap=False gives the same flat gradient through one collective
     opt2 = FlatAdamW(model.parameters(), lr=1e-4, overlap=False)
     assert not opt2._overlap and opt2.set_overlap(True) is False
+    assert opt2.calibrate_overlap(run_steps)["mode"] == "single"
     dist.barrier()
     dist.destroy_process_group()
 
