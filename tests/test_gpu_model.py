@@ -462,12 +462,22 @@ def test_legacy_concat_fusion_model_vs_stock_torch():
         np.testing.assert_allclose(a.grad.cpu().numpy(), b.grad.numpy(), atol=tol, err_msg=k)
 
 
-def test_short_training_run_reduces_loss():
-    """End-to-end sanity through the loop API: 25 AdamW steps on a fixed synthetic batch must fit it."""
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_short_training_run_reduces_loss(precision):
+    """End-to-end sanity through the loop API: 25 AdamW steps on a fixed synthetic batch must fit it — in fp32 and in
+    the opt-in bf16 mode (bf16 conv operands, bf16 storage of y / p / dp between the kernels), whose loss curve must
+    stay within 5 % of the fp32 one at every epoch."""
+    from ecg_hip import functional as hipF
     from ecg_hip.optim import FlatAdamW
     from src.models.ecg_multimodal import ECGMultimodal
     from src.training.loop_demo import eval_one_epoch_demo, train_one_epoch_demo
     from src.utils.seed import set_seed
+    if precision == "bf16":
+        ref = _short_run_losses("fp32")
+        got = _short_run_losses("bf16")
+        assert got[-1] < 0.6 * got[0], got
+        assert all(abs(a - b) <= 0.05 * b for a, b in zip(got, ref)), (got, ref)
+        return
     set_seed(0)
     model = ECGMultimodal().to(DEV)
     batch = tuple(t.to(DEV) for t in R.synthetic_batch(64, 1000, 5, demo=True))
@@ -483,6 +493,27 @@ def test_short_training_run_reduces_loss():
     assert losses[-1] < 0.6 * losses[0], losses
     out = eval_one_epoch_demo(model, Loader(), DEV)
     assert set(out) == {"auroc_macro", "auprc_macro", "f1_macro", "bce_loss"} and np.isfinite(out["bce_loss"])
+
+
+def _short_run_losses(precision):
+    from ecg_hip import functional as hipF
+    from ecg_hip.optim import FlatAdamW
+    from src.models.ecg_multimodal import ECGMultimodal
+    from src.training.loop_demo import train_one_epoch_demo
+    from src.utils.seed import set_seed
+    set_seed(0)
+    model = ECGMultimodal().to(DEV)
+    batch = tuple(t.to(DEV) for t in R.synthetic_batch(64, 1000, 5, demo=True))
+    opt = FlatAdamW(model.parameters(), lr=1e-3, weight_decay=1e-4)
+
+    class Loader:
+        dataset = range(64 * 5)
+
+        def __iter__(self):
+            return iter([batch] * 5)
+
+    with hipF.conv_precision(precision):
+        return [train_one_epoch_demo(model, Loader(), opt, DEV) for _ in range(5)]
 
 
 @pytest.mark.parametrize("act_bf16", [True, False])
