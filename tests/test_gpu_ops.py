@@ -849,6 +849,22 @@ def test_bf16_conv_on_bf16_activations_equals_the_fp32_io_kernels(hip, case):
     with pytest.raises(L.EcgHipError, match="even dx row stride"):
         L.call("ecg_conv1d_bwd_data_bf16hh", L.ptr(dyh), PA, L.ptr(wb_bwd), L.ptr(dxh), Lin | 1, N, Ci, Co, Lin, 15, 7,
                L.stream())
+    # host-side argument checks of the forward: odd row strides, an even pad with a bf16 x (positions are staged in
+    # aligned pairs), a missing statistics buffer
+    y = torch.zeros(N, Co, ldy, dtype=torch.bfloat16, device="cuda")
+    part = torch.empty(Co * P * 2, device="cuda")
+    with pytest.raises(L.EcgHipError, match="a bf16 x needs"):
+        L.call("ecg_conv1d_fwd_bf16_yh", L.ptr(xh), 1, ldx | 1, L.ptr(wb_fwd), L.f32(b), L.ptr(y), ldy, L.f32(part), N, Ci, Co,
+               Lin, 15, 7, L.stream())
+    with pytest.raises(L.EcgHipError, match="a bf16 x needs"):
+        L.call("ecg_conv1d_fwd_bf16_yh", L.ptr(xh), 1, ldx, L.ptr(wb_fwd), L.f32(b), L.ptr(y), ldy, L.f32(part), N, Ci, Co,
+               Lin, 15, 6, L.stream())
+    with pytest.raises(L.EcgHipError, match="even row stride"):
+        L.call("ecg_conv1d_fwd_bf16_yh", L.f32(xr), 0, 0, L.ptr(wb_fwd), L.f32(b), L.ptr(y), Lo | 1, L.f32(part), N, Ci, Co,
+               Lin, 15, 7, L.stream())
+    with pytest.raises(L.EcgHipError, match="null pointer"):
+        L.call("ecg_conv1d_fwd_bf16_yh", L.f32(xr), 0, 0, L.ptr(wb_fwd), L.f32(b), L.ptr(y), ldy, None, N, Ci, Co, Lin, 15, 7,
+               L.stream())
 
 
 @pytest.mark.parametrize("case", [(19, 12, 32, 300), (37, 64, 128, 125), (16, 32, 64, 64)])
