@@ -28,4 +28,12 @@ S="$R/tools/pmc_step.py"
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$O/pmc_fetch_$TAG" -- python3 $S --log "$O/pmc_fetch_$TAG.order.json" > /dev/null 2> "$O/pmc_fetch_$TAG.err" || exit 1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$O/pmc_write_$TAG" -- python3 $S --log "$O/pmc_write_$TAG.order.json" > /dev/null 2> "$O/pmc_write_$TAG.err" || exit 1
 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES --kernel-trace --output-format csv -d "$O/pmc_sq_$TAG" -- python3 $S --log "$O/pmc_sq_$TAG.order.json" > /dev/null 2> "$O/pmc_sq_$TAG.err" || exit 1
+# the same three passes for the other legs of the bench line: ECGMultimodal, and BASELINE configs[4] (12x5000) in fp32 and bf16 mode
+for V in "mm --model multimodal" "c5f32 --labels 1 --length 5000" "c5bf16 --labels 1 --length 5000 --dtype bf16"; do
+set -- $V; T=$1; shift
+rm -rf "$O/pmc_fetch_${TAG}_$T" "$O/pmc_write_${TAG}_$T" "$O/pmc_sq_${TAG}_$T"
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$O/pmc_fetch_${TAG}_$T" -- python3 $S "$@" --log "$O/pmc_fetch_${TAG}_$T.order.json" > /dev/null 2> "$O/pmc_fetch_${TAG}_$T.err" || exit 1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$O/pmc_write_${TAG}_$T" -- python3 $S "$@" --log "$O/pmc_write_${TAG}_$T.order.json" > /dev/null 2> "$O/pmc_write_${TAG}_$T.err" || exit 1
+rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES --kernel-trace --output-format csv -d "$O/pmc_sq_${TAG}_$T" -- python3 $S "$@" --log "$O/pmc_sq_${TAG}_$T.order.json" > /dev/null 2> "$O/pmc_sq_${TAG}_$T.err" || exit 1
+done
 echo "pmc done"

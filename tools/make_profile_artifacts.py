@@ -83,29 +83,36 @@ def main():
     open(os.path.join(PROF, f"{TAG}_kernel_stats_summary.txt"), "w").write(
         f"# rocprofv3 --kernel-trace --stats -- python3 bench.py --no-cpu-baseline --no-also --steps 20 --warmup 5 --priming 0  ({steps} steps incl. warm-up, the per-step-event repeat and the instrumented pass)\n" + summ)
 
-    fetch = per_entry(os.path.join(OUT, f"pmc_fetch_{TAG}"))
-    write = per_entry(os.path.join(OUT, f"pmc_write_{TAG}"))
-    sq = per_entry(os.path.join(OUT, f"pmc_sq_{TAG}"))
-    lines = ["# per entry point of one ECGCNN(5) B=256 12x1000 train step (tools/pmc_step.py; same keys as bench.py `layers`):",
+    lines = ["# per entry point of one B=256 train step (tools/pmc_step.py; same keys as bench.py `layers`):",
              "# launches per call, µs per call (under the counter pass), FETCH_SIZE / WRITE_SIZE in KiB as rocprofv3 reports them",
              "# (separate passes), hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024 (gfx950 FETCH_SIZE correction),",
              "# mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs * GRBM_GUI_ACTIVE / 8), clock = GRBM_GUI_ACTIVE / 8 / duration"]
     entries = {}
-    for key in fetch:
-        f = mean([s.get("FETCH_SIZE", 0.0) for s in fetch[key]])
-        w = mean([s.get("WRITE_SIZE", 0.0) for s in write[key]]) if key in write else float("nan")
-        hb = (2 * f + w) * 1024
-        entries[key] = int(hb)
-        us = mean([s["_ns"] for s in fetch[key]]) / 1e3
-        extra = ""
-        if key in sq and "mfma" in "".join(k for k in [key]) or ("conv1d" in key and key in sq):
-            cyc = mean([s.get("GRBM_GUI_ACTIVE", 0.0) for s in sq[key]]) / 8.0
-            busy = mean([s.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) for s in sq[key]])
-            d_us = mean([s["_ns"] for s in sq[key]]) / 1e3
-            if cyc > 0 and busy > 0:
-                extra = f" mfma_busy={busy / (1024 * cyc):.3f} clock_GHz={cyc / (d_us * 1e3):.3f}"
-        lines.append(f"{key:64s} launches={fetch[key][0]['_n']:2d} us={us:8.1f} FETCH_SIZE={f:10.1f} WRITE_SIZE={w:10.1f} "
-                     f"hbm_bytes={hb:12.0f}{extra}")
+    variants = [("", "ECGCNN(5), 12x1000, fp32 (the headline)"), ("_mm", "ECGMultimodal, 12x1000, fp32"),
+                ("_c5f32", "ECGCNN(1), 12x5000, fp32 (BASELINE configs[4])"),
+                ("_c5bf16", "ECGCNN(1), 12x5000, bf16 mode (BASELINE configs[4])")]
+    for suffix, title in variants:
+      if not os.path.exists(os.path.join(OUT, f"pmc_fetch_{TAG}{suffix}.order.json")):
+          continue
+      lines.append(f"## {title}")
+      fetch = per_entry(os.path.join(OUT, f"pmc_fetch_{TAG}{suffix}"))
+      write = per_entry(os.path.join(OUT, f"pmc_write_{TAG}{suffix}"))
+      sq = per_entry(os.path.join(OUT, f"pmc_sq_{TAG}{suffix}"))
+      for key in fetch:
+          f = mean([s.get("FETCH_SIZE", 0.0) for s in fetch[key]])
+          w = mean([s.get("WRITE_SIZE", 0.0) for s in write[key]]) if key in write else float("nan")
+          hb = (2 * f + w) * 1024
+          entries[key] = int(hb)
+          us = mean([s["_ns"] for s in fetch[key]]) / 1e3
+          extra = ""
+          if key in sq and "mfma" in "".join(k for k in [key]) or ("conv1d" in key and key in sq):
+              cyc = mean([s.get("GRBM_GUI_ACTIVE", 0.0) for s in sq[key]]) / 8.0
+              busy = mean([s.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) for s in sq[key]])
+              d_us = mean([s["_ns"] for s in sq[key]]) / 1e3
+              if cyc > 0 and busy > 0:
+                  extra = f" mfma_busy={busy / (1024 * cyc):.3f} clock_GHz={cyc / (d_us * 1e3):.3f}"
+          lines.append(f"{key:64s} launches={fetch[key][0]['_n']:2d} us={us:8.1f} FETCH_SIZE={f:10.1f} WRITE_SIZE={w:10.1f} "
+                       f"hbm_bytes={hb:12.0f}{extra}")
     open(os.path.join(PROF, f"{TAG}_pmc_summary.txt"), "w").write("\n".join(lines) + "\n")
 
     import bench
