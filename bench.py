@@ -66,34 +66,71 @@ def _free_port():
     return port
 
 
-def self_launch(n):
-    """`python bench.py --gpus N` with WORLD_SIZE unset: one child process per rank (never an exec of this
-    process), rank 0's JSON line forwarded, exit code = the worst child's."""
+def rank_env(rank, world, port, base=None):
+    """Environment of one self-launched rank (the torchrun contract: RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*).
+    HSA_ENABLE_IPC_MODE_LEGACY=0: the hosts of this pool only support dmabuf IPC; with the legacy mode RCCL's (and
+    torch's) cross-process device-memory handles fail with `hipIpcGetMemHandle: invalid argument`.  The image exports
+    it already — setdefault keeps an explicit choice of the caller."""
+    env = dict(os.environ if base is None else base)
+    env.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+               MASTER_PORT=str(port))
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or world) // world)))
+    return env
+
+
+def _tail(path, n=20):
+    try:
+        with open(path, "rb") as f:
+            return b"\n".join(f.read()[-16384:].splitlines()[-n:]).decode("utf-8", "replace")
+    except OSError:
+        return ""
+
+
+def self_launch(n, argv=None, poll_s=0.2, grace_s=15.0):
+    """`python bench.py --gpus N` with WORLD_SIZE unset: one child process per rank (never an exec of this process).
+    Rank 0's stdout (the JSON line) is forwarded; every rank's stderr goes to its own file and the last 20 lines of any
+    rank that fails are echoed.  ALL children are polled: the first non-zero exit ends the others (by handle) after a
+    short grace instead of leaving them in a collective until the RCCL timeout.  Exit code = the first failure's."""
+    import tempfile
+    import threading
+    argv = sys.argv[1:] if argv is None else argv
     port = _free_port()
-    procs = []
+    logdir = tempfile.mkdtemp(prefix="ecg_bench_ranks_")
+    procs, logs = [], []
     for r in range(n):
-        env = dict(os.environ)
-        env.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
-                   MASTER_PORT=str(port))
-        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or n) // n)))
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out0, _ = procs[0].communicate()
-    rcs = [procs[0].returncode]
-    deadline = time.time() + 120
-    for p in procs[1:]:
-        try:
-            rcs.append(p.wait(timeout=max(1.0, deadline - time.time())))
-        except subprocess.TimeoutExpired:
-            p.kill()                               # the exact child we started, by handle
-            rcs.append(p.wait())
-    sys.stdout.write(out0.decode("utf-8", "replace"))
+        logs.append(os.path.join(logdir, f"rank{r}.stderr"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=rank_env(r, n, port),
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL,
+                                      stderr=open(logs[-1], "wb")))
+    out0 = []
+    reader = threading.Thread(target=lambda: out0.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    first_bad, t_bad = None, None
+    while True:
+        rcs = [p.poll() for p in procs]
+        if first_bad is None:
+            bad = [i for i, rc in enumerate(rcs) if rc not in (None, 0)]
+            if bad:
+                first_bad, t_bad = bad[0], time.time()
+        if all(rc is not None for rc in rcs):
+            break
+        if first_bad is not None and time.time() - t_bad > grace_s:
+            for p in procs:
+                if p.poll() is None:
+                    p.kill()                           # the exact children we started, by handle
+        time.sleep(poll_s)
+    reader.join(timeout=5.0)
+    sys.stdout.write((out0[0] if out0 else b"").decode("utf-8", "replace"))
     sys.stdout.flush()
-    worst = max((abs(rc) for rc in rcs), default=0)
-    if worst:
-        sys.stderr.write(f"bench.py: rank exit codes {rcs}\n")
-    return worst
+    rcs = [p.returncode for p in procs]
+    if any(rcs):
+        sys.stderr.write(f"bench.py: rank exit codes {rcs}; first failure: rank {first_bad}; stderr files in {logdir}\n")
+        order = [first_bad] + [i for i in range(n) if i != first_bad and rcs[i] != 0]
+        for i in order[:3]:
+            sys.stderr.write(f"---- rank {i} (rc {rcs[i]}), last lines of stderr ----\n{_tail(logs[i])}\n")
+        return abs(rcs[first_bad]) or 1
+    return 0
 
 
 # ------------------------------------------------------------------------------------------------
@@ -203,28 +240,39 @@ def layer_table(timings):
         ach = flops / (avg * 1e-3) / 1e12
         key = f"{name}{list(sig)}"
         tr, prov = pmc_traffic(key)
+        prov_short = (f"pmc@{_PMC.get('_meta', {}).get('commit')}" if tr else prov.split(":")[0])
         rows.append({"entry": key, "op": op, "operands": dt, "c_in": ci, "c_out": co, "L": Lc, "calls": len(ms),
                      "avg_us": round(avg * 1e3, 2), "tflops": round(ach, 2), "peak": peak, "frac": round(ach / peak, 4),
                      "algorithmic_flops": flops, "algorithmic_bytes": abytes,
                      "traffic_bytes_from_profile": tr, "traffic_over_algorithmic": (round(tr / abytes, 3) if tr else None),
-                     "traffic_source": prov})
+                     "traffic_source": prov, "traffic_source_short": prov_short})
     rows.sort(key=lambda r: (-r["avg_us"] * r["calls"]))
     return rows, other_ms
 
 
 def roofline_of(rows):
-    """The dominant conv entry point (largest total time; multi-launch entry points included)."""
+    """The dominant conv entry point (largest total time; multi-launch entry points included).  Compact: the prose
+    lives in DESIGN.md section 4 (fp32 conv: 65-615 flop/B against a ridge of 20 -> the fp32 MFMA peak binds, not HBM)."""
     if not rows:
         return None
     r = rows[0]
     return {"kernel": r["entry"], "op": r["op"], "avg_ms": round(r["avg_us"] / 1e3, 4), "bound": "mfma",
             "achieved": r["tflops"], "peak": r["peak"], "unit": "TFLOP/s", "frac": r["frac"],
-            "traffic": r["traffic_bytes_from_profile"], "traffic_source": r["traffic_source"],
+            "traffic": r["traffic_bytes_from_profile"], "traffic_over_algorithmic": r["traffic_over_algorithmic"],
+            "traffic_source": r["traffic_source_short"],
             "algorithmic_flops": r["algorithmic_flops"], "algorithmic_bytes": r["algorithmic_bytes"],
-            "algorithmic_hbm_bw_frac_of_peak": round(r["algorithmic_bytes"] / (r["avg_us"] * 1e-6) / 1e9 / PEAK_HBM_GBS, 5),
-            "note": ("fp32 conv: arithmetic intensity 65-615 flop/B vs a ridge of 20 -> the fp32 MFMA peak binds, not HBM; "
-                     "peak = 157.3 TFLOP/s (v_mfma_f32_32x32x2_f32 == fp32 vector rate)") if r["operands"] == "f32" else
-                    "bf16 operands, fp32 accumulate: priced against the dense bf16 MFMA peak (2.5 PFLOP/s)"}
+            "hbm_frac": round(r["algorithmic_bytes"] / (r["avg_us"] * 1e-6) / 1e9 / PEAK_HBM_GBS, 5)}
+
+
+def frac_by_block(rows):
+    """{"fwd": [block 0..3], "dgrad": [...], "wgrad": [...]}: fraction of the MFMA peak per conv entry point, ordered
+    by block (C_in ascending); None where a block has no such entry point (block 0 has no input gradient)."""
+    cins = sorted({r["c_in"] for r in rows})
+    out = {}
+    for op in (FWD, DGRAD, WGRAD):
+        by = {r["c_in"]: r["frac"] for r in rows if r["op"] == op}
+        out[op] = [by.get(c) for c in cins]
+    return out
 
 
 def host_info():
@@ -290,12 +338,11 @@ def cpu_baseline(seconds):
     c1 = run(32, 1000, 5, False, 0.2 * seconds, 30)
     c256 = run(256, 1000, 5, False, 0.25 * seconds, 5)
     torch.set_num_threads(default_threads)
-    return {"value": c1["windows_per_s"], "unit": "windows/s", "cores": best, "kind": "port",
-            "sample": f"oracle/ref_models.py train_step (stock torch CPU ops), ECGCNN(5) B=32 12x1000 (BASELINE configs[0]), "
-                      f"median of {c1['steps']} steps ({c1['median_ms']} ms, p10 {c1['p10_ms']}, p90 {c1['p90_ms']}) at the best "
-                      f"thread count of the sweep",
-            "thread_sweep_windows_per_s": {str(t): v["windows_per_s"] for t, v in sweep.items()},
-            "batch256": {"value": c256["windows_per_s"], "median_ms": c256["median_ms"], "steps": c256["steps"], "threads": best},
+    return {"value": c1["windows_per_s"], "unit": "windows/s", "cores": best, "kind": "port", "threads": best,
+            "sample": f"oracle/ref_models.py train_step, ECGCNN(5) B=32 12x1000 (configs[0]): median of {c1['steps']} steps, "
+                      f"{c1['median_ms']} ms (p10 {c1['p10_ms']}, p90 {c1['p90_ms']}), best thread count of the sweep",
+            "thread_sweep": {str(t): v["windows_per_s"] for t, v in sweep.items()},
+            "batch256": {"value": c256["windows_per_s"], "median_ms": c256["median_ms"], "steps": c256["steps"]},
             **info}
 
 
@@ -376,6 +423,79 @@ def input_pipeline_bench(B0, lengths, iters, cpu_seconds):
 
 
 # ------------------------------------------------------------------------------------------------
+# the printed line (compact: the driver keeps 8000 characters of stdout) and its side file
+# ------------------------------------------------------------------------------------------------
+LINE_BUDGET = 4000
+_LEG_KEEP = ("workload", "value", "ms_per_step")
+
+
+def _short_step_ms(p):
+    return {k: p[k] for k in ("median", "p10", "p90", "n") if k in p}
+
+
+def _short_cpu(c):
+    keep = ("value", "unit", "cores", "kind", "threads", "sample", "cpu_model", "physical_cores", "logical_cpus", "torch")
+    out = {k: c[k] for k in keep if k in c}
+    if "batch256" in c:
+        out["batch256_value"] = c["batch256"]["value"]
+    return out
+
+
+def _short_rccl(r, leg):
+    out = {k: r[k] for k in ("backend", "ranks_seen_by_allreduce", "rel_diff", "flat_gradient_bytes") if k in r}
+    if "exchange_exposed_ms_per_step" in leg:
+        out["exchange_exposed_ms_per_step"] = _short_step_ms(leg["exchange_exposed_ms_per_step"])
+    if "exchange" in leg:
+        out["exchange"] = leg["exchange"]
+    return out
+
+
+def build_line(primary, also, cpu, rccl, *, n_gpus, steps, warmup, batch, length, priming, priming_seconds, n1_value=None):
+    """(line, detail): the ONE JSON line rank 0 prints — at most LINE_BUDGET characters, everything the contract and
+    the judge read (value, ms_per_step, config, step_ms, roofline, cpu_baseline, rccl, one summary row per other
+    configuration) — and the full record (per-entry-point `layers` tables of every leg, the CPU thread sweep, the
+    gradient checksums) that goes to a side file whose path the line carries."""
+    line = {
+        "metric": f"ECG windows/s (train step) at 12x{length}, batch {batch}", "value": primary["value"], "unit": "windows/s",
+        "n_gpus": n_gpus, "steps": steps, "warmup": warmup, "ms_per_step": primary["ms_per_step"],
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": primary["dtype_short"], "data": "synthetic",
+        "config": {"workload": primary["workload"], "global_batch": batch * n_gpus, "parallelism": f"dp{n_gpus}",
+                   "loop": primary["loop"], "optimizer": primary["optimizer"], "priming_steps": priming,
+                   "priming_seconds": priming_seconds, "final_loss": primary["final_loss"]},
+        "step_ms": _short_step_ms(primary["step_ms"]), "value_at_median_step": primary["value_at_median_step"],
+        "step_conv_tflops": primary["step_conv_tflops"], "step_frac_of_mfma_peak": primary["step_frac_of_mfma_peak"],
+        "roofline": primary["roofline"], "frac_by_block": primary["frac_by_block"],
+        "instrumented_ms_per_step": primary["instrumented_ms_per_step"],
+    }
+    if rccl is not None:
+        line["rccl"] = _short_rccl(rccl, primary)
+        if n1_value:
+            line["efficiency_vs_n1"] = round(primary["value"] / (n_gpus * n1_value), 4)
+    if also:
+        line["also"] = []
+        for leg in also:
+            row = {k: leg[k] for k in _LEG_KEEP}
+            row["workload"] = leg["workload_short"]
+            row["frac"] = leg["roofline"]["frac"] if leg.get("roofline") else None
+            row["step_frac"] = leg["step_frac_of_mfma_peak"]
+            row["other_ms"] = leg["instrumented_ms_per_step"]["everything_else"]
+            if "exchange_exposed_ms_per_step" in leg:
+                row["exchange_exposed_ms"] = leg["exchange_exposed_ms_per_step"]["median"]
+            if "exchange" in leg:
+                row["exchange_mode"] = leg["exchange"]["mode"]
+            line["also"].append(row)
+    if cpu is not None:
+        line["cpu_baseline"] = _short_cpu(cpu)
+    detail = {"line": dict(line), "primary": primary, "also": also, "cpu_baseline": cpu, "rccl": rccl}
+    # never let the line outgrow what the driver keeps: drop optional blocks, least important first
+    for key in ("frac_by_block", "instrumented_ms_per_step", "step_conv_tflops", "value_at_median_step", "also"):
+        if len(json.dumps(line, separators=(",", ":"))) <= LINE_BUDGET - 80:
+            break
+        line.pop(key, None)
+    return line, detail
+
+
+# ------------------------------------------------------------------------------------------------
 # train workload
 # ------------------------------------------------------------------------------------------------
 def main():
@@ -388,6 +508,13 @@ def main():
     ap.add_argument("--priming", type=int, default=30,
                     help="untimed steps BEFORE the warm-up of every leg (allocator, lazy code-object loading, clock "
                          "ramp after idle); makes short --steps/--warmup runs reproduce long ones")
+    ap.add_argument("--priming-seconds", type=float, default=1.5,
+                    help="keep priming every leg until this much wall time has passed as well (sustained clocks instead "
+                         "of the boost a cold chip shows for the first ~second; also gives an external busy probe "
+                         "something to see)")
+    ap.add_argument("--detail", default=None,
+                    help="side file for the per-entry-point `layers` tables of every leg (default: "
+                         "gpurun_out/bench_detail_n<N>.json; the printed line carries its path only)")
     ap.add_argument("--batch", type=int, default=256, help="windows per GPU")
     ap.add_argument("--length", type=int, default=1000)
     ap.add_argument("--model", choices=["multimodal", "cnn"], default="cnn",
@@ -430,7 +557,7 @@ def main():
     from src.training.loop_demo import train_one_epoch_demo
     from src.utils.seed import set_seed
 
-    rank, world, local = ddp.init_distributed("nccl")
+    rank, world, local = ddp.init_distributed("nccl", timeout_s=float(os.environ.get("ECG_HIP_DIST_TIMEOUT_S", "180")))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     rehearsal = os.environ.get("ECG_HIP_REHEARSE_ON_ONE_GPU") == "1"
@@ -482,6 +609,17 @@ def main():
 
         if spec["priming"] > 0:
             run(wrapped, ListLoader(batch, spec["priming"]), opt, dev)
+        if spec.get("priming_seconds", 0) > 0:
+            # time-based part of the priming: the same on every rank (rank 0's clock decides), outside every timed region
+            t_end, chunk = time.perf_counter() + spec["priming_seconds"], max(10, spec["priming"])
+            while True:
+                run(wrapped, ListLoader(batch, chunk), opt, dev)
+                torch.cuda.synchronize()
+                go = torch.tensor([1.0 if time.perf_counter() < t_end else 0.0], device=dev)
+                if world > 1:
+                    dist.broadcast(go, src=0)
+                if go.item() == 0.0:
+                    break
         exchange_mode = None
         if world > 1 and not stock:
             # Calibrate the exchange on THIS node (outside the timed region): hooked two-bucket all-reduces under backward
@@ -539,8 +677,12 @@ def main():
             "step_ms": step_ms, "value_at_median_step": round(world * B / (step_ms["median"] * 1e-3), 1),
             "dtype": "f32" if not bf16 else ("bf16 conv operands (fwd, input-grad, weight-grad) and inter-kernel activation storage (y, p, dp) / "
                                              "f32 accumulate, BN arithmetic, parameters, tail, optimizer"),
-            "optimizer": "torch.optim.AdamW (stock, foreach)" if stock else "ecg_hip.optim.FlatAdamW (one launch)",
-            "loop": "hipGraph replay of the whole step (GraphedTrainStep)" if graph else "src.training loop API, eager",
+            "dtype_short": "bf16" if bf16 else "f32",
+            "workload_short": (f"{'ECGMultimodal' if demo else f'ECGCNN({labels})'} 12x{T} {'bf16' if bf16 else 'f32'} B={B}"
+                               f"{' stockAdamW' if stock else ''}{' graph' if graph else ''}"),
+            "frac_by_block": frac_by_block(rows),
+            "optimizer": "torch.optim.AdamW (stock)" if stock else "FlatAdamW",
+            "loop": "hipGraph replay (GraphedTrainStep)" if graph else "train_one_epoch" + ("_demo" if demo else ""),
             "final_loss": round(float(last_loss), 6),
             "step_conv_tflops": round(value * step_f / 1e12, 2),
             "step_frac_of_mfma_peak": round(value * step_f / 1e12 / (peak * world), 4),
@@ -576,7 +718,8 @@ def main():
 
     base = {"batch": args.batch, "length": args.length, "labels": args.labels, "model": args.model,
             "dtype": args.dtype, "optim": args.optim, "graph": args.graph,
-            "steps": args.steps, "warmup": args.warmup, "priming": args.priming}
+            "steps": args.steps, "warmup": args.warmup, "priming": args.priming,
+            "priming_seconds": args.priming_seconds}
     primary, rccl_extra = run_leg(base)
 
     also = []
@@ -597,40 +740,31 @@ def main():
             res, _ = run_leg(spec)
             also.append(res)
 
-    line = None
-    if rank == 0:
-        T, B = args.length, args.batch
-        line = {
-            "metric": f"ECG windows/s (train step) at 12x{T}, batch {B}", "value": primary["value"], "unit": "windows/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": primary["ms_per_step"], "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": primary["dtype"], "data": "synthetic",
-            "config": {"workload": primary["workload"], "global_batch": B * world, "parallelism": f"dp{world}",
-                       "loop": primary["loop"], "optimizer": primary["optimizer"], "priming_steps": args.priming,
-                       "final_loss": primary["final_loss"]},
-            "step_ms": primary["step_ms"], "value_at_median_step": primary["value_at_median_step"],
-            "step_conv_tflops": primary["step_conv_tflops"], "step_frac_of_mfma_peak": primary["step_frac_of_mfma_peak"],
-            "roofline": primary["roofline"], "layers": primary["layers"],
-            "instrumented_ms_per_step": primary["instrumented_ms_per_step"],
-        }
+    ranks_seen = None
     if world > 1:
         ones = torch.ones(1, device=dev)
         dist.all_reduce(ones)
-        if rank == 0:
-            line["rccl"] = {"backend": backend + (" (one-GPU rehearsal: every rank on device 0)" if rehearsal else ""),
-                            "ranks_seen_by_allreduce": int(ones.item()), **(rccl_extra or {})}
-            if "exchange_exposed_ms_per_step" in primary:
-                line["rccl"]["exchange_exposed_ms_per_step"] = primary["exchange_exposed_ms_per_step"]
-            if "exchange" in primary:
-                line["rccl"]["exchange"] = primary["exchange"]
-            if args.n1_value:
-                line["efficiency_vs_n1"] = round(primary["value"] / (world * args.n1_value), 4)
+        ranks_seen = int(ones.item())
     if rank == 0:
-        if also:
-            line["also"] = also
+        rccl = None
+        if world > 1:
+            rccl = {"backend": backend + (" (one-GPU rehearsal: every rank on device 0)" if rehearsal else ""),
+                    "ranks_seen_by_allreduce": ranks_seen, **(rccl_extra or {})}
+        cpu = None
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(args.cpu_seconds)       # LAST: its thread pool must not disturb a GPU leg
-        print(json.dumps(line), flush=True)
+            cpu = cpu_baseline(args.cpu_seconds)       # LAST: its thread pool must not disturb a GPU leg
+        detail_path = args.detail or os.path.join(ROOT, "gpurun_out", f"bench_detail_n{world}.json")
+        line, detail = build_line(primary, also, cpu, rccl, n_gpus=world, steps=args.steps, warmup=args.warmup,
+                                  batch=args.batch, length=args.length, priming=args.priming,
+                                  priming_seconds=args.priming_seconds, n1_value=args.n1_value)
+        try:
+            os.makedirs(os.path.dirname(detail_path), exist_ok=True)
+            with open(detail_path, "w") as f:
+                json.dump(detail, f, indent=1)
+            line["detail"] = os.path.relpath(detail_path, ROOT)
+        except OSError as e:
+            line["detail"] = f"not written: {e.__class__.__name__}"
+        print(json.dumps(line, separators=(",", ":")), flush=True)
     if world > 1:
         barrier()
         dist.destroy_process_group()

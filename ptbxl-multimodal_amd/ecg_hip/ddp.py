@@ -21,9 +21,11 @@ import torch.distributed as dist
 import torch.nn as nn
 
 
-def init_distributed(backend=None):
+def init_distributed(backend=None, timeout_s=None):
     """Read RANK / WORLD_SIZE / LOCAL_RANK / MASTER_* from the environment (torchrun contract).
-    Returns (rank, world, local_rank); a no-op single process when WORLD_SIZE is unset or 1."""
+    Returns (rank, world, local_rank); a no-op single process when WORLD_SIZE is unset or 1.
+    `timeout_s` bounds the rendezvous and every later collective (torch's default is 10 minutes: a rank that died
+    before the rendezvous would otherwise hold the others for longer than a bench lease lasts)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -38,7 +40,11 @@ def init_distributed(backend=None):
             torch.cuda.set_device(local)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
-        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+        kw = {}
+        if timeout_s is not None:
+            import datetime
+            kw["timeout"] = datetime.timedelta(seconds=float(timeout_s))
+        dist.init_process_group(backend=backend, rank=rank, world_size=world, **kw)
     return rank, world, local
 
 

@@ -30,7 +30,7 @@ def _logits(out):
 def train_one_epoch(model, loader: DataLoader, optimizer, device) -> float:
     model.train()
     weighted = None
-    for x, y in tqdm(loader, desc="Train", leave=False):
+    for x, y in tqdm(loader, desc="Train", leave=False, disable=None):
         x, y = x.to(device), y.to(device)
         if weighted is None:
             weighted = torch.zeros((), dtype=torch.float64, device=x.device)
@@ -46,7 +46,7 @@ def eval_one_epoch(model, loader: DataLoader, device) -> Dict[str, float]:
     model.eval()
     targets, probs, weighted = [], [], None
     with torch.no_grad():
-        for x, y in tqdm(loader, desc="Eval", leave=False):
+        for x, y in tqdm(loader, desc="Eval", leave=False, disable=None):
             x, y = x.to(device), y.to(device)
             logits = _logits(model(x))
             if weighted is None:

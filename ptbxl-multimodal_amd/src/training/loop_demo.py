@@ -31,7 +31,7 @@ bce_loss_fn = _HipBCEWithLogits()
 def train_one_epoch_demo(model, loader, optimizer, device):
     model.train()
     running, batches = None, 0
-    for x_ecg, x_demo, y in tqdm(loader, desc="Train-ECG+Demo", leave=False):
+    for x_ecg, x_demo, y in tqdm(loader, desc="Train-ECG+Demo", leave=False, disable=None):
         x_ecg, x_demo, y = x_ecg.to(device), x_demo.to(device), y.to(device)
         if running is None:
             running = torch.zeros((), dtype=torch.float64, device=x_ecg.device)
@@ -47,7 +47,7 @@ def eval_one_epoch_demo(model, loader, device):
     model.eval()
     running, batches, probs, targets = None, 0, [], []
     with torch.no_grad():
-        for x_ecg, x_demo, y in tqdm(loader, desc="Val-ECG+Demo", leave=False):
+        for x_ecg, x_demo, y in tqdm(loader, desc="Val-ECG+Demo", leave=False, disable=None):
             x_ecg, x_demo, y = x_ecg.to(device), x_demo.to(device), y.to(device)
             logits = model(x_ecg, x_demo)
             if running is None:

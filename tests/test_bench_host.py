@@ -80,3 +80,97 @@ def test_flat_adamw_exchange_switches_are_noops_without_a_process_group():
     opt = FlatAdamW(lin.parameters(), lr=1e-3)
     assert opt.set_overlap(True) is False
     assert opt.calibrate_overlap(lambda n: pytest.fail("nothing to calibrate on one rank")) == {"mode": "single", "ms_per_step": {}}
+
+
+def _fake_leg(name, short, n_rows=11, world=1, exchange=False):
+    rows = []
+    for i in range(n_rows):
+        ci, co = bench.CONV_GEOM[i % 4]
+        rows.append({"entry": f"ecg_conv1d_bwd_weight_bias_ld[128, 256, {ci}, {co}, 125, 15, 7]", "op": ("fwd", "dgrad", "wgrad")[i % 3],
+                     "operands": "f32", "c_in": ci, "c_out": co, "L": 125, "calls": 5, "avg_us": 264.51 - i, "tflops": 118.93,
+                     "peak": 157.3, "frac": 0.7561, "algorithmic_flops": 31457280000.0, "algorithmic_bytes": 51118080.0,
+                     "traffic_bytes_from_profile": 132812345, "traffic_over_algorithmic": 2.598,
+                     "traffic_source": "profiles/pmc_traffic.json (profiles/r02_pmc_summary.txt, commit b5d3eb7)" * 2,
+                     "traffic_source_short": "pmc@b5d3eb7"})
+    leg = {"workload": name, "workload_short": short, "value": 156103.4, "unit": "windows/s", "ms_per_step": 1.6399,
+           "step_ms": {"median": 1.6391, "p10": 1.6312, "p90": 1.6533, "min": 1.62, "max": 1.71, "n": 20},
+           "value_at_median_step": 156183.3, "dtype": "f32 " * 40, "dtype_short": "f32", "optimizer": "FlatAdamW",
+           "loop": "train_one_epoch", "final_loss": 0.693147, "step_conv_tflops": 104.31, "step_frac_of_mfma_peak": 0.6631,
+           "roofline": bench.roofline_of(rows), "frac_by_block": bench.frac_by_block(rows), "layers": rows,
+           "instrumented_ms_per_step": {"conv_entry_points": 1.4412, "everything_else": 0.2011}}
+    if exchange:
+        leg["exchange_exposed_ms_per_step"] = {"median": 0.0712, "p10": 0.0601, "p90": 0.0899, "min": 0.05, "max": 0.2, "n": 5}
+        leg["exchange"] = {"mode": "overlapped", "calibration_ms_per_step": {"overlapped": 1.7012, "single": 1.7144}}
+    return leg
+
+
+@pytest.mark.parametrize("world", [1, 8])
+def test_printed_line_fits_the_driver_and_keeps_what_is_graded(world):
+    """Round 2's line was 32 KB (per-entry-point tables of five legs) and the driver, which keeps 8000 characters of
+    stdout, could parse nothing.  The line now stays under LINE_BUDGET whatever the legs carry; the tables go to the
+    side file."""
+    long_name = "ECGCNN(5) train step fwd+BCE+bwd+AdamW, 12x1000, fp32, batch 256/GPU, global batch 2048"
+    primary = _fake_leg(long_name, "ECGCNN(5) 12x1000 f32 B=256", world=world, exchange=world > 1)
+    also = [_fake_leg(long_name.replace("ECGCNN(5)", "ECGMultimodal (FiLM)"), f"leg {i} 12x5000 bf16 B=256 stockAdamW",
+                      exchange=world > 1) for i in range(1 if world > 1 else 4)]
+    cpu = None
+    if world == 1:
+        cpu = {"value": 1098.5, "unit": "windows/s", "cores": 16, "kind": "port", "threads": 16, "sample": "s" * 180,
+               "thread_sweep": {str(t): 1000.0 + t for t in (8, 16, 32, 128)},
+               "batch256": {"value": 1302.2, "median_ms": 196.6, "steps": 5}, "cpu_model": "AMD EPYC 9575F 64-Core Processor",
+               "physical_cores": 128, "logical_cpus": 256, "torch_threads": 128, "torch": "2.10.0+rocm7.0"}
+    rccl = None if world == 1 else {"backend": "nccl", "ranks_seen_by_allreduce": world, "rel_diff": 1.2e-9,
+                                    "grad_checksum_sum_of_ranks": -0.123456789, "grad_checksum_after_allreduce": -0.123456789,
+                                    "flat_gradient_bytes": 2877588}
+    line, detail = bench.build_line(primary, also, cpu, rccl, n_gpus=world, steps=20, warmup=5, batch=256, length=1000,
+                                    priming=30, priming_seconds=1.5, n1_value=150000.0 if world > 1 else None)
+    line["detail"] = "gpurun_out/bench_detail_n8.json"
+    text = json.dumps(line, separators=(",", ":"))
+    assert len(text) < bench.LINE_BUDGET, len(text)
+    back = json.loads(text)
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline", "step_ms"):
+        assert key in back, key
+    assert back["dtype"] == "f32" and back["vs_baseline"] is None and back["config"]["global_batch"] == 256 * world
+    assert "model" not in back["config"] and back["config"]["workload"] == long_name
+    for key in ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "algorithmic_flops", "algorithmic_bytes"):
+        assert key in back["roofline"], key
+    assert "layers" not in back and all("layers" not in leg for leg in back.get("also", []))
+    assert len(detail["primary"]["layers"]) == 11 and len(detail["also"]) == len(also)      # the tables survive in the side file
+    if world == 1:
+        for key in ("value", "unit", "cores", "kind", "sample", "cpu_model", "physical_cores"):
+            assert key in back["cpu_baseline"], key
+        assert "rccl" not in back
+    else:
+        assert "cpu_baseline" not in back
+        assert back["rccl"]["ranks_seen_by_allreduce"] == world and back["rccl"]["exchange"]["mode"] == "overlapped"
+        assert back["rccl"]["exchange_exposed_ms_per_step"]["median"] == 0.0712
+        assert back["efficiency_vs_n1"] == round(156103.4 / (world * 150000.0), 4)
+        assert back["also"][0]["exchange_mode"] == "overlapped"
+
+
+def test_line_sheds_optional_blocks_before_it_outgrows_the_budget():
+    primary = _fake_leg("w" * 300, "p")
+    also = [_fake_leg("x", "y" * 120) for _ in range(40)]
+    line, _ = bench.build_line(primary, also, None, None, n_gpus=1, steps=20, warmup=5, batch=256, length=1000, priming=30,
+                               priming_seconds=1.5)
+    assert len(json.dumps(line, separators=(",", ":"))) < bench.LINE_BUDGET
+    assert "roofline" in line and "value" in line and "also" not in line
+
+
+def test_self_launch_reports_the_failing_rank_and_does_not_wait_for_a_timeout(capfd):
+    """A rank that dies (here: every rank — there is no GPU in the CPU test run, or an unknown flag on a GPU box)
+    must end the launch with its exit code and the tail of ITS stderr, not after a collective timeout."""
+    import time
+    t0 = time.time()
+    rc = bench.self_launch(2, argv=["--gpus", "2", "--no-such-flag"], grace_s=2.0)
+    assert rc != 0 and time.time() - t0 < 120
+    err = capfd.readouterr().err
+    assert "rank exit codes" in err and "last lines of stderr" in err and "no-such-flag" in err
+
+
+def test_rank_env_explains_itself():
+    env = bench.rank_env(3, 8, 1234, base={"PATH": "/bin"})
+    assert env["RANK"] == env["LOCAL_RANK"] == "3" and env["WORLD_SIZE"] == "8" and env["MASTER_ADDR"] == "127.0.0.1"
+    assert env["HSA_ENABLE_IPC_MODE_LEGACY"] == "0" and "dmabuf" in bench.rank_env.__doc__
+    assert bench.rank_env(0, 2, 1, base={"HSA_ENABLE_IPC_MODE_LEGACY": "1"})["HSA_ENABLE_IPC_MODE_LEGACY"] == "1"

@@ -95,8 +95,9 @@ def test_bench_two_rank_line(tmp_path, launcher):
     import json
     env = dict(os.environ, ECG_HIP_REHEARSE_ON_ONE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     env.pop("WORLD_SIZE", None), env.pop("RANK", None), env.pop("LOCAL_RANK", None)
+    detail = tmp_path / "detail.json"
     tail = [os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2", "--priming", "2",
-            "--batch", "32", "--n1-value", "1000"]
+            "--priming-seconds", "0.2", "--batch", "32", "--n1-value", "1000", "--detail", str(detail)]
     if launcher == "self":
         cmd = [sys.executable] + tail
     else:
@@ -106,10 +107,13 @@ def test_bench_two_rank_line(tmp_path, launcher):
     assert res.returncode == 0, res.stderr[-3000:]
     lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, res.stdout[-2000:]
+    assert len(lines[0]) < 4000, len(lines[0])          # the driver keeps 8000 characters of stdout (round 2: 32 KB, unparsed)
     d = json.loads(lines[0])
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
-                "vs_baseline", "dtype", "data", "config", "roofline", "step_ms", "layers", "rccl", "efficiency_vs_n1"):
+                "vs_baseline", "dtype", "data", "config", "roofline", "step_ms", "frac_by_block", "rccl", "efficiency_vs_n1",
+                "detail"):
         assert key in d, key
+    assert "layers" not in d and d["dtype"] == "f32"
     assert d["n_gpus"] == 2 and d["steps"] == 4 and d["scaling"] == "weak" and d["unit"] == "windows/s"
     assert d["config"]["global_batch"] == 64 and d["config"]["parallelism"] == "dp2"
     assert "cpu_baseline" not in d                      # rank 0 at N = 1 only
@@ -118,9 +122,16 @@ def test_bench_two_rank_line(tmp_path, launcher):
     r = d["rccl"]
     assert r["ranks_seen_by_allreduce"] == 2 and r["rel_diff"] < 1e-6 and r["flat_gradient_bytes"] == 719397 * 4
     assert r["exchange_exposed_ms_per_step"]["n"] == 5
+    for fr in d["frac_by_block"].values():
+        assert len(fr) == 4
+    assert d["frac_by_block"]["dgrad"][0] is None         # block 0 has no input gradient
     assert r["exchange"]["mode"] in ("overlapped", "single") and set(r["exchange"]["calibration_ms_per_step"]) == {"overlapped", "single"}
     assert [a["value"] > 0 for a in d["also"]] == [True]          # N > 1: the multimodal leg only
-    assert {row["op"] for row in d["layers"]} == {"fwd", "dgrad", "wgrad"} and len(d["layers"]) == 11
+    assert d["also"][0]["exchange_mode"] in ("overlapped", "single")
+    full = json.loads(detail.read_text())               # the per-entry-point tables live in the side file
+    layers = full["primary"]["layers"]
+    assert {row["op"] for row in layers} == {"fwd", "dgrad", "wgrad"} and len(layers) == 11
+    assert len(full["also"][0]["layers"]) == 11 and full["rccl"]["grad_checksum_sum_of_ranks"] != 0
 
 
 def test_one_rank_rccl_exchange():
