@@ -50,7 +50,9 @@ def _grad_out(key, ref, *shape):
     a tensor nobody else holds) or a new tensor.  A sink is handed out AT MOST ONCE per backward pass: a
     parameter used twice in one graph (model called twice before backward(), shared weights) gets a private
     tensor for its second gradient, which autograd then adds to the first — two kernels writing the same
-    sink would leave 2*dw2 instead of dw1 + dw2.  The set is cleared by an engine callback when the pass ends."""
+    sink would leave 2*dw2 instead of dw1 + dw2.  The set is cleared by an engine callback when the pass ends — and,
+    because the engine runs no callbacks for a backward pass that RAISED, again whenever a new step begins
+    (backward_from_loss, FlatAdamW.zero_grad / step): one failed backward must not disable the sinks for good."""
     ent = _grad_sinks.get(key) if key is not None else None
     if ent is not None and key not in _sinks_handed:
         p, v = ent[0](), ent[1]
@@ -401,6 +403,13 @@ class ConvBlockFn(torch.autograd.Function):
         if (ldyh and PX and len(next_geom) >= 4 and next_geom[3]
                 and _bf16_chain_ok(Co, next_geom[2], next_geom[0], next_geom[1], Lo // 2)):
             ldp = (Lo // 2 + 7) & ~7
+        if x_h and not ldyh:
+            # the producer wrote p as bf16 because THIS block looked able to read it (_bf16_chain_ok), but the bf16-y
+            # forward is not taken here (the block after this one is not a K=15/pad=7 conv, or activation storage was
+            # switched off between the two calls): the fp32 kernels below cannot read a bf16 x
+            raise L.EcgHipError("ConvBlock: input arrived as a bf16 activation but this block does not take the bf16-"
+                                "storage forward (next block's geometry, or set_bf16_activation_storage() changed "
+                                "between blocks); run the chain with activation storage off")
         if ldyh:
             y = torch.empty(N, Co, ldyh, dtype=torch.bfloat16, device=x.device)
             P = _query("ecg_conv1d_fwd_bf16_stat_partials", N, Ci, Co, Lin, K, pad)
@@ -728,6 +737,7 @@ def backward_from_loss(loss):
     one = _unit_grads.get(loss.device)
     if one is None:
         one = _unit_grads[loss.device] = torch.ones((), dtype=loss.dtype, device=loss.device)
+    _sinks_handed.clear()                  # left over only if an earlier backward pass raised (no engine callback then)
     loss.backward(one)
 
 

@@ -265,8 +265,21 @@ class FlatAdamW(torch.optim.Optimizer):
             return g, 1.0 / self.world_size
         return g, 1.0
 
+    def zero_grad(self, set_to_none=True):
+        self._forget_handed_sinks()
+        return super().zero_grad(set_to_none=set_to_none)
+
+    def _forget_handed_sinks(self):
+        """A backward pass that raised leaves functional._sinks_handed non-empty (the autograd engine runs no
+        end-of-pass callbacks then) and every later pass would get private gradient tensors instead of the flat-buffer
+        sinks, silently.  A new step starts from a clean slate."""
+        if self._sink_keys:
+            from . import functional as F
+            F._sinks_handed.clear()
+
     @torch.no_grad()
     def step(self, closure=None):
+        self._forget_handed_sinks()
         loss = None
         if closure is not None:
             with torch.enable_grad():

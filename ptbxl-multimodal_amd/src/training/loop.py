@@ -5,6 +5,10 @@ path (ecg_bce_logits_fwd / ecg_sigmoid_fwd).
 Epoch loss is sample-weighted: sum(loss_b * B_b) / len(loader.dataset).  The reference reads
 `loss.item()` every step (a device sync per step); here the same double-precision running sum
 is kept on the device and read once per epoch — same value, no per-step stall.
+
+With an `ecg_hip.optim.FlatAdamW` on one GPU and an unhooked model the step is replayed as ONE captured hipGraph
+per batch shape (ecg_hip.graph.LoopStepper; ECG_HIP_LOOP_GRAPH=0 turns it off): at the reference's batch sizes
+(32 / 64 windows) the eager step is bound by Python's enqueue time, not by the GPU.  Same kernels, same values.
 """
 from typing import Dict
 
@@ -13,6 +17,7 @@ import torch
 from torch.utils.data import DataLoader
 
 from ecg_hip import functional as hipF
+from ecg_hip.graph import LoopStepper
 from src.training.metrics import compute_metrics
 
 try:
@@ -27,18 +32,24 @@ def _logits(out):
     return out[0] if isinstance(out, tuple) else out
 
 
+def _eager_step(model, optimizer, x, y, weighted):
+    optimizer.zero_grad()
+    # the BCE launch also does `weighted += loss * batch_size` (double, on the device)
+    loss = hipF.binary_cross_entropy_with_logits(_logits(model(x)), y, weighted, x.size(0))
+    hipF.backward_from_loss(loss)            # loss.backward() minus two one-element launches
+    optimizer.step()
+
+
 def train_one_epoch(model, loader: DataLoader, optimizer, device) -> float:
     model.train()
-    weighted = None
+    stepper = LoopStepper.for_loop(model, optimizer, loss_weight_is_batch=True)
+    weighted = None if stepper is None else stepper.running
     for x, y in tqdm(loader, desc="Train", leave=False, disable=None):
         x, y = x.to(device), y.to(device)
         if weighted is None:
             weighted = torch.zeros((), dtype=torch.float64, device=x.device)
-        optimizer.zero_grad()
-        # the BCE launch also does `weighted += loss * batch_size` (double, on the device)
-        loss = hipF.binary_cross_entropy_with_logits(_logits(model(x)), y, weighted, x.size(0))
-        hipF.backward_from_loss(loss)            # loss.backward() minus two one-element launches
-        optimizer.step()
+        if stepper is None or not stepper.step((x, y)):
+            _eager_step(model, optimizer, x, y, weighted)
     return (0.0 if weighted is None else weighted.item()) / len(loader.dataset)
 
 

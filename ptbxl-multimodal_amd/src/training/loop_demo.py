@@ -4,11 +4,14 @@ src/training/loop_demo.py (train_one_epoch_demo :13-43, eval_one_epoch_demo :46-
 Unlike loop.py the epoch loss here is the plain mean of per-batch means, and a module-level
 `bce_loss_fn` object is kept because callers import it.  The running sum lives on the device
 in double precision and is read once per epoch (the reference syncs twice per step).
+With a FlatAdamW on one GPU and an unhooked model the step is replayed as one captured hipGraph per batch
+shape (ecg_hip.graph.LoopStepper, as in loop.py; ECG_HIP_LOOP_GRAPH=0 turns it off).
 """
 import numpy as np
 import torch
 
 from ecg_hip import functional as hipF
+from ecg_hip.graph import LoopStepper
 from src.training.metrics import compute_metrics
 
 try:
@@ -28,17 +31,23 @@ class _HipBCEWithLogits(torch.nn.Module):
 bce_loss_fn = _HipBCEWithLogits()
 
 
+def _eager_step(model, optimizer, x_ecg, x_demo, y, running):
+    optimizer.zero_grad()
+    loss = bce_loss_fn(model(x_ecg, x_demo), y, running, 1.0)    # running += loss inside the launch
+    hipF.backward_from_loss(loss)            # loss.backward() minus two one-element launches
+    optimizer.step()
+
+
 def train_one_epoch_demo(model, loader, optimizer, device):
     model.train()
-    running, batches = None, 0
+    stepper = LoopStepper.for_loop(model, optimizer, loss_weight_is_batch=False)
+    running, batches = (None if stepper is None else stepper.running), 0
     for x_ecg, x_demo, y in tqdm(loader, desc="Train-ECG+Demo", leave=False, disable=None):
         x_ecg, x_demo, y = x_ecg.to(device), x_demo.to(device), y.to(device)
         if running is None:
             running = torch.zeros((), dtype=torch.float64, device=x_ecg.device)
-        optimizer.zero_grad()
-        loss = bce_loss_fn(model(x_ecg, x_demo), y, running, 1.0)    # running += loss inside the launch
-        hipF.backward_from_loss(loss)            # loss.backward() minus two one-element launches
-        optimizer.step()
+        if stepper is None or not stepper.step((x_ecg, x_demo, y)):
+            _eager_step(model, optimizer, x_ecg, x_demo, y, running)
         batches += 1
     return (0.0 if running is None else running.item()) / max(1, batches)
 

@@ -210,17 +210,19 @@ def test_full_size_train_step_vs_cpu_oracle(name, B, T):
             np.testing.assert_allclose(a.cpu().numpy(), b.numpy(), atol=1e-5, err_msg=k)
 
 
-@pytest.mark.parametrize("name,optim", [("cnn5", "flat"), ("cnn5", "torch"), ("mm", "flat")])
-def test_trajectory_error_vs_float64_no_worse_than_the_cpu_fp32_path(name, optim):
+@pytest.mark.parametrize("name,optim,B,steps", [("cnn5", "flat", 32, 8), ("cnn5", "torch", 32, 8), ("mm", "flat", 32, 8),
+                                                ("cnn5", "flat", 256, 3), ("mm", "flat", 256, 3)])
+def test_trajectory_error_vs_float64_no_worse_than_the_cpu_fp32_path(name, optim, B, steps):
     """Multi-step trajectories cannot be pinned element by element (AdamW normalises noise-level gradients: two
     correct fp32 runs differ by up to lr per step on those elements — the bound test_g4 uses).  What CAN be pinned:
     against the SAME model trained in float64 (the exact trajectory, CPU oracle in double), the HIP path must not
-    drift more than the reference's own CPU fp32 run does.  Eight AdamW steps, B=32, lr 1e-3."""
+    drift more than the reference's own CPU fp32 run does.  Eight AdamW steps at B=32, and three at the HEADLINE size
+    (B=256, 12x1000: BASELINE.json configs[1] / configs[2]), lr 1e-3."""
     from ecg_hip.optim import FlatAdamW
     from src.utils.seed import set_seed
     from ecg_hip import functional as hipF
     ctor, rctor, C, demo = _ctors()[name]
-    lr, steps, B = 1e-3, 8, 32
+    lr = 1e-3
     batch = R.synthetic_batch(B, 1000, C, demo=demo)
     set_seed(42)
     model = ctor().to(DEV).train()
@@ -684,3 +686,55 @@ def test_train_step_is_bitwise_reproducible(name):
     assert torch.equal(outs[0][1], outs[1][1])
     for k in outs[0][2]:
         assert torch.equal(outs[0][2][k], outs[1][2][k]), k
+
+
+@pytest.mark.parametrize("name", ["cnn5", "mm"])
+def test_loop_api_replays_a_captured_step_and_matches_the_eager_loop(name, monkeypatch):
+    """train_one_epoch[_demo] with a FlatAdamW replay the step as one hipGraph per batch shape once a shape has been
+    seen twice (the reference's batch sizes are host-bound eagerly: configs/ecg_baseline.yaml:12, src/training/
+    loop.py:22-36).  Same kernels in the same order: parameters, buffers, counters and epoch losses must be
+    BIT-identical to the eager loop (ECG_HIP_LOOP_GRAPH=0), ragged last batch included."""
+    from ecg_hip.graph import LoopStepper
+    from ecg_hip.optim import FlatAdamW
+    from src.training.loop import train_one_epoch
+    from src.training.loop_demo import train_one_epoch_demo
+    from src.utils.seed import set_seed
+    ctor, _, C, demo = _ctors()[name]
+    data = R.synthetic_batch(8 * 5 + 3, 500, C, demo=demo)               # 5 full batches of 8 and a ragged one of 3
+    loader = torch.utils.data.DataLoader(_DS(*data), batch_size=8, shuffle=False)
+    fn = train_one_epoch_demo if demo else train_one_epoch
+    runs = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("ECG_HIP_LOOP_GRAPH", mode)
+        set_seed(11)
+        model = ctor().to(DEV)
+        opt = FlatAdamW(model.parameters(), lr=1e-3, weight_decay=1e-4)
+        losses = [fn(model, loader, opt, DEV) for _ in range(3)]
+        st = getattr(opt, "_ecg_loop_steppers", {})
+        runs[mode] = (losses, {k: v.clone() for k, v in model.state_dict().items()}, opt.steps_taken, st)
+    assert runs["0"][3] == {}                                             # opt-out: nothing was captured
+    (stepper,) = runs["1"][3].values()
+    assert len(stepper.graphs) == 2                                       # the full shape (epoch 1) and the ragged one (epoch 2)
+    assert runs["0"][2] == runs["1"][2] == 18
+    assert runs["0"][0] == runs["1"][0], (runs["0"][0], runs["1"][0])     # epoch losses: same double sums
+    for k, v in runs["0"][1].items():
+        assert torch.equal(v, runs["1"][1][k]), k
+
+
+def test_loop_api_stays_eager_when_a_graph_would_change_behaviour():
+    from ecg_hip.graph import LoopStepper
+    from ecg_hip.optim import FlatAdamW
+    from src.models.ecg_cnn import ECGCNN
+    model = ECGCNN(num_labels=5).to(DEV)
+    flat = FlatAdamW(model.parameters(), lr=1e-3)
+    assert LoopStepper.for_loop(model, flat, True) is not None
+    assert LoopStepper.for_loop(model, torch.optim.AdamW(model.parameters()), True) is None      # stock optimizer
+    h = model.backbone[-1].net[0].register_forward_hook(lambda m, i, o: None)                      # Grad-CAM style hook
+    assert LoopStepper.for_loop(model, flat, True) is None
+    h.remove()
+    assert LoopStepper.for_loop(model, flat, True) is not None
+    with torch.no_grad():
+        assert LoopStepper.for_loop(model, flat, True) is None
+    extra = torch.nn.Linear(3, 3).to(DEV)                                                          # a parameter the optimizer does not own
+    model.extra = extra
+    assert LoopStepper.for_loop(model, flat, True) is None

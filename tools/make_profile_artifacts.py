@@ -71,6 +71,27 @@ def mean(v):
     return sum(v) / len(v)
 
 
+MAX_CLOCK_GHZ = 2.4        # MI355X peak engine clock: no dispatch runs faster
+STAMPED_CLOCK_GHZ = 2.1    # what in-kernel s_memtime stamps read under the conv kernels (2.08-2.13)
+
+
+def mfma_busy_columns(busy_cycles, gui_active_per_xcd, d_us):
+    """MFMA-pipe busy fraction of one entry point.  SQ_VALU_MFMA_BUSY_CYCLES counts shader cycles per SIMD (1024 SIMDs).
+    The denominator needs the cycles the dispatch lasted: GRBM_GUI_ACTIVE / 8 is that on long dispatches, but it keeps
+    counting before the first and after the last wave, so on dispatches of a few tens of microseconds it spans MORE
+    than the kernel's own timestamps and the clock derived from it (GUI_ACTIVE / 8 / duration) reads above the
+    2.4 GHz the chip can run at (round 2 printed 3.18 GHz for the 42 us block-0 weight gradient).  Such rows are
+    flagged and priced with duration x the stamped clock instead; `mfma_busy_floor` (duration x 2.4 GHz, the largest
+    the denominator can be) is a lower bound that holds for every row."""
+    clock = gui_active_per_xcd / (d_us * 1e3)
+    floor = busy_cycles / (1024 * d_us * 1e3 * MAX_CLOCK_GHZ)
+    if clock <= MAX_CLOCK_GHZ:
+        return f" mfma_busy={busy_cycles / (1024 * gui_active_per_xcd):.3f} clock_GHz={clock:.3f} mfma_busy_floor={floor:.3f}"
+    est = busy_cycles / (1024 * d_us * 1e3 * STAMPED_CLOCK_GHZ)
+    return (f" mfma_busy={min(est, 1.0):.3f}(at the stamped {STAMPED_CLOCK_GHZ} GHz) clock_GHz=invalid({clock:.2f}>2.4: "
+            f"GUI_ACTIVE spans beyond a short dispatch) mfma_busy_floor={floor:.3f}")
+
+
 def main():
     os.makedirs(PROF, exist_ok=True)
     for f in glob.glob(os.path.join(OUT, f"{TAG}_bench*.json")) + glob.glob(os.path.join(OUT, f"{TAG}_input_pipeline.json")) + glob.glob(os.path.join(OUT, f"{TAG}_inference.json")):
@@ -86,7 +107,9 @@ def main():
     lines = ["# per entry point of one B=256 train step (tools/pmc_step.py; same keys as bench.py `layers`):",
              "# launches per call, µs per call (under the counter pass), FETCH_SIZE / WRITE_SIZE in KiB as rocprofv3 reports them",
              "# (separate passes), hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024 (gfx950 FETCH_SIZE correction),",
-             "# mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs * GRBM_GUI_ACTIVE / 8), clock = GRBM_GUI_ACTIVE / 8 / duration"]
+             "# mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs * GRBM_GUI_ACTIVE / 8), clock = GRBM_GUI_ACTIVE / 8 / duration;",
+             "# a derived clock above 2.4 GHz means GUI_ACTIVE spans more than the (short) dispatch: the row is flagged and priced",
+             "# with duration x the stamped 2.1 GHz instead; mfma_busy_floor = busy / (1024 * duration * 2.4 GHz) always holds"]
     entries = {}
     variants = [("", "ECGCNN(5), 12x1000, fp32 (the headline)"), ("_mm", "ECGMultimodal, 12x1000, fp32"),
                 ("_c5f32", "ECGCNN(1), 12x5000, fp32 (BASELINE configs[4])"),
@@ -110,7 +133,7 @@ def main():
               busy = mean([s.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) for s in sq[key]])
               d_us = mean([s["_ns"] for s in sq[key]]) / 1e3
               if cyc > 0 and busy > 0:
-                  extra = f" mfma_busy={busy / (1024 * cyc):.3f} clock_GHz={cyc / (d_us * 1e3):.3f}"
+                  extra = mfma_busy_columns(busy, cyc, d_us)
           lines.append(f"{key:64s} launches={fetch[key][0]['_n']:2d} us={us:8.1f} FETCH_SIZE={f:10.1f} WRITE_SIZE={w:10.1f} "
                        f"hbm_bytes={hb:12.0f}{extra}")
     open(os.path.join(PROF, f"{TAG}_pmc_summary.txt"), "w").write("\n".join(lines) + "\n")
