@@ -450,7 +450,8 @@ def _short_rccl(r, leg):
     return out
 
 
-def build_line(primary, also, cpu, rccl, *, n_gpus, steps, warmup, batch, length, priming, priming_seconds, n1_value=None):
+def build_line(primary, also, cpu, rccl, *, n_gpus, steps, warmup, batch, length, priming, priming_seconds, n1_value=None,
+               small=None):
     """(line, detail): the ONE JSON line rank 0 prints — at most LINE_BUDGET characters, everything the contract and
     the judge read (value, ms_per_step, config, step_ms, roofline, cpu_baseline, rccl, one summary row per other
     configuration) — and the full record (per-entry-point `layers` tables of every leg, the CPU thread sweep, the
@@ -484,11 +485,16 @@ def build_line(primary, also, cpu, rccl, *, n_gpus, steps, warmup, batch, length
             if "exchange" in leg:
                 row["exchange_mode"] = leg["exchange"]["mode"]
             line["also"].append(row)
+    if small:
+        # the reference's own batch sizes through train_one_epoch: windows/s with the captured-graph loop and eagerly
+        line["ref_batch_sizes"] = [{"workload": p["graph"]["workload_short"], "value": p["graph"]["value"],
+                                    "ms_per_step": p["graph"]["ms_per_step"], "eager_value": p["eager"]["value"]} for p in small]
     if cpu is not None:
         line["cpu_baseline"] = _short_cpu(cpu)
-    detail = {"line": dict(line), "primary": primary, "also": also, "cpu_baseline": cpu, "rccl": rccl}
+    detail = {"line": dict(line), "primary": primary, "also": also, "ref_batch_sizes": small or [], "cpu_baseline": cpu,
+              "rccl": rccl}
     # never let the line outgrow what the driver keeps: drop optional blocks, least important first
-    for key in ("frac_by_block", "instrumented_ms_per_step", "step_conv_tflops", "value_at_median_step", "also"):
+    for key in ("ref_batch_sizes", "frac_by_block", "instrumented_ms_per_step", "step_conv_tflops", "value_at_median_step", "also"):
         if len(json.dumps(line, separators=(",", ":"))) <= LINE_BUDGET - 80:
             break
         line.pop(key, None)
@@ -665,6 +671,8 @@ def main():
         if exch:
             opt.reduce_gradients = inner
         rows, other_ms = layer_table(kt.result)
+        # did the loop API replay a captured step (ecg_hip.graph.LoopStepper: FlatAdamW, one rank, no hooks)?
+        loop_replays = (not graph) and any(st.graphs for st in getattr(opt, "_ecg_loop_steppers", {}).values())
         conv_ms = sum(r["avg_us"] * r["calls"] for r in rows) / 1e3
 
         value = world * B * spec["steps"] / elapsed
@@ -682,7 +690,8 @@ def main():
                                f"{' stockAdamW' if stock else ''}{' graph' if graph else ''}"),
             "frac_by_block": frac_by_block(rows),
             "optimizer": "torch.optim.AdamW (stock)" if stock else "FlatAdamW",
-            "loop": "hipGraph replay (GraphedTrainStep)" if graph else "train_one_epoch" + ("_demo" if demo else ""),
+            "loop": ("hipGraph replay (GraphedTrainStep)" if graph else "train_one_epoch" + ("_demo" if demo else "") +
+                     (" (hipGraph replay per batch shape)" if loop_replays else "")),
             "final_loss": round(float(last_loss), 6),
             "step_conv_tflops": round(value * step_f / 1e12, 2),
             "step_frac_of_mfma_peak": round(value * step_f / 1e12 / (peak * world), 4),
@@ -740,6 +749,22 @@ def main():
             res, _ = run_leg(spec)
             also.append(res)
 
+    # The reference's OWN batch sizes through the unchanged loop API (configs/ecg_baseline.yaml:12 batch 64,
+    # configs/af_binary.yaml:8 batch 32; 12x5000 is what its 500 Hz records are, 12x1000 BASELINE's window): there the
+    # eager step is bound by Python's enqueue time, and train_one_epoch replays a captured hipGraph instead
+    # (ecg_hip.graph.LoopStepper).  Both forms are measured; detail file only, one summary row each in the line.
+    small = []
+    if world == 1 and not args.no_also and not args.graph and args.dtype == "f32" and args.length == 1000 and args.optim == "flat":
+        for B_, T_, labels_ in ((64, 5000, 5), (32, 5000, 1), (32, 1000, 5)):
+            pair = {}
+            for mode in ("1", "0"):
+                os.environ["ECG_HIP_LOOP_GRAPH"] = mode
+                res, _ = run_leg(dict(base, model="cnn", labels=labels_, length=T_, batch=B_, optim="flat", graph=False,
+                                      steps=max(20, args.steps), priming=10, priming_seconds=0.5))
+                pair["graph" if mode == "1" else "eager"] = res
+            os.environ.pop("ECG_HIP_LOOP_GRAPH", None)
+            small.append(pair)
+
     ranks_seen = None
     if world > 1:
         ones = torch.ones(1, device=dev)
@@ -756,7 +781,7 @@ def main():
         detail_path = args.detail or os.path.join(ROOT, "gpurun_out", f"bench_detail_n{world}.json")
         line, detail = build_line(primary, also, cpu, rccl, n_gpus=world, steps=args.steps, warmup=args.warmup,
                                   batch=args.batch, length=args.length, priming=args.priming,
-                                  priming_seconds=args.priming_seconds, n1_value=args.n1_value)
+                                  priming_seconds=args.priming_seconds, n1_value=args.n1_value, small=small)
         try:
             os.makedirs(os.path.dirname(detail_path), exist_ok=True)
             with open(detail_path, "w") as f:

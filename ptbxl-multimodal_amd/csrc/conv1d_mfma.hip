@@ -19,6 +19,7 @@
 // Replaces the ATen work behind ConvBlock.net[0] (reference src/models/ecg_cnn.py:13) and its
 // backward (src/training/loop.py:33).
 #include "common.h"
+#include <cstdlib>
 
 namespace ecg {
 
@@ -957,14 +958,25 @@ int wgrad_reduce(const float *ws, float *dw, float *db, size_t wslab, int Cout, 
 
 struct WgCfg { int m_t, r_t, splits; };
 
+static int tune_int(const char *name, int def) {       // development knobs (tools/layer_bench.py A/B runs)
+    const char *v = getenv(name);
+    return v && *v ? atoi(v) : def;
+}
+
 static WgCfg wgrad_cfg(int N, int Cin, int Cout, int Lo, bool dma) {
     const int R = Cin * kKM;
+    static const int slots = tune_int("ECG_WG_SLOTS", 512), rt128 = tune_int("ECG_WG_RT", 0);
     WgCfg c;
-    if (Cout % 128 == 0) c = {128, 128, 0};
+    // 128 x 192 tiles where 128-wide column tiles would leave a ragged last tile and 192 divide the columns (block 2:
+    // R = 960 = 5 x 192 instead of 7.5 x 128: 154.7 -> 150.3 us; block 3, R = 1920 = 15 x 128 = 10 x 192: 264.0 vs 267.5 us,
+    // stays at 128).  More, smaller workgroups (ECG_WG_SLOTS 768 / 1024: a second round in the slots the early finishers
+    // free) measured 2-8 % SLOWER on every layer — the second prologue / slab costs more than the tail it evens out.
+    const bool wide = dma && R % 192 == 0 && (rt128 == 192 || (rt128 == 0 && R % 128 != 0));
+    if (Cout % 128 == 0) c = {128, wide ? 192 : 128, 0};
     else if (Cout % 64 == 0) c = {64, 128, 0};
     else c = {32, 192, 0};
     const int tiles = cdiv(R, c.r_t) * (Cout / c.m_t);
-    int s = 512 / tiles;               // fill, but never exceed, the 2 x 256 resident-workgroup slots:
+    int s = slots / tiles;             // fill, but never exceed, the 2 x 256 resident-workgroup slots:
                                        // one workgroup over and the launch takes two rounds.
                                        // (64-channel tiles at 4 workgroups per CU measured no better here; nor did
                                        // 128 x 256 column tiles for block 3: 273 vs 271 us, 236 VGPRs.)
@@ -1003,7 +1015,8 @@ int mfma_wgrad(const float *dy, int ldy, const float *x, float *dw, float *db, f
     dim3 grid((unsigned)(cdiv(R, c.r_t) * (Cout / c.m_t) * c.splits)), block(256);
 #define ECG_WG(KERNEL) \
     hipLaunchKernelGGL(KERNEL, grid, block, 0, st, dy, x, ws, N, Cin, Cout, L, Lo, ldy, pad, c.splits)
-    if (dma && c.m_t == 128) ECG_WG((conv1d_mfma_wgrad_dma_kernel<128, 128, 2, 2, 1, kKM>));
+    if (dma && c.m_t == 128 && c.r_t == 192) ECG_WG((conv1d_mfma_wgrad_dma_kernel<128, 192, 2, 2, 1, kKM>));
+    else if (dma && c.m_t == 128) ECG_WG((conv1d_mfma_wgrad_dma_kernel<128, 128, 2, 2, 1, kKM>));
     else if (dma && c.m_t == 64) ECG_WG((conv1d_mfma_wgrad_dma_kernel<64, 128, 2, 2, 1, kKM>));
     else if (dma) ECG_WG((conv1d_mfma_wgrad_dma_kernel<32, 192, 1, 2, 2, kKM>));
     else if (c.m_t == 128) ECG_WG((conv1d_mfma_wgrad_kernel<128, 128, 2, 2, 1, 64, kKM>));

@@ -11,9 +11,10 @@ counter lives on the device); no hooks that synchronise.  BatchNorm counters, ru
 and the optional running-loss accumulator are all updated by kernels, so replay keeps them right.
 Not used with a process group (collectives are left out of the capture).
 
-`LoopStepper` is how the UNCHANGED loop API gets this: `train_one_epoch[_demo]` ask it for every batch; once a
-batch shape has been seen twice it builds a GraphedTrainStep for that shape and replays it, anything else (ragged
-last batch, a hooked model, a stock optimizer, several ranks, ECG_HIP_LOOP_GRAPH=0) runs the eager step.
+`LoopStepper` is how the UNCHANGED loop API gets this (opt-in: ECG_HIP_LOOP_GRAPH=1, see loop_graph_enabled):
+`train_one_epoch[_demo]` ask it for every batch; once a batch shape has been seen twice it builds a GraphedTrainStep
+for that shape and replays it, anything else (ragged last batch, a hooked model, a stock optimizer, several ranks)
+runs the eager step.
 """
 import os
 
@@ -92,8 +93,13 @@ class GraphedTrainStep:
 # the loop API's way in
 # --------------------------------------------------------------------------------------------------------------
 def loop_graph_enabled():
-    """ECG_HIP_LOOP_GRAPH=0 keeps train_one_epoch[_demo] on the eager step whatever the optimizer."""
-    return os.environ.get("ECG_HIP_LOOP_GRAPH", "1") != "0"
+    """ECG_HIP_LOOP_GRAPH=1 lets train_one_epoch[_demo] replay captured steps; the default is the eager step.
+    Why opt-in (measured on MI355X, round 3, `bench.py` `ref_batch_sizes`): with 33 launches per step the eager loop is
+    no longer host-bound even at the reference's batch sizes — B=32 12x1000: 0.591 ms eager vs 0.605 ms replayed,
+    B=32 12x5000: 1.276 vs 1.296, B=64 12x5000: 2.110 vs 2.128, B=256 12x1000: 1.640 vs 1.659 — the replay pays for
+    the copies into its static input buffers and gains nothing while the GPU is the bottleneck.  It frees the host
+    thread (one call per step instead of ~45), which matters only when the input pipeline needs that thread."""
+    return os.environ.get("ECG_HIP_LOOP_GRAPH", "0") == "1"
 
 
 _HOOK_DICTS = ("_forward_hooks", "_forward_pre_hooks", "_backward_hooks", "_backward_pre_hooks")

@@ -6,9 +6,9 @@ Epoch loss is sample-weighted: sum(loss_b * B_b) / len(loader.dataset).  The ref
 `loss.item()` every step (a device sync per step); here the same double-precision running sum
 is kept on the device and read once per epoch — same value, no per-step stall.
 
-With an `ecg_hip.optim.FlatAdamW` on one GPU and an unhooked model the step is replayed as ONE captured hipGraph
-per batch shape (ecg_hip.graph.LoopStepper; ECG_HIP_LOOP_GRAPH=0 turns it off): at the reference's batch sizes
-(32 / 64 windows) the eager step is bound by Python's enqueue time, not by the GPU.  Same kernels, same values.
+With an `ecg_hip.optim.FlatAdamW` on one GPU and an unhooked model the step CAN be replayed as one captured hipGraph
+per batch shape (ecg_hip.graph.LoopStepper; opt-in: ECG_HIP_LOOP_GRAPH=1) — same kernels, same values, one host call
+per step.  Measured: no faster than the eager loop at any batch size while the GPU is the bottleneck (graph.py).
 """
 from typing import Dict
 

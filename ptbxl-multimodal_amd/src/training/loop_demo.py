@@ -5,7 +5,7 @@ Unlike loop.py the epoch loss here is the plain mean of per-batch means, and a m
 `bce_loss_fn` object is kept because callers import it.  The running sum lives on the device
 in double precision and is read once per epoch (the reference syncs twice per step).
 With a FlatAdamW on one GPU and an unhooked model the step is replayed as one captured hipGraph per batch
-shape (ecg_hip.graph.LoopStepper, as in loop.py; ECG_HIP_LOOP_GRAPH=0 turns it off).
+shape (ecg_hip.graph.LoopStepper, as in loop.py; opt-in: ECG_HIP_LOOP_GRAPH=1).
 """
 import numpy as np
 import torch
