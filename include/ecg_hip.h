@@ -175,6 +175,15 @@ int ecg_conv1d_bwd_data_bf16h(const void *dy_bf16, int ldy, const void *wb_bwd, 
 int ecg_conv1d_fwd_bf16_yh(const void *x, int x_bf16, int ldx, const void *wb_fwd, const float *bias, void *y_bf16,
                            int ldy, float *stat_partials, int N, int C_in, int C_out, int L, int K, int pad,
                            ecg_stream_t stream);
+/* How many (sum, sum^2) partials per channel ecg_conv1d_fwd_bf16_yh writes for exactly these arguments.  Long rows with
+ * bf16 on both sides (x_bf16 != 0, ldy % 8 == 0) take the round-3 ring kernel (csrc/conv1d_bf16_ring.hip: 640 / 1280
+ * time steps per workgroup, weights through an LDS-DMA ring, transposed accumulators), whose workgroup count differs
+ * from the kernel behind ecg_conv1d_fwd_bf16_stat_partials.  Same reference call site: src/models/ecg_cnn.py:13-14. */
+int ecg_conv1d_fwd_bf16_yh_stat_partials(int N, int C_in, int C_out, int L, int K, int pad, int x_bf16, int ldx, int ldy);
+/* Which kernel a conv with bf16 tensors on both sides takes (ecg_conv1d_fwd_bf16_yh with x_bf16 != 0: C_red = C_in,
+ * C_res = C_out, pad; ecg_conv1d_bwd_data_bf16hh: C_red = C_out, C_res = C_in, pad = K-1-pad): the ring kernel's time
+ * steps per workgroup tile (640 / 1280), or 0 = the round-2 kernel of conv1d_mfma_bf16.hip.  Tests and profiles. */
+int ecg_conv1d_bf16_ring_tile(int N, int C_red, int C_res, int L_out, int K, int pad, int ld_in, int ld_out);
 int ecg_bn_stats_relu_pool_fwd_yh(const float *stat_partials, int P, long long count, float *running_mean,
                                   float *running_var, long long *num_batches_tracked, float momentum, float eps,
                                   const void *y_bf16, int ldy, const float *gamma, const float *beta, float *mean,

@@ -498,12 +498,22 @@ static void launch_bf16(const void *x, int ldx, bool xh, const u16 *wb, const fl
 #undef ECG_BF
 }
 
+// conv1d_bf16_ring.hip: the round-3 kernel for long rows with bf16 activations on both sides
+struct RingPlan { bool ok; int co_t, t_t, res_ch, G; };
+RingPlan bf16_ring_plan(int N, int Cin, int Cout, int Lo, int K, int pad, int ldx, int ldyo);
+int bf16_ring_launch(const RingPlan &p, const void *x, int ldx, const void *wb, const float *bias, void *y, int ldyo,
+                     float *partials, int P_stride, int N, int Cin, int Cout, int L, int Lo, int pad, hipStream_t st);
+
 // x: fp32 [N][Cin][L] (xh false, ldx ignored) or bf16 [N][Cin][ldx] with rows zero-filled past L (xh true);
 // y: fp32 [N][Cout][ldyo] or (yh, with statistics) bf16 [N][Cout][ldyo]
 static int bf16_fwd_any(const void *x, int ldx, bool xh, const void *wb, const float *bias, float *y, int ldyo, bool yh,
                         float *partials, int N, int Cin, int Cout, int L, int K, int pad, hipStream_t st) {
     const int Lo = L + 2 * pad - K + 1;
     const u16 *w = static_cast<const u16 *>(wb);
+    if (xh && yh && ((reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(wb)) & 15) == 0) {
+        const RingPlan rp = bf16_ring_plan(N, Cin, Cout, Lo, K, pad, ldx, ldyo);
+        if (rp.ok) return bf16_ring_launch(rp, x, ldx, wb, bias, y, ldyo, partials, rp.G, N, Cin, Cout, L, Lo, pad, st);
+    }
     const Bf16Cfg c = bf16_cfg(N, Cout, Lo);
     if (c.co_t == 128) launch_bf16<128, 256, 2, 4>(x, ldx, xh, w, bias, y, ldyo, yh, partials, N, Cin, Cout, L, Lo, pad, c.G, st);
     else if (c.co_t == 64 && c.t_t == 256) launch_bf16<64, 256, 1, 4>(x, ldx, xh, w, bias, y, ldyo, yh, partials, N, Cin, Cout, L, Lo, pad, c.G, st);
@@ -621,6 +631,25 @@ ECG_API int ecg_conv1d_pack_weights_bf16(const float *w, void *wb_fwd, void *wb_
 ECG_API int ecg_conv1d_fwd_bf16_stat_partials(int N, int C_in, int C_out, int L, int K, int pad) {
     (void)C_in;
     return bf16_fwd_stat_partials(N, C_out, L + 2 * pad - K + 1);
+}
+
+// partials per channel that ecg_conv1d_fwd_bf16_yh writes for these arguments (it picks its kernel by the operand
+// types and row strides too, so the count can differ from ecg_conv1d_fwd_bf16_stat_partials)
+ECG_API int ecg_conv1d_fwd_bf16_yh_stat_partials(int N, int C_in, int C_out, int L, int K, int pad, int x_bf16, int ldx,
+                                                 int ldy) {
+    const int Lo = L + 2 * pad - K + 1;
+    if (x_bf16) {
+        const RingPlan rp = bf16_ring_plan(N, C_in, C_out, Lo, K, pad, ldx, ldy);
+        if (rp.ok) return rp.G;
+    }
+    return bf16_fwd_stat_partials(N, C_out, Lo);
+}
+
+// time steps per workgroup tile of the ring kernel when a conv with bf16 tensors on both sides (C_red reduction channels,
+// C_res result channels, L_out result positions, `pad` as the kernel sees it) takes it, 0 when the round-2 kernel runs
+ECG_API int ecg_conv1d_bf16_ring_tile(int N, int C_red, int C_res, int L_out, int K, int pad, int ld_in, int ld_out) {
+    const RingPlan rp = bf16_ring_plan(N, C_red, C_res, L_out, K, pad, ld_in, ld_out);
+    return rp.ok ? rp.t_t : 0;
 }
 
 ECG_API int ecg_conv1d_fwd_bf16(const float *x, const void *wb_fwd, const float *bias, float *y,

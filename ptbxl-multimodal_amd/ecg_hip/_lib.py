@@ -47,6 +47,8 @@ SIGNATURES = {
     "ecg_bn_relu_pool_bwd_n16": (_i, [_vp] * 7 + [_i, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "ecg_conv1d_bwd_data_bf16h": (_i, [_vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "ecg_conv1d_fwd_bf16_yh": (_i, [_vp, _i, _i, _vp, _vp, _vp, _i, _vp] + [_i] * 6 + [_vp]),
+    "ecg_conv1d_fwd_bf16_yh_stat_partials": (_i, [_i] * 9),
+    "ecg_conv1d_bf16_ring_tile": (_i, [_i] * 8),
     "ecg_bn_stats_relu_pool_fwd_yh": (_i, [_vp, _i, _ll, _vp, _vp, _vp, _f, _f, _vp, _i] + [_vp] * 7 + [_i] * 7 + [_vp]),
     "ecg_bn_relu_pool_bwd_n16_yh": (_i, [_vp, _i, _vp, _i, _i] + [_vp] * 5 +
                                     [_i, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),

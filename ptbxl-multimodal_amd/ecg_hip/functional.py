@@ -412,7 +412,7 @@ class ConvBlockFn(torch.autograd.Function):
                                 "between blocks); run the chain with activation storage off")
         if ldyh:
             y = torch.empty(N, Co, ldyh, dtype=torch.bfloat16, device=x.device)
-            P = _query("ecg_conv1d_fwd_bf16_stat_partials", N, Ci, Co, Lin, K, pad)
+            P = _query("ecg_conv1d_fwd_bf16_yh_stat_partials", N, Ci, Co, Lin, K, pad, 1 if x_h else 0, ldx, ldyh)
             partials = _empty(x, Co * P * 2)
             _call("ecg_conv1d_fwd_bf16_yh", L.ptr(x), 1 if x_h else 0, ldx, L.ptr(w_fwd), _f32(b), L.ptr(y), ldyh,
                   _f32(partials), N, Ci, Co, Lin, K, pad, _st())

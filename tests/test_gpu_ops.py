@@ -955,3 +955,125 @@ def test_bf16_input_grad_from_bf16_dy_equals_the_fp32_dy_entry_point(hip, case):
     assert torch.equal(dx, dx_ref)
     with pytest.raises(L.EcgHipError, match="even row stride"):
         L.call("ecg_conv1d_bwd_data_bf16h", L.ptr(dyh), PA + 1, L.ptr(wb_bwd), L.f32(dx), N, Ci, Co, Lin, 15, 7, L.stream())
+
+
+def _bf16_rows(a, ld, fill=0.0):
+    """fp32 numpy [N][C][L] -> torch.bfloat16 CUDA tensor [N][C][ld], rows filled with `fill` past L."""
+    N, C, Lr = a.shape
+    t = torch.full((N, C, ld), fill, dtype=torch.float32)
+    t[:, :, :Lr] = torch.from_numpy(a)
+    return t.to(torch.bfloat16).cuda().contiguous()
+
+
+# (N, C_in, C_out, L): the shapes of BASELINE.json configs[4] (12x5000 pools to 2500 / 1250 / 625) at small N — every
+# configuration of csrc/conv1d_bf16_ring.hip: 128-channel ring (2-tap groups; 4, 8 and 16 chunks), 64-channel resident
+# (2 chunks), 64-channel ring (4-tap groups, 8 chunks), 32-channel resident (4 chunks); rows of 625 are ragged in every tile
+@pytest.mark.parametrize("case", [(2, 64, 128, 1250), (1, 128, 256, 625), (3, 32, 64, 2500), (2, 128, 64, 1250),
+                                  (2, 64, 32, 2500), (1, 256, 128, 625), (2, 64, 128, 625)])
+def test_bf16_ring_forward_is_exact_on_bf16_rounded_operands(hip, oracle, case):
+    """The round-3 long-row kernel (bf16 x [N][Ci][ldx] in, bf16 y [N][Co][ldy] out, weights through an LDS-DMA ring or
+    resident, transposed accumulators): y must be the bf16 rounding of the oracle's convolution of the SAME bf16 operands
+    (fp32 accumulation: at most one bf16 ulp where the sum sits on a rounding boundary), and the statistics partials
+    must be the sums over exactly the stored values."""
+    from ecg_hip import _lib as L
+    N, Ci, Co, Lin = case
+    rng = np.random.default_rng(Ci * 11 + Co + Lin)
+    x = _bf16_round(rng.standard_normal((N, Ci, Lin)).astype(np.float32))
+    w = (rng.standard_normal((Co, Ci, 15)) / np.sqrt(Ci * 15)).astype(np.float32)
+    b = rng.standard_normal(Co).astype(np.float32)
+    ldx, ldy = (Lin + 7) & ~7, (Lin + 7) & ~7
+    P = L.query("ecg_conv1d_fwd_bf16_yh_stat_partials", N, Ci, Co, Lin, 15, 7, 1, ldx, ldy)
+    P_old = L.query("ecg_conv1d_fwd_bf16_stat_partials", N, Ci, Co, Lin, 15, 7)
+    assert L.query("ecg_conv1d_bf16_ring_tile", N, Ci, Co, Lin, 15, 7, ldx, ldy) == (640 if Co % 128 == 0 else 1280)
+    assert L.query("ecg_conv1d_bf16_ring_tile", N, Ci, Co, 300, 15, 7, 304, 304) == 0       # short rows: the round-2 kernel
+    xh = _bf16_rows(x, ldx)
+    wb_fwd, _ = hip.conv1d_pack_bf16(dev(w), need_bwd=False)
+    yh = torch.full((N, Co, ldy), float("nan"), dtype=torch.bfloat16, device="cuda")
+    part = torch.full((Co * P * 2,), float("nan"), device="cuda")
+    L.call("ecg_conv1d_fwd_bf16_yh", L.ptr(xh), 1, ldx, L.ptr(wb_fwd), L.f32(dev(b)), L.ptr(yh), ldy, L.f32(part),
+           N, Ci, Co, Lin, 15, 7, L.stream())
+    torch.cuda.synchronize()
+    ry = oracle.conv1d_fwd(x, _bf16_round(w), b, 7)
+    got = yh.float().cpu().numpy()
+    ulp = np.abs(ry) * 2.0 ** -7 + 1e-6                     # one bf16 ulp of the exact value
+    assert np.all(np.abs(got[:, :, :Lin] - ry) <= ulp), float(np.abs(got[:, :, :Lin] - ry).max())
+    assert np.mean(got[:, :, :Lin] != _bf16_round(ry)) < 0.01        # ... and almost everywhere the same rounding
+    pad = got[:, :, Lin:]
+    assert np.all((pad == 0) | np.isnan(pad))                # the row padding holds zeros (or was never written)
+    ps = part.cpu().numpy().reshape(Co, P, 2).astype(np.float64).sum(axis=1)
+    v = got[:, :, :Lin].astype(np.float64)
+    np.testing.assert_allclose(ps[:, 0], v.sum(axis=(0, 2)), rtol=1e-5, atol=1e-3)
+    np.testing.assert_allclose(ps[:, 1], (v * v).sum(axis=(0, 2)), rtol=1e-5, atol=1e-3)
+    # the same call with the kernel switched to the fp32-x entry point (round-2 kernel) gives the same tensor up to the
+    # rounding-boundary cases: both are roundings of the same exact sums
+    y_old = torch.empty(N, Co, ldy, dtype=torch.bfloat16, device="cuda")
+    part_old = torch.empty(Co * P_old * 2, device="cuda")
+    L.call("ecg_conv1d_fwd_bf16_yh", L.f32(dev(x)), 0, 0, L.ptr(wb_fwd), L.f32(dev(b)), L.ptr(y_old), ldy, L.f32(part_old),
+           N, Ci, Co, Lin, 15, 7, L.stream())
+    assert np.mean(y_old.float().cpu().numpy()[:, :, :Lin] != got[:, :, :Lin]) < 0.01
+
+
+@pytest.mark.parametrize("case", [(2, 64, 128, 1250), (1, 128, 256, 625), (2, 32, 64, 2500), (2, 64, 128, 2500)])
+def test_bf16_ring_input_grad_is_exact_on_bf16_rounded_operands(hip, oracle, case):
+    """ecg_conv1d_bwd_data_bf16hh on long rows = the same kernel with the channel roles swapped (dY bf16 [N][Co][PA] in,
+    dx bf16 [N][Ci][ldx] out, no bias, no statistics)."""
+    from ecg_hip import _lib as L
+    N, Ci, Co, Lin = case
+    rng = np.random.default_rng(Ci * 13 + Co + Lin)
+    dy = _bf16_round(rng.standard_normal((N, Co, Lin)).astype(np.float32))
+    w = (rng.standard_normal((Co, Ci, 15)) / np.sqrt(Co * 15)).astype(np.float32)
+    PA = L.query("ecg_conv1d_n16_positions", Lin, 15, 7, 0)
+    ldx = (Lin + 7) & ~7
+    assert L.query("ecg_conv1d_bf16_ring_tile", N, Co, Ci, Lin, 15, 7, PA, ldx) == (640 if Ci % 128 == 0 else 1280)
+    dyh = _bf16_rows(dy, PA)
+    _, wb_bwd = hip.conv1d_pack_bf16(dev(w), need_bwd=True)
+    dxh = torch.full((N, Ci, ldx), float("nan"), dtype=torch.bfloat16, device="cuda")
+    L.call("ecg_conv1d_bwd_data_bf16hh", L.ptr(dyh), PA, L.ptr(wb_bwd), L.ptr(dxh), ldx, N, Ci, Co, Lin, 15, 7, L.stream())
+    torch.cuda.synchronize()
+    rdx = oracle.conv1d_bwd_data(dy, _bf16_round(w), Lin, 7)
+    got = dxh.float().cpu().numpy()[:, :, :Lin]
+    assert np.all(np.abs(got - rdx) <= np.abs(rdx) * 2.0 ** -7 + 1e-6), float(np.abs(got - rdx).max())
+    assert np.mean(got != _bf16_round(rdx)) < 0.01
+
+
+@pytest.mark.parametrize("block", [1, 2, 3])
+def test_bf16_ring_full_size_config5_vs_torch(hip, block):
+    """BASELINE.json configs[4] at full size (B=256, 12x5000): the persistent workgroups of the ring kernel run several
+    tiles each (weights re-streamed / resident across tiles, x staged one chunk ahead across tile boundaries).
+    Expected values: torch's own convolution of the same bf16 values in fp32."""
+    from ecg_hip import _lib as L
+    Ci, Co = [(12, 32), (32, 64), (64, 128), (128, 256)][block]
+    N, Lin = 256, 5000 >> block
+    g = torch.Generator().manual_seed(block)
+    x = torch.randn(N, Ci, Lin, generator=g).to(torch.bfloat16)
+    w = (torch.randn(Co, Ci, 15, generator=g) / (Ci * 15) ** 0.5)
+    b = torch.randn(Co, generator=g)
+    ldx = ldy = (Lin + 7) & ~7
+    xh = torch.zeros(N, Ci, ldx, dtype=torch.bfloat16)
+    xh[:, :, :Lin] = x
+    xh = xh.cuda()
+    wb_fwd, wb_bwd = hip.conv1d_pack_bf16(w.cuda(), need_bwd=True)
+    P = L.query("ecg_conv1d_fwd_bf16_yh_stat_partials", N, Ci, Co, Lin, 15, 7, 1, ldx, ldy)
+    assert L.query("ecg_conv1d_bf16_ring_tile", N, Ci, Co, Lin, 15, 7, ldx, ldy) > 0
+    yh = torch.empty(N, Co, ldy, dtype=torch.bfloat16, device="cuda")
+    part = torch.empty(Co * P * 2, device="cuda")
+    L.call("ecg_conv1d_fwd_bf16_yh", L.ptr(xh), 1, ldx, L.ptr(wb_fwd), L.f32(b.cuda()), L.ptr(yh), ldy, L.f32(part),
+           N, Ci, Co, Lin, 15, 7, L.stream())
+    wr = w.to(torch.bfloat16).float().cuda()
+    ref = torch.nn.functional.conv1d(xh[:, :, :Lin].float(), wr, b.cuda(), padding=7)
+    got = yh[:, :, :Lin].float()
+    assert torch.all((got - ref).abs() <= ref.abs() * 2.0 ** -7 + 2e-5), float((got - ref).abs().max())
+    ps = part.view(Co, P, 2).double().sum(dim=1)
+    torch.testing.assert_close(ps[:, 0], got.double().sum(dim=(0, 2)), rtol=2e-5, atol=1e-2)
+    torch.testing.assert_close(ps[:, 1], (got.double() ** 2).sum(dim=(0, 2)), rtol=2e-5, atol=1e-2)
+    # input gradient of the same layer
+    PA = L.query("ecg_conv1d_n16_positions", Lin, 15, 7, 0)
+    dy = torch.randn(N, Co, Lin, generator=g).to(torch.bfloat16)
+    dyh = torch.zeros(N, Co, PA, dtype=torch.bfloat16)
+    dyh[:, :, :Lin] = dy
+    dyh = dyh.cuda()
+    dxh = torch.empty(N, Ci, ldx, dtype=torch.bfloat16, device="cuda")
+    L.call("ecg_conv1d_bwd_data_bf16hh", L.ptr(dyh), PA, L.ptr(wb_bwd), L.ptr(dxh), ldx, N, Ci, Co, Lin, 15, 7, L.stream())
+    rdx = torch.nn.functional.conv_transpose1d(dyh[:, :, :Lin].float(), wr, padding=7)
+    gdx = dxh[:, :, :Lin].float()
+    assert torch.all((gdx - rdx).abs() <= rdx.abs() * 2.0 ** -7 + 2e-5), float((gdx - rdx).abs().max())

@@ -27,7 +27,9 @@ def main():
     ap.add_argument("--batch", type=int, default=256)
     ap.add_argument("--length", type=int, default=1000)
     ap.add_argument("--reps", type=int, default=30)
-    ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32")
+    ap.add_argument("--dtype", choices=["f32", "bf16", "bf16h"], default="f32",
+                    help="bf16h = the bf16-storage entry points of the train step (bf16 activations on both sides: "
+                         "ecg_conv1d_fwd_bf16_yh / ecg_conv1d_bwd_data_bf16hh; weight gradient on packed n16 operands)")
     ap.add_argument("--check", action="store_true")
     ap.add_argument("--blocks", default="0,1,2,3")
     ap.add_argument("--tag", default="")
@@ -39,7 +41,8 @@ def main():
     L.call("ecg_check_device")
     call, q, f32, st = L.call, L.query, L.f32, L.stream
     N, K, pad = a.batch, 15, 7
-    peak = 2500.0 if a.dtype == "bf16" else 157.3
+    peak = 2500.0 if a.dtype.startswith("bf16") else 157.3
+    H = a.dtype == "bf16h"
     rows, total = [], 0.0
     Lc = a.length
     g = torch.Generator(device="cpu").manual_seed(5)
@@ -53,7 +56,7 @@ def main():
         Lo = Lc
         flops = 2.0 * N * co * ci * K * Lo
         need_dx = b > 0
-        if a.dtype == "bf16":
+        if a.dtype.startswith("bf16"):
             wf, wb = F.conv1d_pack_bf16(w, need_bwd=need_dx)
             ldy = Lo
         else:
@@ -65,8 +68,28 @@ def main():
         dx = torch.empty_like(x)
         dw, db = torch.empty_like(w), torch.empty_like(bias)
 
+        if H:
+            ldh = (Lc + 7) & ~7
+            PA = q("ecg_conv1d_n16_positions", Lc, K, pad, 0)
+            PX = q("ecg_conv1d_n16_positions", Lc, K, pad, 1)
+            xh = torch.zeros(N, ci, ldh, dtype=torch.bfloat16, device=dev)
+            xh[:, :, :Lc] = x.to(torch.bfloat16)
+            yh = torch.empty(N, co, ldh, dtype=torch.bfloat16, device=dev)
+            dyh = torch.zeros(N, co, PA, dtype=torch.bfloat16, device=dev)
+            dyh[:, :, :Lo] = dy[:, :, :Lo].to(torch.bfloat16)
+            dxh = torch.empty(N, ci, ldh, dtype=torch.bfloat16, device=dev)
+            G16 = (N + 15) // 16
+            dyb = torch.randn(G16 * co * PA * 16, device=dev).to(torch.bfloat16)
+            xb = torch.randn(G16 * ci * PX * 16, device=dev).to(torch.bfloat16)
+            xin_h = b > 0                      # block 0 reads the fp32 network input
+
         def fwd():
-            if a.dtype == "bf16":
+            if H:
+                P = q("ecg_conv1d_fwd_bf16_yh_stat_partials", N, ci, co, Lc, K, pad, 1 if xin_h else 0, ldh, ldh)
+                part = torch.empty(co * P * 2, device=dev)
+                call("ecg_conv1d_fwd_bf16_yh", L.ptr(xh) if xin_h else f32(x), 1 if xin_h else 0, ldh, L.ptr(wf), f32(bias),
+                     L.ptr(yh), ldh, f32(part), N, ci, co, Lc, K, pad, st())
+            elif a.dtype == "bf16":
                 P = q("ecg_conv1d_fwd_bf16_stat_partials", N, ci, co, Lc, K, pad)
                 part = torch.empty(co * P * 2, device=dev)
                 call("ecg_conv1d_fwd_bf16", f32(x), L.ptr(wf), f32(bias), f32(y), f32(part), N, ci, co, Lc, K, pad, st())
@@ -76,16 +99,22 @@ def main():
                 call("ecg_conv1d_fwd", f32(x), f32(wf), f32(bias), f32(y), f32(part), N, ci, co, Lc, K, pad, st())
 
         def dgrad():
-            if a.dtype == "bf16":
+            if H:
+                call("ecg_conv1d_bwd_data_bf16hh", L.ptr(dyh), PA, L.ptr(wb), L.ptr(dxh), ldh, N, ci, co, Lc, K, pad, st())
+            elif a.dtype == "bf16":
                 call("ecg_conv1d_bwd_data_bf16", f32(dy), L.ptr(wb), f32(dx), N, ci, co, Lc, K, pad, st())
             else:
                 call("ecg_conv1d_bwd_data_ld", f32(dy), ldy, f32(wb), f32(dx), N, ci, co, Lc, K, pad, st())
 
-        wsn = max(1, q("ecg_conv1d_bwd_weight_bf16_ws_floats" if a.dtype == "bf16" else "ecg_conv1d_bwd_weight_ws_floats",
+        wsn = max(1, q("ecg_conv1d_bwd_weight_bf16_ws_floats" if a.dtype.startswith("bf16") else "ecg_conv1d_bwd_weight_ws_floats",
                        N, ci, co, Lc, K, pad))
         ws = torch.empty(wsn, device=dev)
 
         def wgrad():
+            if H:
+                call("ecg_conv1d_bwd_weight_bias_bf16_packed", L.ptr(dyb), L.ptr(xb), f32(dw), f32(db), f32(ws), N, ci, co, Lc, K,
+                     pad, st())
+                return
             call("ecg_conv1d_bwd_weight_bias_bf16" if a.dtype == "bf16" else "ecg_conv1d_bwd_weight_bias_ld",
                  f32(dy), ldy, f32(x), f32(dw), f32(db), f32(ws), N, ci, co, Lc, K, pad, st())
 
@@ -105,7 +134,7 @@ def main():
             total += med
             rows.append({"block": b, "op": name, "us": round(med, 1), "min_us": round(ts[0], 1),
                          "tflops": round(flops / med / 1e6, 1), "frac": round(flops / med / 1e6 / peak, 3)})
-        if a.check:
+        if a.check and not H:
             xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
             br = bias.clone().requires_grad_(True)
             yr = torch.nn.functional.conv1d(xr, wr, br, padding=pad)
