@@ -697,7 +697,7 @@ ECG_API int ecg_conv1d_bwd_data_bf16h(const void *dy_bf16, int ldy, const void *
                         as_stream(stream));
 }
 
-// ... and writes dx itself as bf16 [N][C_in][ldx] (ldx even, >= L; the row padding is left unwritten): the dp that the
+// ... and writes dx itself as bf16 [N][C_in][ldx] (ldx even, >= L; the row padding is left unwritten or zeroed): the dp that the
 // previous block's ecg_bn_relu_pool_bwd_n16_yh reads
 ECG_API int ecg_conv1d_bwd_data_bf16hh(const void *dy_bf16, int ldy, const void *wb_bwd, void *dx_bf16, int ldx, int N,
                                        int C_in, int C_out, int L, int K, int pad, ecg_stream_t stream) {

@@ -827,15 +827,20 @@ def test_bf16_conv_on_bf16_activations_equals_the_fp32_io_kernels(hip, case):
     w = dev((rng.standard_normal((Co, Ci, 15)) / np.sqrt(Ci * 15)).astype(np.float32))
     b = dev(rng.standard_normal(Co).astype(np.float32))
     wb_fwd, wb_bwd = hip.conv1d_pack_bf16(w, need_bwd=True)
-    P = L.query("ecg_conv1d_fwd_bf16_stat_partials", N, Ci, Co, Lin, 15, 7)
     res = []
+    ring = L.query("ecg_conv1d_bf16_ring_tile", N, Ci, Co, Lo, 15, 7, ldx, ldy) > 0     # long rows: the bf16-input call takes the ring kernel
     for use_h in (False, True):
+        P = L.query("ecg_conv1d_fwd_bf16_yh_stat_partials", N, Ci, Co, Lin, 15, 7, 1 if use_h else 0, ldx, ldy)
         y = torch.zeros(N, Co, ldy, dtype=torch.bfloat16, device="cuda")
         part = torch.empty(Co * P * 2, device="cuda")
         L.call("ecg_conv1d_fwd_bf16_yh", L.ptr(xh) if use_h else L.f32(xr), 1 if use_h else 0, ldx, L.ptr(wb_fwd), L.f32(b),
                L.ptr(y), ldy, L.f32(part), N, Ci, Co, Lin, 15, 7, L.stream())
-        res.append((y, part))
-    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+        res.append((y, part.view(Co, P, 2)))
+    if not ring:        # the same kernel with two staging paths: bit-identical y and partials
+        assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+    else:               # two kernels, two accumulation orders: the same tensor up to rounding-boundary cases, the same sums
+        assert (res[0][0][:, :, :Lo] != res[1][0][:, :, :Lo]).float().mean().item() < 0.01
+        torch.testing.assert_close(res[0][1].double().sum(1), res[1][1].double().sum(1), rtol=2e-3, atol=2e-2)
     # input gradient: dY bf16 [N][Co][PA] -> dx fp32 (existing entry point) vs dx bf16 [N][Ci][ldx]
     PA = L.query("ecg_conv1d_n16_positions", Lo, 15, 7, 0)
     dyh = torch.zeros(N, Co, PA, dtype=torch.bfloat16, device="cuda")
@@ -844,8 +849,12 @@ def test_bf16_conv_on_bf16_activations_equals_the_fp32_io_kernels(hip, case):
     L.call("ecg_conv1d_bwd_data_bf16h", L.ptr(dyh), PA, L.ptr(wb_bwd), L.f32(dx32), N, Ci, Co, Lin, 15, 7, L.stream())
     dxh = torch.full((N, Ci, ldx), 3.0, dtype=torch.bfloat16, device="cuda")
     L.call("ecg_conv1d_bwd_data_bf16hh", L.ptr(dyh), PA, L.ptr(wb_bwd), L.ptr(dxh), ldx, N, Ci, Co, Lin, 15, 7, L.stream())
-    assert torch.equal(dxh[:, :, :Lin], dx32.to(torch.bfloat16))
-    assert bool((dxh[:, :, Lin:].float() == 3.0).all())            # the row padding is not written
+    if L.query("ecg_conv1d_bf16_ring_tile", N, Co, Ci, Lin, 15, 7, PA, ldx) == 0:
+        assert torch.equal(dxh[:, :, :Lin], dx32.to(torch.bfloat16))
+    else:
+        assert (dxh[:, :, :Lin] != dx32.to(torch.bfloat16)).float().mean().item() < 0.01
+    padv = dxh[:, :, Lin:].float()
+    assert bool(((padv == 3.0) | (padv == 0.0)).all())             # the row padding is left alone or zeroed, never garbage
     with pytest.raises(L.EcgHipError, match="even dx row stride"):
         L.call("ecg_conv1d_bwd_data_bf16hh", L.ptr(dyh), PA, L.ptr(wb_bwd), L.ptr(dxh), Lin | 1, N, Ci, Co, Lin, 15, 7,
                L.stream())
