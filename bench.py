@@ -218,14 +218,20 @@ def pmc_traffic(key):
     return _PMC["entries"][key], f"profiles/pmc_traffic.json ({meta.get('source')}, commit {meta.get('commit')})"
 
 
+OTHER_ROWS = []          # the non-conv entry points of the last layer_table() call (BatchNorm / pool passes, tail, loss, optimizer, packs)
+
+
 def layer_table(timings):
     """Instrumented pass -> one row per (conv entry point, layer): live µs per call (all launches of the entry
     point, e.g. weight-gradient MFMA kernel + slab reduce), TFLOP/s, fraction of the MFMA peak for its operand
     type, algorithmic bytes and, when a matching counter collection is committed, HBM traffic / algorithmic."""
     rows, other_ms, n_steps = [], 0.0, None
+    OTHER_ROWS.clear()
     for (name, sig), ms in timings.items():
         if name not in CONV_ENTRY:
             other_ms += sum(ms)
+            OTHER_ROWS.append({"entry": f"{name}{list(sig)}", "calls": len(ms), "avg_us": round(sum(ms) / len(ms) * 1e3, 2),
+                               "group": "bn_pool" if name.startswith("ecg_bn_") else "rest"})
             continue
         op, dt = CONV_ENTRY[name]
         N, ci, co, Lc, K, pad = sig[-6:]
@@ -480,6 +486,8 @@ def build_line(primary, also, cpu, rccl, *, n_gpus, steps, warmup, batch, length
             row["frac"] = leg["roofline"]["frac"] if leg.get("roofline") else None
             row["step_frac"] = leg["step_frac_of_mfma_peak"]
             row["other_ms"] = leg["instrumented_ms_per_step"]["everything_else"]
+            row["bn_pool_ms"] = leg["instrumented_ms_per_step"].get("bn_pool_passes")
+            row["host_gap_ms"] = leg["instrumented_ms_per_step"].get("host_gap")
             if "exchange_exposed_ms_per_step" in leg:
                 row["exchange_exposed_ms"] = leg["exchange_exposed_ms_per_step"]["median"]
             if "exchange" in leg:
@@ -678,6 +686,8 @@ def main():
         value = world * B * spec["steps"] / elapsed
         fwd_f, step_f = conv_flops_per_window(T)
         peak = PEAK_BF16_TFLOPS if bf16 else PEAK_F32_TFLOPS
+        passes = sorted(OTHER_ROWS, key=lambda r: -r["avg_us"] * r["calls"])
+        bn_ms = sum(r["avg_us"] * r["calls"] for r in passes if r["group"] == "bn_pool") / 1e3
         res = {
             "workload": (f"{'ECGMultimodal (FiLM)' if demo else f'ECGCNN({labels})'} train step fwd+BCE+bwd+AdamW, 12x{T}, "
                          f"{'bf16 conv operands' if bf16 else 'fp32'}, batch {B}/GPU, global batch {B * world}"),
@@ -696,8 +706,13 @@ def main():
             "step_conv_tflops": round(value * step_f / 1e12, 2),
             "step_frac_of_mfma_peak": round(value * step_f / 1e12 / (peak * world), 4),
             "roofline": roofline_of(rows), "layers": rows,
+            # everything_else = BatchNorm/pool passes (HBM-bound streams) + the rest (tail, loss, optimizer, weight packs);
+            # host_gap = step time the GPU spends on none of them (launch gaps: the eager loop is host-bound when > 0)
             "instrumented_ms_per_step": {"conv_entry_points": round(conv_ms / n_instr, 4),
-                                         "everything_else": round(other_ms / n_instr, 4)},
+                                         "everything_else": round(other_ms / n_instr, 4),
+                                         "bn_pool_passes": round(bn_ms / n_instr, 4),
+                                         "host_gap": round(max(0.0, 1e3 * elapsed / spec["steps"] - (conv_ms + other_ms) / n_instr), 4)},
+            "passes": passes,
         }
         if exch:
             torch.cuda.synchronize()

@@ -186,12 +186,20 @@ __global__ __launch_bounds__(kBlock) void bn_relu_pool_gap_fwd_kernel(
     for (int n = n0 + (threadIdx.x >> 6); n < n1; n += 4) {
         const size_t row = (size_t)n * C + c;
         float a = 0.f;
-        for (int j = lane; j < Lp; j += 64) {
-            float r0, r1;
-            ld_pair_y<false, YH>(y, row, ldy, 2 * j, r0, r1);
-            float a0 = bn_apply1(r0, mu, sc, be), a1 = bn_apply1(r1, mu, sc, be);
-            float m = a1 > a0 ? a1 : a0;
-            a += m > 0.f ? m : 0.f;
+        // eight pair loads in flight per lane (unconditional, clamped); a lane still adds its pairs in ascending order
+        // (one load per loop trip left this pass latency-bound: 82 MB in 25 us on the last block of 12x5000)
+        constexpr int U = 8;
+        for (int j0 = lane; j0 < Lp; j0 += 64 * U) {
+            float r0[U], r1[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) ld_pair_y<false, YH>(y, row, ldy, 2 * min(j0 + 64 * u, Lp - 1), r0[u], r1[u]);
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const float a0 = bn_apply1(r0[u], mu, sc, be), a1 = bn_apply1(r1[u], mu, sc, be);
+                float m = a1 > a0 ? a1 : a0;
+                m = m > 0.f ? m : 0.f;
+                a += (j0 + 64 * u < Lp) ? m : 0.f;
+            }
         }
         a = wave_sum(a);
         if (lane == 0) g[row] = a / (float)Lp;
@@ -419,11 +427,15 @@ __global__ __launch_bounds__(kBlock) void bn_relu_pool_fwd_n16_kernel(
     const float *__restrict__ mean, const float *__restrict__ invstd, float *__restrict__ p,
     u16n *__restrict__ pb, int N, int C, int L, int Lp, int PX, int shift, BnFin fin, int ldyy,
     u16n *__restrict__ ph, int ldp) {
-    const int pos = blockIdx.x * kBlock + threadIdx.x, c = blockIdx.y, g = blockIdx.z;
+    // grid = (ceil(G * PX / 256), C): the (sample group, position) pairs of a channel are walked FLAT — a grid of
+    // ceil(PX / 256) blocks per group left up to a third of the threads idle on the short rows of the deep blocks
+    // (PX = 656: 3 blocks = 768 threads)
+    const int flat = blockIdx.x * kBlock + threadIdx.x, c = blockIdx.y;
+    const int g = flat / PX, pos = flat - g * PX;
     float mu, is;
-    if (FIN) bn_finalize_block(fin, c, blockIdx.x == 0 && g == 0, mu, is);
+    if (FIN) bn_finalize_block(fin, c, blockIdx.x == 0, mu, is);
     else { mu = mean[c]; is = invstd[c]; }
-    if (pos >= PX) return;
+    if (g >= (N + 15) / 16) return;
     const float sc = is * gamma[c], be = beta[c];
     const int j = pos - shift;
     const bool in_row = (j >= 0) && (j < Lp);
@@ -462,7 +474,10 @@ __global__ __launch_bounds__(kBlock) void bn_bwd_dx_n16_kernel(
     int C, int L, float bcast, int train, unsigned *__restrict__ dyh, int ldyy, int ldp) {
     __shared__ double red[4][2];
     __shared__ float kk[2];
-    const int c = blockIdx.y, g = blockIdx.z, tl = threadIdx.x;
+    // grid = (ceil(G * PA/2 / 256), C): flat walk over (sample group, output pair) of a channel (rows of 625 have 320
+    // pairs: one block per 256 pairs and group left 37 % of the threads idle)
+    const int c = blockIdx.y, tl = threadIdx.x;
+    const int HP = PA >> 1, flat = blockIdx.x * kBlock + tl, g = flat / HP;
     {
         double a = 0.0, q = 0.0;
         for (int pp = tl; pp < S; pp += kBlock) {
@@ -475,7 +490,7 @@ __global__ __launch_bounds__(kBlock) void bn_bwd_dx_n16_kernel(
         if (tl == 0) {
             a = ((red[0][0] + red[1][0]) + red[2][0]) + red[3][0];
             q = ((red[0][1] + red[1][1]) + red[2][1]) + red[3][1];
-            if (blockIdx.x == 0 && g == 0) {
+            if (blockIdx.x == 0) {
                 if (dbeta) dbeta[c] = (float)a;
                 if (dgamma) dgamma[c] = (float)q;
             }
@@ -484,8 +499,8 @@ __global__ __launch_bounds__(kBlock) void bn_bwd_dx_n16_kernel(
         }
         __syncthreads();
     }
-    const int j = blockIdx.x * kBlock + tl, t0 = 2 * j;
-    if (t0 >= PA) return;
+    const int j = flat - g * HP, t0 = 2 * j;
+    if (g >= (N + 15) / 16) return;
     const float k1 = kk[0], k2 = kk[1];
     const float mu = mean[c], is = invstd[c], ga = gamma[c], sc = is * ga, gi = ga * is, be = beta[c];
     const int Lp = L >> 1;
@@ -679,13 +694,13 @@ static int pool_fwd_n16_impl(const BnFin *fin, const float *y, const float *gamm
     const int G = cdiv(N, 16);
     const bool al8 = pairs_aligned(y, L);
     const BnFin f = fin ? *fin : BnFin{};
-#define ECG_POOLN(FIN, AL8) hipLaunchKernelGGL((bn_relu_pool_fwd_n16_kernel<FIN, AL8>), dim3(cdiv(PX, kBlock), C, G), \
+#define ECG_POOLN(FIN, AL8) hipLaunchKernelGGL((bn_relu_pool_fwd_n16_kernel<FIN, AL8>), dim3(cdiv((long long)G * PX, kBlock), C), \
                                                dim3(kBlock), 0, st, y, gamma, beta, mean, invstd, p,                   \
                                                static_cast<u16n *>(p_n16), N, C, L, Lp, PX, shift, f, L, nullptr, 0)
     ECG_REQUIRE(!p_bf16 || (yh && ldp >= Lp && ldp % 2 == 0 && ldp <= PX - shift),
                 "bn_relu_pool_fwd_n16: the bf16 copy of p needs an even row stride in [L/2, PX - shift]");
     if (yh)
-        hipLaunchKernelGGL((bn_relu_pool_fwd_n16_kernel<true, true, true>), dim3(cdiv(PX, kBlock), C, G), dim3(kBlock), 0, st,
+        hipLaunchKernelGGL((bn_relu_pool_fwd_n16_kernel<true, true, true>), dim3(cdiv((long long)G * PX, kBlock), C), dim3(kBlock), 0, st,
                            y, gamma, beta, mean, invstd, p, static_cast<u16n *>(p_n16), N, C, L, Lp, PX, shift, f, ldy,
                            static_cast<u16n *>(p_bf16), ldp);
     else if (fin) { if (al8) ECG_POOLN(true, true); else ECG_POOLN(true, false); }
@@ -920,7 +935,7 @@ static int bwd_n16_impl(const char *who, const float *y, bool yh, int ldyy, cons
     rc = check_launch("bn_bwd_reduce_kernel");
     if (rc) return rc;
     const int G = cdiv(N, 16);
-#define ECG_DXN(AL8, YH, DH) hipLaunchKernelGGL((bn_bwd_dx_n16_kernel<AL8, YH, DH>), dim3(cdiv(PA / 2, kBlock), C, G),        \
+#define ECG_DXN(AL8, YH, DH) hipLaunchKernelGGL((bn_bwd_dx_n16_kernel<AL8, YH, DH>), dim3(cdiv((long long)G * (PA / 2), kBlock), C), \
                                                 dim3(kBlock), 0, st, y, dp, gamma, beta, mean, invstd, ws, S, (double)N * L,  \
                                                 dgamma, dbeta, dy, ldy, static_cast<u16n *>(dy_n16), PA, N, C, L, bcast,     \
                                                 train, static_cast<unsigned *>(dy_bf16), yh ? ldyy : L, ldp)
