@@ -1,27 +1,27 @@
 #!/bin/bash
 # Collect the round's measurement artefacts on the GPU box (run from the repo root through gpurun):
-#   bash tools/collect_profiles.sh r02 [quick]
+#   bash tools/collect_profiles.sh r03 [quick]
 # Writes under gpurun_out/: the bench line, a rocprofv3 --kernel-trace --stats run of bench.py, and three
 # separate --pmc passes of tools/pmc_step.py (FETCH_SIZE / WRITE_SIZE / MFMA-busy; counters are never combined
 # with other trace domains).  tools/make_profile_artifacts.py turns them into the files committed under profiles/.
 set -o pipefail
-TAG=${1:-r02}
+TAG=${1:-r03}
 R=$PWD
 O=$R/gpurun_out
 mkdir -p "$O"
 rm -rf "$O/prof_$TAG" "$O/pmc_fetch_$TAG" "$O/pmc_write_$TAG" "$O/pmc_sq_$TAG"
-python bench.py --steps 100 --warmup 20 > "$O/${TAG}_bench.json" 2> "$O/${TAG}_bench.err" || exit 1
+python bench.py --steps 100 --warmup 20 --detail "$O/${TAG}_bench_detail.json" > "$O/${TAG}_bench.json" 2> "$O/${TAG}_bench.err" || exit 1
 echo "bench done"
 if [ "$2" != "quick" ]; then
-python bench.py --steps 20 --warmup 5 > "$O/${TAG}_bench_driver_form.json" 2>/dev/null || exit 1
-python bench.py --steps 50 --warmup 10 --graph --no-cpu-baseline --no-also > "$O/${TAG}_bench_graph_replay.json" 2>/dev/null || exit 1
-python bench.py --steps 100 --warmup 20 --dtype bf16 --graph --no-cpu-baseline --no-also > "$O/${TAG}_bench_bf16_graph_replay.json" 2>/dev/null || exit 1
+python bench.py --steps 20 --warmup 5 --detail "$O/${TAG}_bench_driver_form_detail.json" > "$O/${TAG}_bench_driver_form.json" 2>/dev/null || exit 1
+python bench.py --steps 50 --warmup 10 --graph --no-cpu-baseline --no-also --detail "$O/${TAG}_bench_graph_replay_detail.json" > "$O/${TAG}_bench_graph_replay.json" 2>/dev/null || exit 1
+python bench.py --steps 100 --warmup 20 --dtype bf16 --graph --no-cpu-baseline --no-also --detail "$O/${TAG}_bench_bf16_graph_replay_detail.json" > "$O/${TAG}_bench_bf16_graph_replay.json" 2>/dev/null || exit 1
 python bench.py --workload input > "$O/${TAG}_input_pipeline.json" 2>/dev/null || exit 1
 python tools/bench_eval.py > "$O/${TAG}_inference.json" 2>/dev/null || exit 1
 echo "variants done"
 fi
 cd /tmp && export TMPDIR=/tmp
-B="$R/bench.py --no-cpu-baseline --no-also"
+B="$R/bench.py --no-cpu-baseline --no-also --priming-seconds 0 --detail $O/prof_${TAG}_detail.json"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/prof_$TAG" -- python3 $B --steps 20 --warmup 5 --priming 0 > "$O/prof_$TAG.json" 2> "$O/prof_$TAG.err" || exit 1
 echo "kernel trace done"
 S="$R/tools/pmc_step.py"

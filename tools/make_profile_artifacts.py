@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Turn gpurun_out/ of tools/collect_profiles.sh into the artefacts committed under profiles/.
 
-    python tools/make_profile_artifacts.py r02
+    python tools/make_profile_artifacts.py r03
 
 profiles/<tag>_bench*.json            the bench lines as printed
 profiles/<tag>_kernel_stats.csv       rocprofv3 --stats table of the bench command
@@ -27,7 +27,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-TAG = sys.argv[1] if len(sys.argv) > 1 else "r02"
+TAG = sys.argv[1] if len(sys.argv) > 1 else "r03"
 OUT, PROF = os.path.join(ROOT, "gpurun_out"), os.path.join(ROOT, "profiles")
 MARKER = "relu_fwd_kernel"
 
