@@ -23,6 +23,7 @@
 //                      wgrad_reduce_kernel sums in fixed order, like the fp32 kernel.
 // Replaces autograd's conv weight-gradient (reference src/models/ecg_cnn.py:13 via loss.backward()).
 #include "common.h"
+#include <cstdlib>
 
 namespace ecg {
 
@@ -246,10 +247,266 @@ __global__ __launch_bounds__(256, 3) void conv1d_wgrad_bf16_kernel(
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Round 3: the same reduction on LARGE tiles with a double-buffered stage pipeline (one workgroup of eight waves per CU).
+// The kernel above (64 x 128 tiles, one LDS image, three workgroups per CU covering for each other) sits at 0.24-0.34 of
+// the bf16 peak: every (co, t) granule of dY is pulled L2 -> LDS once per 128 columns, and a workgroup's DMA round trip is
+// exposed at every stage.  Here a tile is M_T x 512 columns (the dY tile is re-used 4x more), a stage is (sample group,
+// 8 time steps), the next stage's two operand tiles stream into the other LDS image while this one is multiplied (asm
+// LDS-DMA: see conv1d_bf16_ring.hip for why not the builtin), one vmcnt(0) + barrier per stage — the pieces were
+// issued in the first half of the stage — and the step loop carries explicit counted lgkmcnt waits.
+// Images: dY [M_T][16 slots] (row co: slot 2t + half at slot ^ (co & 15)); x [NCI][kXP] granules as above.
+template <int M_T, int WM, int WR>
+__global__ __launch_bounds__(512) void conv1d_wgrad_bf16_ring_kernel(
+    const u16 *__restrict__ dyb, const u16 *__restrict__ xb, float *__restrict__ slab, int G, int Cin,
+    int Cout, int PA, int PX, int S) {
+    static_assert(WM * WR == 8, "8 waves per workgroup");
+    constexpr int KK = kKW, R_T = 512, TS = 8;
+    constexpr int MC = M_T / WM / 32, MR = R_T / WR / 32;
+    static_assert(MC == 2 && (MR == 4 || MR == 2), "wave tile 64 x 128 or 64 x 64");
+    constexpr int NCI = (R_T + KK - 2) / KK + 1;
+    constexpr int ASLOTS = TS * M_T * 2;                   // 16-byte slots of the dY image
+    constexpr int BSLOTS = NCI * kXP * 2;
+    constexpr int ADMA = ASLOTS / 64, BDMA = (BSLOTS + 63) / 64;
+    constexpr int APW = ADMA / 8, BPW = (BDMA + 7) / 8;    // DMA pieces per wave per stage
+    static_assert(ADMA % 8 == 0, "dY image must split evenly over the eight waves");
+    // The x image spans 16 time steps (+ 14 of halo = kXP - 1): it serves TWO stages and is re-streamed only when the next
+    // stage starts a new 16-step block — per stage the dY tile is 32 KB (M_T = 128) and the x tile 35 KB of which 9 KB are
+    // new, so streaming it every stage would double the LDS-DMA work.  Two dY images and two x images, flipped separately.
+    constexpr int AIMG = ASLOTS * 16, BIMG = BDMA * 64 * 16;
+    static_assert(2 * (AIMG + BIMG) <= 160 * 1024, "LDS");
+    static_assert(APW + BPW <= 2 * TS, "at most two DMA pieces per time step");
+    static_assert(kTW == 2 * TS && kXP >= kTW + KK - 1, "an x image covers two stages");
+
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[2 * (AIMG + BIMG)];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int half = lane >> 5, l31 = lane & 31;
+    const int R = Cin * KK;
+    const int RT = (R + R_T - 1) / R_T, CT = Cout / M_T;
+    int tile;
+    {
+        const int nwg = gridDim.x, bid = blockIdx.x;
+        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+        tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    }
+    const int tile_r = tile % RT, tile_cs = tile / RT;
+    const int r0 = tile_r * R_T, co0 = (tile_cs % CT) * M_T, s = tile_cs / CT;
+    const int wr = wave % WR, wm = wave / WR;
+    const int wm0 = wm * (M_T / WM), wr0 = wr * (R_T / WR);
+    const int ci_base = r0 / KK;
+    const int ntt = PA / TS;
+    const int total = G * ntt;
+    const int st_begin = (int)((long long)total * s / S), st_end = (int)((long long)total * (s + 1) / S);
+
+    // fragment addressing: byte offsets inside an image
+    int aoffl[MC], boffl[MR];
+#pragma unroll
+    for (int i = 0; i < MC; ++i) aoffl[i] = (wm0 + 32 * i + l31) * (2 * TS) * 16;        // + ((2t + half) ^ (co & 15)) * 16
+    const int asw = l31 & 15;                               // (wm0 + 32 i) is a multiple of 16: co & 15 = l31 & 15
+#pragma unroll
+    for (int j = 0; j < MR; ++j) {
+        int r = r0 + wr0 + 32 * j + l31;
+        if (r >= R) r = R - 1;                              // clamped columns compute garbage that is never stored
+        const int ci = r / KK;
+        boffl[j] = (ci - ci_base) * kXP + (r - ci * KK);    // granule index before the time offset
+    }
+
+    f32x16 acc[MC][MR];
+#pragma unroll
+    for (int a = 0; a < MC; ++a)
+#pragma unroll
+        for (int b = 0; b < MR; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+    float bsum[MC];
+#pragma unroll
+    for (int a = 0; a < MC; ++a) bsum[a] = 0.f;
+    // db rides on the dY fragments of the workgroups of column tile 0; the WR waves that hold the same channel rows take
+    // every WR-th time step each (on two of eight waves the unpack + add work delayed the whole workgroup at every barrier)
+    const bool want_bias = (tile_r == 0);
+
+    // ---- DMA geometry (loop-invariant per lane) ---------------------------------------------------------
+    int aoff[APW], brow[BPW], bpos[BPW], bhalf[BPW];
+#pragma unroll
+    for (int j = 0; j < APW; ++j) {
+        const int sl = (j * 8 + wave) * 64 + lane;
+        const int co = sl / (2 * TS), ls = sl - co * (2 * TS);
+        const int gs = ls ^ (co & 15);                      // LDS slot ls of row co holds global slot 2t + half
+        aoff[j] = ((co * PA + (gs >> 1)) * 16 + 8 * (gs & 1)) * 2;       // bytes
+    }
+#pragma unroll
+    for (int j = 0; j < BPW; ++j) {
+        const int sl = min((j * 8 + wave) * 64 + lane, BSLOTS - 1);
+        // x image WITHOUT the half swap of the kernel above: slot = 2 * granule + half.  Two granules 8 apart then share
+        // their banks (2-way conflict on the x fragment reads, the LDS is ~20 % busy in this kernel), but a fragment's
+        // address becomes base + 32 t: an instruction offset instead of four VALU instructions per read — with two waves per
+        // SIMD the loop was bound by vector ISSUE (5 VALU per MFMA), not by the matrix pipe.
+        const int qb = sl >> 1, h = sl & 1;
+        const int cl = qb / kXP;
+        brow[j] = min(ci_base + cl, Cin - 1) * PX;
+        bpos[j] = qb - cl * kXP;
+        bhalf[j] = 16 * h;                                  // bytes
+    }
+    const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)lds;
+    // LDS-DMA piece: wave-uniform 64-bit base in SGPRs + a per-lane 32-bit BYTE offset (no 64-bit VALU address math)
+    auto glds = [&](const u16 *base, unsigned voff, unsigned dst_off) __attribute__((always_inline)) {
+        const unsigned dst = (unsigned)__builtin_amdgcn_readfirstlane((int)(lds_base + dst_off));   // wave-uniform by construction
+        unsigned keep;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(voff), "s"(base), "s"(dst) : "memory");
+    };
+    // stage coordinates of the stage whose tiles are DMA'd next
+    int dg = st_begin / ntt, dt0 = (st_begin - dg * ntt) * TS;
+    // piece j (0 .. APW + BPW - 1) of stage (dg, dt0): dY pieces into dY image `aimg`; x pieces — only when the stage opens a
+    // new 16-step block (uniform) — into x image `bimg`
+    auto dma_piece = [&](int j, int aimg, int bimg) __attribute__((always_inline)) {
+        if (j < APW) {
+            const u16 *abase = dyb + (((size_t)dg * Cout + co0) * PA + dt0) * 16;          // uniform
+            glds(abase, (unsigned)aoff[j], (unsigned)(aimg * AIMG + (j * 8 + wave) * 1024));
+        } else {
+            const int jb = j - APW;
+            if ((dt0 & (kTW - 1)) == 0 && jb * 8 + wave < BDMA) {
+                // granules past the end of the x row (only reached by the slots nobody reads) are clamped into it
+                const u16 *bbase = xb + (size_t)dg * Cin * PX * 16;                        // uniform
+                const unsigned voff = (unsigned)(brow[jb] + min(dt0 + bpos[jb], PX - 1)) * 32u + (unsigned)bhalf[jb];
+                glds(bbase, voff, (unsigned)(2 * AIMG + bimg * BIMG + (jb * 8 + wave) * 1024));
+            }
+        }
+    };
+    auto dma_advance = [&]() __attribute__((always_inline)) {
+        dt0 += TS;
+        if (dt0 >= PA) { dt0 = 0; ++dg; }
+        if (dg >= G) { dg = G - 1; dt0 = PA - TS; }          // past the end: restage a valid tile nobody reads
+    };
+
+    int bcur = 0;                                           // x image that holds the block of the stage being multiplied
+    int ct0 = dt0;                                          // first time step of the stage being multiplied
+    if (st_begin < st_end) {
+        // the first stage may start in the middle of a 16-step block: stream the x block from its start
+        const int keep = dt0;
+        dt0 &= ~(kTW - 1);
+#pragma unroll
+        for (int j = APW; j < APW + BPW; ++j) dma_piece(j, 0, 0);
+        dt0 = keep;
+#pragma unroll
+        for (int j = 0; j < APW; ++j) dma_piece(j, 0, 0);
+        dma_advance();
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    for (int st = st_begin; st < st_end; ++st) {
+        const int img = (st - st_begin) & 1;
+        const bool new_block = (dt0 & (kTW - 1)) == 0;      // the NEXT stage opens a new x block (uniform)
+        const int bnext = new_block ? bcur ^ 1 : bcur;
+        const int abase_l = img * AIMG, bbase_l = 2 * AIMG + bcur * BIMG;
+        const int tb = ct0 & TS;                            // second stage of a block: its granules start 8 further in
+        // (the per-lane terms are made opaque where they are used: left alone, hipcc precomputes one address register per
+        // (time step, fragment) — 48 of them — and spills)
+        auto ld_a = [&](int t, int i) __attribute__((always_inline)) {
+            int sw = asw;
+            asm volatile("" : "+v"(sw));
+            return *reinterpret_cast<const bf16x8 *>(&lds[abase_l + aoffl[0] + (((2 * t + half) ^ sw) << 4) + i * (32 * 2 * TS * 16)]);
+        };
+        int bl[MR];                                         // this stage's x fragment bases: + 32 t is an instruction offset
+#pragma unroll
+        for (int j = 0; j < MR; ++j) {
+            bl[j] = bbase_l + (boffl[j] + tb) * 32 + half * 16;
+            asm volatile("" : "+v"(bl[j]));
+        }
+        auto ld_b = [&](int t, int j) __attribute__((always_inline)) {
+            return *reinterpret_cast<const bf16x8 *>(&lds[bl[j] + 32 * t]);
+        };
+        bf16x8 a_c[MC], a_n[MC], b_c[MR];
+#pragma unroll
+        for (int i = 0; i < MC; ++i) a_c[i] = ld_a(0, i);
+#pragma unroll
+        for (int j = 0; j < MR; ++j) b_c[j] = ld_b(0, j);
+#pragma unroll
+        for (int t = 0; t < TS; ++t) {
+            if (2 * t < APW + BPW) dma_piece(2 * t, img ^ 1, bnext);            // the next stage's tiles, two pieces per time step
+            if (2 * t + 1 < APW + BPW) dma_piece(2 * t + 1, img ^ 1, bnext);    // (all issued in the first half of the stage)
+            const int tn = t + 1 < TS ? t + 1 : TS - 1;      // (the last step re-reads its own fragments: unused)
+#pragma unroll
+            for (int i = 0; i < MC; ++i) a_n[i] = ld_a(tn, i);
+            if (want_bias && (t % WR) == wr) {               // (bf16-rounded dY, fp32 sum)
+#pragma unroll
+                for (int i = 0; i < MC; ++i)
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) bsum[i] += (float)a_c[i][e];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < MR; ++j) {
+                // issued since fragment j of this step was read: the other MR - 1 x fragments and the MC dY fragments
+                if (MR == 4) __builtin_amdgcn_s_waitcnt(0xC07F | (5 << 8)); else __builtin_amdgcn_s_waitcnt(0xC07F | (3 << 8));
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int i = 0; i < MC; ++i)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_c[i], b_c[j], acc[i][j], 0, 0, 0);
+                b_c[j] = ld_b(tn, j);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int i = 0; i < MC; ++i) a_c[i] = a_n[i];
+        }
+        ct0 = dt0;
+        bcur = bnext;
+        dma_advance();
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");     // this wave's pieces of the next stage have landed
+        __syncthreads();                                                 // ... everybody's; and this image is free again
+    }
+
+    if (want_bias) {                                        // uniform per workgroup; the images are dead (last barrier of the loop)
+        float *bred = reinterpret_cast<float *>(lds);
+#pragma unroll
+        for (int i = 0; i < MC; ++i) {
+            bsum[i] += __shfl_xor(bsum[i], 32, 64);
+            if (half == 0) bred[wave * (MC * 32) + 32 * i + l31] = bsum[i];
+        }
+        __syncthreads();
+        if (wr == 0) {
+#pragma unroll
+            for (int i = 0; i < MC; ++i) {
+                float t = 0.f;
+                for (int w = 0; w < WR; ++w) t += bred[(wm * WR + w) * (MC * 32) + 32 * i + l31];     // fixed order
+                bsum[i] = t;
+            }
+        }
+    }
+    const size_t wslab = (size_t)Cout * R;
+    float *out = slab + (size_t)s * wslab;
+#pragma unroll
+    for (int i = 0; i < MC; ++i)
+#pragma unroll
+        for (int j = 0; j < MR; ++j) {
+            const int r = r0 + wr0 + 32 * j + l31;
+            if (r < R) {
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    const int co = co0 + wm0 + 32 * i + acc_row_w(q, half);
+                    out[(size_t)co * R + r] = acc[i][j][q];
+                }
+            }
+        }
+    if (want_bias && wr == 0 && half == 0) {
+#pragma unroll
+        for (int i = 0; i < MC; ++i)
+            slab[(size_t)S * wslab + (size_t)s * Cout + co0 + wm0 + 32 * i + l31] = bsum[i];
+    }
+}
+
 // conv1d_direct.hip: dw[i] = sum_s slab[s][i] in fixed order
 int wgrad_reduce(const float *ws, float *dw, float *db, size_t wslab, int Cout, int S, hipStream_t st);
 
-struct WgBf16Plan { int G, PA, PX, ntt, splits; size_t dyb_elems, xb_elems, slab_floats; };
+struct WgBf16Plan { int G, PA, PX, ntt, splits, ring_mt; size_t dyb_elems, xb_elems, slab_floats; };
+
+static int wgb_ring_enabled() {
+    static const int v = [] { const char *e = getenv("ECG_WGB_RING"); return e && *e ? atoi(e) : 1; }();
+    return v;
+}
 
 static WgBf16Plan wgrad_bf16_plan(int N, int Cin, int Cout, int Lo) {
     WgBf16Plan p;
@@ -257,6 +514,22 @@ static WgBf16Plan wgrad_bf16_plan(int N, int Cin, int Cout, int Lo) {
     p.ntt = cdiv(Lo, kTW);
     p.PA = p.ntt * kTW;                  // dY rows padded to whole stages (zeros)
     p.PX = p.PA + 16;                    // x rows: conv padding baked in, +kXP-1 granules readable past the last stage
+    // the ring kernel (512-column tiles, one eight-wave workgroup per CU) for layers with at least one full column tile's
+    // worth of work per output tile; stages of 8 time steps
+    p.ring_mt = 0;
+    if (wgb_ring_enabled() && Cout % 64 == 0 && Cin * kKW >= 448 && (long long)p.G * (p.PA / 8) >= 64) {
+        p.ring_mt = Cout % 128 == 0 ? 128 : 64;
+        const int tiles = cdiv(Cin * kKW, 512) * (Cout / p.ring_mt);
+        int s = 256 / tiles;
+        const int total = p.G * (p.PA / 8);
+        if (s > total / 8) s = total / 8;
+        if (s < 1) s = 1;
+        p.splits = s;
+        p.dyb_elems = (size_t)p.G * Cout * p.PA * 16;
+        p.xb_elems = (size_t)p.G * Cin * p.PX * 16;
+        p.slab_floats = (size_t)s * ((size_t)Cout * Cin * kKW + Cout);
+        return p;
+    }
     const int m_t = Cout % 64 == 0 ? 64 : 32, r_t = Cout % 64 == 0 ? 128 : 256;
     const int tiles = cdiv(Cin * kKW, r_t) * (Cout / m_t);
     int s = 768 / tiles;                 // 3 resident workgroups per CU ...
@@ -285,6 +558,18 @@ size_t wgrad_bf16_ws_floats(int N, int Cin, int Cout, int L, int K, int pad) {
 static int wgrad_bf16_run(const u16 *dyb, const u16 *xb, float *dw, float *db, float *slab, const WgBf16Plan &p,
                           int Cin, int Cout, int K, hipStream_t st) {
     const int R = Cin * K;
+    if (p.ring_mt) {
+        dim3 grid((unsigned)(cdiv(R, 512) * (Cout / p.ring_mt) * p.splits)), block(512);
+        if (p.ring_mt == 128)
+            hipLaunchKernelGGL((conv1d_wgrad_bf16_ring_kernel<128, 2, 4>), grid, block, 0, st, dyb, xb, slab, p.G, Cin, Cout,
+                               p.PA, p.PX, p.splits);
+        else
+            hipLaunchKernelGGL((conv1d_wgrad_bf16_ring_kernel<64, 1, 8>), grid, block, 0, st, dyb, xb, slab, p.G, Cin, Cout,
+                               p.PA, p.PX, p.splits);
+        int rc = check_launch("conv1d_wgrad_bf16_ring_kernel");
+        if (rc) return rc;
+        return wgrad_reduce(slab, dw, db, (size_t)Cout * R, Cout, p.splits, st);
+    }
     dim3 block(256);
     if (Cout % 64 == 0) {
         dim3 grid((unsigned)(cdiv(R, 128) * (Cout / 64) * p.splits));
