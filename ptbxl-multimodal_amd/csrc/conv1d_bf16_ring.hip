@@ -167,8 +167,6 @@ __global__ __launch_bounds__(NT) void conv1d_bf16_ring_kernel(
     // ---- weight stream -------------------------------------------------------------------------------------
     // global slice of tap f (flat inside the tile's reduction): wb + f * Cout * 32 bytes, rows co0 .. co0 + CO_T
     // LDS row r of a slice holds global half h at half position h ^ bit3(r)  (swizzle on the SOURCE address)
-    const unsigned char *const wsrc = reinterpret_cast<const unsigned char *>(wb) + (size_t)co0 * 32 +
-                                      (lane >> 1) * 32 + (((lane & 1) ^ ((lane >> 4) & 1)) << 4);
     const size_t tap_bytes = (size_t)Cout * 32;
     // The LDS-DMA is issued from INLINE ASM: hipcc models __builtin_amdgcn_global_load_lds like a FLAT access, and then waits
     // vmcnt(0) / lgkmcnt(0) for every load and LDS read that was pending when one issued (39 + 4 full drains per 30 taps in
@@ -176,12 +174,15 @@ __global__ __launch_bounds__(NT) void conv1d_bf16_ring_kernel(
     // protect but LDS, which the counted vmcnt + barrier at the group starts orders).  M0 is saved and restored inside
     // the statement (the compiler owns it).
     const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)lds;
+    // source = wave-uniform 64-bit base (SGPR pair: tap slice + row block) + this lane's 32-bit byte offset inside the piece
+    const unsigned wlane = (unsigned)((lane >> 1) * 32 + (((lane & 1) ^ ((lane >> 4) & 1)) << 4));
+    const unsigned char *const wtile = reinterpret_cast<const unsigned char *>(wb) + (size_t)co0 * 32;
     auto dma_piece = [&](int f, int rb, unsigned dst_off) __attribute__((always_inline)) {   // rows rb*32 .. +31 of tap f -> 1 KB at lds + dst_off
-        const unsigned char *src = wsrc + (size_t)f * tap_bytes + rb * 1024;
-        const unsigned dst = lds_base + dst_off;
+        const unsigned char *src = wtile + (size_t)f * tap_bytes + rb * 1024;                // uniform
+        const unsigned dst = (unsigned)__builtin_amdgcn_readfirstlane((int)(lds_base + dst_off));
         unsigned keep;
-        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                     : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(wlane), "s"(src), "s"(dst) : "memory");
     };
     int wtap = 0;                                        // ring: first tap (mod KT) of the NEXT group to issue
     auto dma_group = [&](int slot) __attribute__((always_inline)) {
@@ -361,8 +362,9 @@ __global__ __launch_bounds__(NT) void conv1d_bf16_ring_kernel(
     // too short to cover an LDS read two steps ahead).
     constexpr int XW = MC == 2 ? 3 : MT;
     bf16x8 xa[XW], wf[MC], wn[MC];
+    int xb_carry = x_base(0, 0);                         // x fragment base of the tap about to be multiplied
     {
-        const int xb0 = x_base(0, 0);
+        const int xb0 = xb_carry;
 #pragma unroll
         for (int i = 0; i < MC; ++i) wf[i] = ld_w(woff_lane, i);        // tap 0 of chunk 0: resident slice 0 / slot 0, tap 0
         if constexpr (MC == 2) { xa[0] = ld_x(xb0, 0, 0); xa[1] = ld_x(xb0, 0, 1); }
@@ -421,10 +423,11 @@ __global__ __launch_bounds__(NT) void conv1d_bf16_ring_kernel(
                     int wbase_n;
                     if constexpr (RES) wbase_n = (k + 1 < KK) ? wres_lane + (k + 1) * (CO_T * 32) : wres_next_lane;
                     else wbase_n = woff_lane + ((un / GT) % NSLOT) * SLOTB + (un % GT) * (CO_T * 32);
+                    const int xbase_c = xb_carry;                         // computed by the previous tap
                     const int xbase_n = x_base((k + 1 < KK) ? par : npar, kn);
+                    xb_carry = xbase_n;
                     // ---- MFMAs of this tap ----
                     if constexpr (MC == 2) {
-                        const int xbase_c = x_base(par, k);
                         static_for<MT>([&](auto J_) __attribute__((always_inline)) {
                             constexpr int j = decltype(J_)::value;
                             constexpr int sj = (5 * u + j) % 3;                  // register set of fragment j
