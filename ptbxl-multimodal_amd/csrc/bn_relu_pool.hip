@@ -186,20 +186,14 @@ __global__ __launch_bounds__(kBlock) void bn_relu_pool_gap_fwd_kernel(
     for (int n = n0 + (threadIdx.x >> 6); n < n1; n += 4) {
         const size_t row = (size_t)n * C + c;
         float a = 0.f;
-        // eight pair loads in flight per lane (unconditional, clamped); a lane still adds its pairs in ascending order
-        // (one load per loop trip left this pass latency-bound: 82 MB in 25 us on the last block of 12x5000)
-        constexpr int U = 8;
-        for (int j0 = lane; j0 < Lp; j0 += 64 * U) {
-            float r0[U], r1[U];
-#pragma unroll
-            for (int u = 0; u < U; ++u) ld_pair_y<false, YH>(y, row, ldy, 2 * min(j0 + 64 * u, Lp - 1), r0[u], r1[u]);
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const float a0 = bn_apply1(r0[u], mu, sc, be), a1 = bn_apply1(r1[u], mu, sc, be);
-                float m = a1 > a0 ? a1 : a0;
-                m = m > 0.f ? m : 0.f;
-                a += (j0 + 64 * u < Lp) ? m : 0.f;
-            }
+        // (eight clamped pair loads in flight per lane instead of one per trip were measured on the 312-pair rows of 12x5000:
+        // 25.4 vs 25.0 us, and on the 62-pair rows of 12x1000 they doubled the pass: 11.7 -> 22.9 us — not adopted)
+        for (int j = lane; j < Lp; j += 64) {
+            float r0, r1;
+            ld_pair_y<false, YH>(y, row, ldy, 2 * j, r0, r1);
+            float a0 = bn_apply1(r0, mu, sc, be), a1 = bn_apply1(r1, mu, sc, be);
+            float m = a1 > a0 ? a1 : a0;
+            a += m > 0.f ? m : 0.f;
         }
         a = wave_sum(a);
         if (lane == 0) g[row] = a / (float)Lp;
