@@ -49,6 +49,18 @@ __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
 // reads just issued for the NEXT step in front of MFMAs that only need the previous ones; an explicit counted wait
 // placed before the MFMAs tells its scoreboard the operands are complete (a count larger than the reads really in
 // flight is harmless: the compiler still adds whatever wait correctness needs).
+// One LDS-DMA piece (1 KB per wave) from INLINE ASM: wave-uniform 64-bit base in SGPRs + this lane's 32-bit byte offset ->
+// LDS byte address `dst` (wave-uniform, + 16 * lane implied).  hipcc books __builtin_amdgcn_global_load_lds like a FLAT
+// access: every LDS read that is pending when one issues is later waited for with lgkmcnt(0), together with the fragments
+// read since (22 of the 30 steps of a forward chunk).  The asm statement has no register result, so there is nothing for
+// the compiler to protect; M0 is saved and restored inside it; completion is waited for explicitly (vmcnt) before the
+// barrier that publishes the image.
+__device__ __forceinline__ void glds16(const void *base, unsigned voff, unsigned dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(base), "s"(dst) : "memory");
+}
+
 __device__ __forceinline__ void wait_lgkm_f(int n) {
     switch (n) {
         case 1: __builtin_amdgcn_s_waitcnt(0xC17F); break;
@@ -181,11 +193,12 @@ __global__ __launch_bounds__(256, 2) void conv1d_mfma_fwd_kernel(
     }
     float xreg[XLOADS];
 
+    const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) float *)lds;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
     auto dma_w = [&](int j, int ci0, float *img) {       // one 1 KB piece of the weight slice
-        if ((j * 4 + wave) < NDMA)
-            __builtin_amdgcn_global_load_lds(
-                (const __attribute__((address_space(1))) void *)(wp + (size_t)ci0 * Cout + co0 + woff[j]),
-                (__attribute__((address_space(3))) void *)(img + (j * 4 + wave) * 256), 16, 0, 0);
+        if ((j * 4 + wave_u) < NDMA)
+            glds16(wp + (size_t)ci0 * Cout + co0, (unsigned)woff[j] * 4u,
+                   (unsigned)__builtin_amdgcn_readfirstlane((int)(lds_base + (unsigned)((img - lds) + (j * 4 + wave_u) * 256) * 4u)));
     };
     auto load_x = [&](int j, int ci0) { xreg[j] = xn[(size_t)ci0 * ldx + xoff[j]]; };
     auto commit_x = [&](int j, float *img) {
@@ -207,6 +220,7 @@ __global__ __launch_bounds__(256, 2) void conv1d_mfma_fwd_kernel(
 #pragma unroll
         for (int j = 0; j < XLOADS; ++j) load_x(j, CI_C);
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // (the asm DMA pieces are not in hipcc's books)
     __syncthreads();
     ECG_STAMP_AT(1);
 
@@ -252,6 +266,7 @@ __global__ __launch_bounds__(256, 2) void conv1d_mfma_fwd_kernel(
 #pragma unroll
             for (int i = 0; i < MT; ++i) b_c[i] = b_n[i];
         }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();      // image c&1 free again; image (c+1)&1 complete (vmcnt(0) + barrier)
         if (c == 0) ECG_STAMP_AT(2);
     }
@@ -793,11 +808,12 @@ __global__ __launch_bounds__(256, 2) void conv1d_mfma_wgrad_dma_kernel(
     int sn = it_begin / ntt, stt = it_begin - sn * ntt;     // stage whose x tile is loaded next
     int dn = sn, dtt = stt;                                 // stage whose dY tile is DMA'd next
     auto advance = [&]() { if (++stt == ntt) { stt = 0; ++sn; } };
-    auto dma_a = [&](int j, float *img) {               // one 1 KB piece of stage (dn, dtt)'s dY tile
-        const float *base = dy + ((size_t)min(dn, N - 1) * Cout + co0) * ldy + dtt * T_T;
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(base + doff[j]),
-                                         (__attribute__((address_space(3))) void *)(img + (j * 4 + wave) * 256),
-                                         16, 0, 0);
+    const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) float *)lds;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    auto dma_a = [&](int j, float *img) {               // one 1 KB piece of stage (dn, dtt)'s dY tile (asm LDS-DMA: glds16)
+        const float *base = dy + ((size_t)min(dn, N - 1) * Cout + co0) * ldy + dtt * T_T;        // uniform
+        glds16(base, (unsigned)doff[j] * 4u,
+               (unsigned)__builtin_amdgcn_readfirstlane((int)(lds_base + (unsigned)((img - lds) + (j * 4 + wave_u) * 256) * 4u)));
     };
     auto load_x = [&](int j) {                          // x tile element of stage (sn, stt)
         const float *xn = x + (size_t)min(sn, N - 1) * Cin * L;
@@ -828,6 +844,7 @@ __global__ __launch_bounds__(256, 2) void conv1d_mfma_wgrad_dma_kernel(
         for (int j = 0; j < XLOADS; ++j) load_x(j);
         advance();                                      // stage 2
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // (the asm DMA pieces are not in hipcc's books)
     __syncthreads();
     ECG_STAMP_AT(1);
 
@@ -883,6 +900,7 @@ __global__ __launch_bounds__(256, 2) void conv1d_mfma_wgrad_dma_kernel(
         }
         dn = sn; dtt = stt;
         advance();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();      // image it&1 free again; image (it+1)&1 complete (vmcnt(0) + barrier)
         if (it == 0) ECG_STAMP_AT(2);
     }
