@@ -178,7 +178,10 @@ __global__ __launch_bounds__(NT) void conv1d_bf16_ring_kernel(
     const unsigned wlane = (unsigned)((lane >> 1) * 32 + (((lane & 1) ^ ((lane >> 4) & 1)) << 4));
     const unsigned char *const wtile = reinterpret_cast<const unsigned char *>(wb) + (size_t)co0 * 32;
     auto dma_piece = [&](int f, int rb, unsigned dst_off) __attribute__((always_inline)) {   // rows rb*32 .. +31 of tap f -> 1 KB at lds + dst_off
-        const unsigned char *src = wtile + (size_t)f * tap_bytes + rb * 1024;                // uniform
+        const unsigned long long s0 = (unsigned long long)(wtile + (size_t)f * tap_bytes + rb * 1024);   // uniform; made provably so
+        const unsigned char *src = reinterpret_cast<const unsigned char *>(
+            ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(s0 >> 32)) << 32) |
+            (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)s0));
         const unsigned dst = (unsigned)__builtin_amdgcn_readfirstlane((int)(lds_base + dst_off));
         unsigned keep;
         asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"

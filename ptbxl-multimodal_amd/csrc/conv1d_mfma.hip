@@ -55,7 +55,13 @@ __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
 // read since (22 of the 30 steps of a forward chunk).  The asm statement has no register result, so there is nothing for
 // the compiler to protect; M0 is saved and restored inside it; completion is waited for explicitly (vmcnt) before the
 // barrier that publishes the image.
-__device__ __forceinline__ void glds16(const void *base, unsigned voff, unsigned dst) {
+__device__ __forceinline__ void glds16(const void *base_in, unsigned voff, unsigned dst) {
+    // (uniform by construction; readfirstlane makes it PROVABLY so for the "s" operand — the diagnostic STAMP build could
+    // not prove it on its own)
+    const unsigned long long b = (unsigned long long)base_in;
+    const unsigned blo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)b);
+    const unsigned bhi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(b >> 32));
+    const void *base = (const void *)(((unsigned long long)bhi << 32) | blo);
     unsigned keep;
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(voff), "s"(base), "s"(dst) : "memory");
