@@ -69,6 +69,15 @@ int ecg_pack_weights_grouped(const float *const *w, float *const *w_fwd, float *
                              const int *C_out, const int *C_in, const int *K, int count,
                              ecg_stream_t stream);
 
+/* The same launch, also writing the bf16 MFMA operands of the opt-in mixed-precision mode: problem q additionally
+ * == ecg_conv1d_pack_weights_bf16(w[q], wb_fwd[q], wb_bwd[q], ...) (K[q] <= 15 when either is given).  Any of the
+ * four destinations of a problem may be NULL, not all.  One launch per train step instead of one per conv layer
+ * plus the fp32 one (the reference has no counterpart: ATen reads nn.Conv1d.weight as it stands,
+ * src/models/ecg_cnn.py:13). */
+int ecg_pack_weights_grouped_mixed(const float *const *w, float *const *w_fwd, float *const *w_bwd,
+                                   void *const *wb_fwd, void *const *wb_bwd, const int *C_out,
+                                   const int *C_in, const int *K, int count, ecg_stream_t stream);
+
 /* Number P of per-channel (sum, sum-of-squares) partials ecg_conv1d_fwd writes per output
  * channel for this shape; stat_partials must hold C_out*P*2 floats. */
 int ecg_conv1d_fwd_stat_partials(int N, int C_in, int C_out, int L, int K, int pad);
@@ -175,10 +184,13 @@ int ecg_conv1d_bwd_data_bf16h(const void *dy_bf16, int ldy, const void *wb_bwd, 
 int ecg_conv1d_fwd_bf16_yh(const void *x, int x_bf16, int ldx, const void *wb_fwd, const float *bias, void *y_bf16,
                            int ldy, float *stat_partials, int N, int C_in, int C_out, int L, int K, int pad,
                            ecg_stream_t stream);
-/* How many (sum, sum^2) partials per channel ecg_conv1d_fwd_bf16_yh writes for exactly these arguments.  Long rows with
- * bf16 on both sides (x_bf16 != 0, ldy % 8 == 0) take the round-3 ring kernel (csrc/conv1d_bf16_ring.hip: 640 / 1280
- * time steps per workgroup, weights through an LDS-DMA ring, transposed accumulators), whose workgroup count differs
- * from the kernel behind ecg_conv1d_fwd_bf16_stat_partials.  Same reference call site: src/models/ecg_cnn.py:13-14. */
+/* How many (sum, sum^2) partials per channel ecg_conv1d_fwd_bf16_yh writes for exactly these arguments — ALWAYS size
+ * stat_partials with this query, never with ecg_conv1d_fwd_bf16_stat_partials.  Long rows with bf16 on both sides
+ * (x_bf16 != 0, ldy % 8 == 0) take the round-3 ring kernel (csrc/conv1d_bf16_ring.hip: 640 / 1280 time steps per
+ * workgroup, weights through an LDS-DMA ring, transposed accumulators), and so does the fp32 network input (x_bf16 == 0)
+ * of at most 16 channels on rows of even length where 512-step tiles pad no more than 256-step ones (one chunk per
+ * tile, weights resident, two workgroups per CU); their workgroup counts differ from the kernel behind
+ * ecg_conv1d_fwd_bf16_stat_partials.  Same reference call site: src/models/ecg_cnn.py:13-14. */
 int ecg_conv1d_fwd_bf16_yh_stat_partials(int N, int C_in, int C_out, int L, int K, int pad, int x_bf16, int ldx, int ldy);
 /* Which kernel a conv with bf16 tensors on both sides takes (ecg_conv1d_fwd_bf16_yh with x_bf16 != 0: C_red = C_in,
  * C_res = C_out, pad; ecg_conv1d_bwd_data_bf16hh: C_red = C_out, C_res = C_in, pad = K-1-pad): the ring kernel's time

@@ -12,8 +12,8 @@ int direct_wgrad(const float *dy, const float *x, float *dw, float *db, float *w
                  int Cout, int L, int K, int pad, hipStream_t st);
 int pack_weights(const float *w, float *w_fwd, float *w_bwd, int Co, int Ci, int K,
                  hipStream_t st);
-int pack_weights_grouped(const float *const *w, float *const *w_fwd, float *const *w_bwd,
-                         const int *Co, const int *Ci, const int *K, int count, hipStream_t st);
+int pack_weights_grouped(const float *const *w, float *const *w_fwd, float *const *w_bwd, void *const *wb_fwd,
+                         void *const *wb_bwd, const int *Co, const int *Ci, const int *K, int count, hipStream_t st);
 // conv1d_mfma.hip
 bool mfma_fwd_supported(int Cin, int Cout, int K, int pad);
 int mfma_fwd_stat_partials(int N, int Cin, int Cout, int Lo);
@@ -59,7 +59,23 @@ ECG_API int ecg_pack_weights_grouped(const float *const *w, float *const *w_fwd,
         ECG_REQUIRE(C_out[q] > 0 && C_in[q] > 0 && K[q] >= 1 && K[q] <= 31,
                     "pack_weights_grouped: problem %d has a bad shape", q);
     }
-    return pack_weights_grouped(w, w_fwd, w_bwd, C_out, C_in, K, count, as_stream(stream));
+    return pack_weights_grouped(w, w_fwd, w_bwd, nullptr, nullptr, C_out, C_in, K, count, as_stream(stream));
+}
+
+ECG_API int ecg_pack_weights_grouped_mixed(const float *const *w, float *const *w_fwd, float *const *w_bwd,
+                                           void *const *wb_fwd, void *const *wb_bwd, const int *C_out,
+                                           const int *C_in, const int *K, int count, ecg_stream_t stream) {
+    ECG_REQUIRE(w && w_fwd && w_bwd && wb_fwd && wb_bwd && C_out && C_in && K, "pack_weights_grouped_mixed: null table");
+    ECG_REQUIRE(count >= 1 && count <= 16, "pack_weights_grouped_mixed: count=%d outside [1,16]", count);
+    for (int q = 0; q < count; ++q) {
+        ECG_REQUIRE(w[q] && (w_fwd[q] || w_bwd[q] || wb_fwd[q] || wb_bwd[q]),
+                    "pack_weights_grouped_mixed: problem %d has null pointers", q);
+        ECG_REQUIRE(C_out[q] > 0 && C_in[q] > 0 && K[q] >= 1 && K[q] <= 31,
+                    "pack_weights_grouped_mixed: problem %d has a bad shape", q);
+        ECG_REQUIRE(K[q] <= 15 || !(wb_fwd[q] || wb_bwd[q]),
+                    "pack_weights_grouped_mixed: problem %d asks for bf16 operands with K=%d > 15", q, K[q]);
+    }
+    return pack_weights_grouped(w, w_fwd, w_bwd, wb_fwd, wb_bwd, C_out, C_in, K, count, as_stream(stream));
 }
 
 ECG_API int ecg_conv1d_fwd_stat_partials(int N, int C_in, int C_out, int L, int K, int pad) {

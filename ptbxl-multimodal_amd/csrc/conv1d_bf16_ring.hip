@@ -27,6 +27,7 @@
 // Replaces the ATen work behind ConvBlock.net[0] (reference src/models/ecg_cnn.py:13) and its input gradient.
 #include "common.h"
 #include <cstdlib>
+#include <type_traits>
 #include <utility>
 
 namespace ecg {
@@ -96,9 +97,16 @@ constexpr int commit_tap(int cb, int GT) {
 
 // CO_T output channels x (WT * MT * 32) time steps per workgroup; WCO x WT = 8 waves; wave tile (MT*32) x (MC*32).
 // RES_CH = 0: weights through the ring; RES_CH > 0: the whole slice of <= RES_CH chunks resident in LDS.
-template <int CO_T, int WCO, int WT, int MT, bool STATS, int RES_CH>
-__global__ __launch_bounds__(NT) void conv1d_bf16_ring_kernel(
-    const u16 *__restrict__ x, const u16 *__restrict__ wb, const float *__restrict__ bias, u16 *__restrict__ y,
+// XF32: x is the fp32 NETWORK INPUT ([N][C_in][ldx] floats; block 0 of the model, C_in = 12 -> ONE chunk per tile) and is
+// rounded to bf16 on its way into the LDS image.  RES_CH == 1 (one chunk per tile): the loop body is two TILES, each
+// chunk followed by its epilogue.
+// MT == 2 (512-step tiles, the fp32-input variant): 128 registers and ~70 KB of LDS, TWO workgroups per CU — a one-chunk
+// tile is 75 MFMAs per wave against an epilogue of comparable length, and two independent workgroups fill each other's
+// epilogues (in-kernel stamps with one 1280-step workgroup per CU: taps 5.4 us, epilogue 2.9 us per tile, matrix pipe
+// idle in the latter).
+template <int CO_T, int WCO, int WT, int MT, bool STATS, int RES_CH, bool XF32 = false>
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(MT == 2 ? 4 : 2))) void conv1d_bf16_ring_kernel(
+    const void *__restrict__ xv, const u16 *__restrict__ wb, const float *__restrict__ bias, u16 *__restrict__ y,
     float *__restrict__ partials, int Cin, int Cout, int L, int Lo, int pad, int tiles_t, int N, int G, int P_stride,
     int ldx, int ldyo) {
     static_assert(WCO * WT == NW, "eight waves");
@@ -108,6 +116,11 @@ __global__ __launch_bounds__(NT) void conv1d_bf16_ring_kernel(
     constexpr int SPAN = T_T + KK - 1;
     constexpr int PPT = CO_T / 32;                       // 1 KB pieces per tap slice [CO_T][16] bf16
     constexpr bool RES = RES_CH > 0;
+    constexpr bool ONECH = RES_CH == 1;
+    static_assert(!XF32 || ONECH, "the fp32 input is the network input: one chunk");
+    using XT = std::conditional_t<XF32, float, u16>;
+    const XT *const x = static_cast<const XT *>(xv);
+    constexpr int XR = XF32 ? 8 : 4;                     // registers per staged item
     constexpr int GT = RES ? 1 : NW / PPT;               // taps per ring group (8 pieces = one per wave)
     constexpr int BODY_CH = RES ? 2 : GT;                // chunks per unrolled loop body (GT * 15 taps = 15 groups)
     static_assert(RES || (GT * PPT == NW && (GT == 2 || GT == 4)), "ring groups of 2 or 4 taps");
@@ -120,9 +133,11 @@ __global__ __launch_bounds__(NT) void conv1d_bf16_ring_kernel(
     constexpr int XB = ((SPAN * 32 + 16 + 15) / 16) * 16;   // x image + one dummy slot for items outside the tile
     constexpr int REDB = STATS ? NW * (CO_T / WCO) * 2 * 4 : 0;
     static_assert(REDB <= XB, "stat scratch aliases x image 0");
-    static_assert(WAREA + 2 * XB <= 160 * 1024, "LDS");
+    constexpr int EPROW = 80;                            // bytes per epilogue patch row (64 of data)
+    constexpr int EPB = (NW * 32 * EPROW <= XB) ? 0 : NW * 32 * EPROW;   // patches in the dead x image, or (short tiles) behind the images
+    static_assert(WAREA + 2 * XB + EPB <= 160 * 1024, "LDS");
 
-    __shared__ __attribute__((aligned(1024))) unsigned char lds[WAREA + 2 * XB];
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[WAREA + 2 * XB + EPB];
     unsigned char *const xlds = lds + WAREA;
 
     ECG_STAMPR_AT(0);
@@ -207,12 +222,12 @@ __global__ __launch_bounds__(NT) void conv1d_bf16_ring_kernel(
         const int q = itc / NPAIR, pi = itc - q * NPAIR;
         xitem[j] = (unsigned)pi | ((unsigned)q << 16) | (it < XITEMS ? 0x80000000u : 0u);
     }
-    unsigned xreg[XL][4];
+    unsigned xreg[XL][XR];
     unsigned xok = 0, xok1 = 0;
 
     int cn = q0 / tiles_t, ctt = q0 - cn * tiles_t;               // compute stage: (sample, t tile)
     const size_t xstep_n = (size_t)Cin * ldx;
-    const u16 *xld = x + (size_t)cn * xstep_n;
+    const XT *xld = x + (size_t)cn * xstep_n;
     int ltt = ctt, lc = 0, lleft = total;
     auto ld_advance = [&]() __attribute__((always_inline)) {      // stays on the last chunk once everything is loaded
         if (--lleft > 0) {
@@ -230,8 +245,16 @@ __global__ __launch_bounds__(NT) void conv1d_bf16_ring_kernel(
         const int sidx = ltt * T_T + 2 * pi - 1 - pad;   // even: pad is odd
         const int sc = min(max(sidx, 0), ldx - 2);
         const size_t off = (size_t)min(ci, Cin - 4) * ldx + sc;
+        if constexpr (XF32) {
 #pragma unroll
-        for (int u = 0; u < 4; ++u) xreg[j][u] = *reinterpret_cast<const unsigned *>(xld + off + (size_t)u * ldx);
+            for (int u = 0; u < 4; ++u) {                // two positions of channel ci + u: one aligned 8-byte load
+                const uint2 v = *reinterpret_cast<const uint2 *>(xld + off + (size_t)u * ldx);
+                xreg[j][2 * u] = v.x; xreg[j][2 * u + 1] = v.y;
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) xreg[j][u] = *reinterpret_cast<const unsigned *>(xld + off + (size_t)u * ldx);
+        }
         const unsigned cok = ci < Cin ? 1u : 0u;
         const unsigned ok0 = ((sidx >= 0) && (sidx < ldx)) ? cok : 0u, ok1 = ((sidx + 1 >= 0) && (sidx + 1 < ldx)) ? cok : 0u;
         xok = (xok & ~(1u << j)) | (ok0 << j);
@@ -251,9 +274,19 @@ __global__ __launch_bounds__(NT) void conv1d_bf16_ring_kernel(
         const bool in0 = live & (pos >= 0) & (pos < SPAN), in1 = live & (pos1 < SPAN);
         const int d0 = in0 ? a0 : SPAN * 32, d1 = in1 ? a1 : SPAN * 32;
         const unsigned keep = 0u - ((xok >> j) & 1u), keep1 = 0u - ((xok1 >> j) & 1u);
-        const unsigned w0 = xreg[j][0], w1 = xreg[j][1], w2 = xreg[j][2], w3 = xreg[j][3];
-        const uint2 a = make_uint2(((w0 & 0xFFFFu) | (w1 << 16)) & keep, ((w2 & 0xFFFFu) | (w3 << 16)) & keep);
-        const uint2 b = make_uint2(((w0 >> 16) | (w1 & 0xFFFF0000u)) & keep1, ((w2 >> 16) | (w3 & 0xFFFF0000u)) & keep1);
+        uint2 a, b;
+        if constexpr (XF32) {
+            auto pk = [](unsigned lo, unsigned hi) __attribute__((always_inline)) {
+                return (unsigned)__builtin_bit_cast(u16, (__bf16)__uint_as_float(lo)) |
+                       ((unsigned)__builtin_bit_cast(u16, (__bf16)__uint_as_float(hi)) << 16);
+            };
+            a = make_uint2(pk(xreg[j][0], xreg[j][2]) & keep, pk(xreg[j][4], xreg[j][6]) & keep);
+            b = make_uint2(pk(xreg[j][1], xreg[j][3]) & keep1, pk(xreg[j][5], xreg[j][7]) & keep1);
+        } else {
+            const unsigned w0 = xreg[j][0], w1 = xreg[j][1], w2 = xreg[j][2], w3 = xreg[j][3];
+            a = make_uint2(((w0 & 0xFFFFu) | (w1 << 16)) & keep, ((w2 & 0xFFFFu) | (w3 << 16)) & keep);
+            b = make_uint2(((w0 >> 16) | (w1 & 0xFFFF0000u)) & keep1, ((w2 >> 16) | (w3 & 0xFFFF0000u)) & keep1);
+        }
         *reinterpret_cast<uint2 *>(&lds[img_off + d0]) = a;
         *reinterpret_cast<uint2 *>(&lds[img_off + d1]) = b;
     };
@@ -266,12 +299,10 @@ __global__ __launch_bounds__(NT) void conv1d_bf16_ring_kernel(
     // wave-private 2.5 KB LDS patch ([32 channels][32 times] bf16, 80-byte rows) and leaves as two 16-byte-per-lane
     // stores: 16 rows x 64 contiguous bytes per instruction.  The patch lives in the x image of the tile's LAST chunk,
     // which nobody reads any more once the workgroup has passed the barrier in front of the epilogue.
-    constexpr int EPROW = 80;                            // bytes per patch row (64 of data)
-    static_assert(NW * 32 * EPROW <= XB, "epilogue patches fit the x image");
     auto epilogue = [&](int n, int tt, int img_off) __attribute__((always_inline)) {
         const int pt0 = tt * T_T + wt;
         const bool full = pt0 + MT * 32 <= Lo;           // wave-uniform: no masks, no store predicates
-        const int patch = img_off + wave * (32 * EPROW);
+        const int patch = (EPB ? WAREA + 2 * XB : img_off) + wave * (32 * EPROW);
         const int wr_off = patch + l31 * EPROW + 8 * half;               // + 16 g4 : this lane's 8 bytes of group g4
         const int rd_row = lane >> 2, rd_ch = lane & 3;                  // read side: row (and row + 16), 16-byte chunk
         const int rd_off = patch + rd_row * EPROW + 16 * rd_ch;
@@ -381,15 +412,13 @@ __global__ __launch_bounds__(NT) void conv1d_bf16_ring_kernel(
     // is a multiple of BODY_CH): no condition sits between the MFMAs of a tile, and the accumulators are re-initialised
     // at a loop boundary (a conditional epilogue inside the unrolled body made hipcc spill half of them)
     const int nbodies = nchunks / BODY_CH;
-    for (int tile = q0; tile < q1; ++tile) {
-      for (int body = 0; body < nbodies; ++body) {
-        static_for<BODY_CH>([&](auto CB_) __attribute__((always_inline)) {
+    auto run_chunk = [&](auto CB_, int body) __attribute__((always_inline)) {
             constexpr int cb = decltype(CB_)::value;
             {
                 constexpr int par = cb & 1, npar = par ^ 1;
                 int wres_lane = 0, wres_next_lane = 0;   // RES: this chunk's / the next chunk's first slice, + woff_lane
                 if constexpr (RES) {
-                    const int cc = body * BODY_CH + cb;
+                    const int cc = ONECH ? 0 : body * BODY_CH + cb;
                     wres_lane = cc * (KK * CO_T * 32) + woff_lane;
                     wres_next_lane = ((cc + 1 == nchunks) ? 0 : cc + 1) * (KK * CO_T * 32) + woff_lane;
                 }
@@ -454,8 +483,8 @@ __global__ __launch_bounds__(NT) void conv1d_bf16_ring_kernel(
                         wn[0] = ld_w(wbase_n, 0);
 #pragma unroll
                         for (int j = 0; j < MT; ++j) {
-                            // issued since fragment j was read: the other four fragments and the next weight fragment
-                            wait_lgkm<5>();
+                            // issued since fragment j was read: the other MT - 1 fragments and the next weight fragment
+                            wait_lgkm<MT>();
                             __builtin_amdgcn_sched_barrier(0);
                             acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa[j], wf[0], acc[0][j], 0, 0, 0);
                             xa[j] = ld_x(xbase_n, kn, j);
@@ -467,12 +496,31 @@ __global__ __launch_bounds__(NT) void conv1d_bf16_ring_kernel(
                 });
                 ld_advance();
             }
-        });
-      }
-      if (tile == q0) ECG_STAMPR_AT(2);
-      epilogue(cn, ctt, WAREA + ((BODY_CH - 1) & 1) * XB);
-      if (tile == q0) ECG_STAMPR_AT(3);
-      if (++ctt == tiles_t) { ctt = 0; ++cn; }
+    };
+    if constexpr (ONECH) {
+        // one chunk per tile: tiles alternate between the two x images; the second half of a pair is skipped (uniformly)
+        // when the workgroup's tile count is odd — nothing is live across an epilogue but zeroed accumulators
+        for (int tile = q0; tile < q1; tile += 2) {
+            run_chunk(std::integral_constant<int, 0>{}, 0);
+            if (tile == q0) ECG_STAMPR_AT(2);
+            epilogue(cn, ctt, WAREA);
+            if (tile == q0) ECG_STAMPR_AT(3);
+            if (++ctt == tiles_t) { ctt = 0; ++cn; }
+            if (tile + 1 < q1) {
+                run_chunk(std::integral_constant<int, 1>{}, 0);
+                epilogue(cn, ctt, WAREA + XB);
+                if (++ctt == tiles_t) { ctt = 0; ++cn; }
+            }
+        }
+    } else {
+        for (int tile = q0; tile < q1; ++tile) {
+            for (int body = 0; body < nbodies; ++body)
+                static_for<BODY_CH>([&](auto CB_) __attribute__((always_inline)) { run_chunk(CB_, body); });
+            if (tile == q0) ECG_STAMPR_AT(2);
+            epilogue(cn, ctt, WAREA + ((BODY_CH - 1) & 1) * XB);
+            if (tile == q0) ECG_STAMPR_AT(3);
+            if (++ctt == tiles_t) { ctt = 0; ++cn; }
+        }
     }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // the ring keeps issuing to the end: let everything land
 #ifdef ECG_STAMP
@@ -510,7 +558,7 @@ __global__ __launch_bounds__(NT) void conv1d_bf16_ring_kernel(
 // ---------------------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------------------
-struct RingPlan { bool ok; int co_t, t_t, res_ch, G; };
+struct RingPlan { bool ok; int co_t, t_t, res_ch, G; bool xf32; };
 
 static int ring_enabled() {
     static const int v = [] { const char *e = getenv("ECG_BF16_RING"); return e && *e ? atoi(e) : 1; }();
@@ -519,24 +567,28 @@ static int ring_enabled() {
 
 // Which shapes the ring kernel takes: bf16 in and out (x_bf16 / y_bf16 of the callers), K = 15, odd pad, even ldx,
 // ldy % 4 == 0, and rows long enough that 640-step tiles waste no more than the 256-step tiles of the old kernel.
-RingPlan bf16_ring_plan(int N, int Cin, int Cout, int Lo, int K, int pad, int ldx, int ldyo) {
-    RingPlan p{false, 0, 0, 0, 0};
+// xf32: the input is the fp32 network input (one 16-channel chunk: C_in <= 16), rounded to bf16 while it is staged.
+RingPlan bf16_ring_plan(int N, int Cin, int Cout, int Lo, int K, int pad, int ldx, int ldyo, bool xf32) {
+    RingPlan p{false, 0, 0, 0, 0, xf32};
     if (!ring_enabled() || K != 15 || (pad & 1) == 0 || Cin % 4 || Cout % 32 || ldx % 2 || ldyo % 8) return p;
     const int nch = (Cin + 15) / 16;
-    if (Cout % 128 == 0) { p.co_t = 128; p.t_t = 640; p.res_ch = 0; }
+    if (xf32) {
+        if (nch != 1) return p;
+        p.co_t = 32; p.t_t = 512; p.res_ch = 1;
+    } else if (Cout % 128 == 0) { p.co_t = 128; p.t_t = 640; p.res_ch = 0; }
     else if (Cout % 64 == 0) { p.co_t = 64; p.t_t = 1280; p.res_ch = nch <= 2 ? 2 : 0; }
     else { p.co_t = 32; p.t_t = 1280; p.res_ch = nch <= 4 ? 4 : -1; }
     if (p.res_ch < 0) return p;
     // a tile is a whole number of unrolled loop bodies: 2 chunks (resident weights, 128-channel ring) or 4 (64-channel ring)
     const int body_ch = (p.res_ch == 0 && p.co_t == 64) ? 4 : 2;
-    if (nch % body_ch) return p;
+    if (!xf32 && nch % body_ch) return p;
     if (ring_enabled() != 2) {          // 2 = force (tests of short rows); 1 = only where the tiles fit the row
         const long long new_pad = (long long)cdiv(Lo, p.t_t) * p.t_t, old_pad = (long long)cdiv(Lo, 256) * 256;
         if (new_pad > old_pad + old_pad / 50) return p;
     }
     const int CT = Cout / p.co_t;
     const long long ntiles = (long long)N * cdiv(Lo, p.t_t);
-    long long G = 256 / CT;
+    long long G = (xf32 ? 512 : 256) / CT;                // (the fp32-input variant runs two workgroups per CU)
     if (G < 1) G = 1;
     if (G > ntiles) G = ntiles;
     const long long per = (ntiles + G - 1) / G;
@@ -550,12 +602,20 @@ int bf16_ring_launch(const RingPlan &p, const void *x, int ldx, const void *wb, 
     using namespace ring;
     const int tiles_t = cdiv(Lo, p.t_t);
     dim3 grid((unsigned)((Cout / p.co_t) * p.G)), block(NT);
-    const u16 *xh = static_cast<const u16 *>(x), *w = static_cast<const u16 *>(wb);
+    const void *xh = x;
+    const u16 *w = static_cast<const u16 *>(wb);
     u16 *yh = static_cast<u16 *>(y);
 #define ECG_RING(CO, WCO_, WT_, STATS_, RES_)                                                                        \
     hipLaunchKernelGGL((conv1d_bf16_ring_kernel<CO, WCO_, WT_, 5, STATS_, RES_>), grid, block, 0, st, xh, w, bias, yh, \
                        partials, Cin, Cout, L, Lo, pad, tiles_t, N, p.G, P_stride, ldx, ldyo)
-    if (p.co_t == 128) { if (partials) ECG_RING(128, 2, 4, true, 0); else ECG_RING(128, 2, 4, false, 0); }
+    if (p.xf32) {
+        if (partials)
+            hipLaunchKernelGGL((conv1d_bf16_ring_kernel<32, 1, 8, 2, true, 1, true>), grid, block, 0, st, xh, w, bias, yh,
+                               partials, Cin, Cout, L, Lo, pad, tiles_t, N, p.G, P_stride, ldx, ldyo);
+        else
+            hipLaunchKernelGGL((conv1d_bf16_ring_kernel<32, 1, 8, 2, false, 1, true>), grid, block, 0, st, xh, w, bias, yh,
+                               partials, Cin, Cout, L, Lo, pad, tiles_t, N, p.G, P_stride, ldx, ldyo);
+    } else if (p.co_t == 128) { if (partials) ECG_RING(128, 2, 4, true, 0); else ECG_RING(128, 2, 4, false, 0); }
     else if (p.co_t == 64 && p.res_ch) { if (partials) ECG_RING(64, 1, 8, true, 2); else ECG_RING(64, 1, 8, false, 2); }
     else if (p.co_t == 64) { if (partials) ECG_RING(64, 1, 8, true, 0); else ECG_RING(64, 1, 8, false, 0); }
     else { if (partials) ECG_RING(32, 1, 8, true, 4); else ECG_RING(32, 1, 8, false, 4); }

@@ -350,8 +350,39 @@ int pack_weights(const float *w, float *w_fwd, float *w_bwd, int Co, int Ci, int
 // replaces wrote every float to a different cache line (17.6 MB of write traffic for 5.7 MB of packed weights).
 constexpr int kMaxPack = 16;
 constexpr int kPackCo = 16, kPackCi = 16, kPackKMax = 15;   // ~700 tiles of 15 KB for the whole model: enough workgroups to fill the chip
-struct PackProb { const float *w; float *w_fwd, *w_bwd; int Co, Ci, K, block0, ci_tiles; };
+// wb_fwd / wb_bwd: the bf16 operand layouts of conv1d_mfma_bf16.hip ([ceil(C_red/16)][K][C_res][16], zero-filled past
+// the channel count; the input-grad one tap-flipped with the channel roles swapped) — a 16 x 16 tile here is exactly
+// one 16-channel chunk of either
+struct PackProb { const float *w; float *w_fwd, *w_bwd; unsigned short *wb_fwd, *wb_bwd; int Co, Ci, K, block0, ci_tiles; };
 struct PackArgs { PackProb p[kMaxPack]; int count; };
+
+__device__ __forceinline__ unsigned pack_bf16_pair(float lo, float hi) {
+    return (unsigned)__builtin_bit_cast(unsigned short, (__bf16)lo) | ((unsigned)__builtin_bit_cast(unsigned short, (__bf16)hi) << 16);
+}
+
+// the bf16 operands of one staged tile (tile[co * ld + ci * K + k]), two channels per thread and store
+__device__ __forceinline__ void pack_tile_bf16(const PackProb &pr, const float *tile, int ld, int co0, int ci0, int nco,
+                                               int nci, int tid) {
+    const int K = pr.K;
+    if (pr.wb_fwd) {            // [ci0 / 16][k][co0 + co][j = ci]: per tap, nco rows of 32 contiguous bytes
+        unsigned *dst = reinterpret_cast<unsigned *>(pr.wb_fwd + ((size_t)(ci0 / kPackCi) * K * pr.Co + co0) * kPackCi);
+        for (int e = tid; e < K * nco * 8; e += 256) {
+            const int jp = e & 7, r = e >> 3, co = r % nco, k = r / nco;
+            const float lo = 2 * jp < nci ? tile[co * ld + (2 * jp) * K + k] : 0.f;
+            const float hi = 2 * jp + 1 < nci ? tile[co * ld + (2 * jp + 1) * K + k] : 0.f;
+            dst[((size_t)k * pr.Co + co) * 8 + jp] = pack_bf16_pair(lo, hi);
+        }
+    }
+    if (pr.wb_bwd) {            // [co0 / 16][K-1-k][ci0 + ci][j = co]
+        unsigned *dst = reinterpret_cast<unsigned *>(pr.wb_bwd + ((size_t)(co0 / kPackCo) * K * pr.Ci + ci0) * kPackCo);
+        for (int e = tid; e < K * nci * 8; e += 256) {
+            const int jp = e & 7, r = e >> 3, ci = r % nci, k = r / nci;
+            const float lo = 2 * jp < nco ? tile[(2 * jp) * ld + ci * K + (K - 1 - k)] : 0.f;
+            const float hi = 2 * jp + 1 < nco ? tile[(2 * jp + 1) * ld + ci * K + (K - 1 - k)] : 0.f;
+            dst[((size_t)k * pr.Ci + ci) * 8 + jp] = pack_bf16_pair(lo, hi);
+        }
+    }
+}
 
 __global__ __launch_bounds__(256) void pack_weights_grouped_kernel(PackArgs a) {
     __shared__ float tile[kPackCo * (kPackCi * kPackKMax + 1)];
@@ -394,6 +425,7 @@ __global__ __launch_bounds__(256) void pack_weights_grouped_kernel(PackArgs a) {
                 pr.w_bwd[((size_t)(KC - 1 - k) * pr.Co + co0 + co) * pr.Ci + ci0 + ci] = tile[co * ld + ci * KC + k];
             }
         }
+        pack_tile_bf16(pr, tile, ld, co0, ci0, nco, nci, tid);
         return;
     }
     for (int e = tid; e < nco * run; e += 256) {
@@ -413,10 +445,11 @@ __global__ __launch_bounds__(256) void pack_weights_grouped_kernel(PackArgs a) {
             const int co = r % nco, k = r / nco;
             pr.w_bwd[((size_t)(K - 1 - k) * pr.Co + co0 + co) * pr.Ci + ci0 + ci] = tile[co * ld + ci * K + k];
         }
+    pack_tile_bf16(pr, tile, ld, co0, ci0, nco, nci, tid);
 }
 
-int pack_weights_grouped(const float *const *w, float *const *w_fwd, float *const *w_bwd,
-                         const int *Co, const int *Ci, const int *K, int count, hipStream_t st) {
+int pack_weights_grouped(const float *const *w, float *const *w_fwd, float *const *w_bwd, void *const *wb_fwd,
+                         void *const *wb_bwd, const int *Co, const int *Ci, const int *K, int count, hipStream_t st) {
     PackArgs a;
     a.count = count;
     int blocks = 0;
@@ -424,14 +457,15 @@ int pack_weights_grouped(const float *const *w, float *const *w_fwd, float *cons
         if (K[q] > kPackKMax) {          // (never in this model: fall back to one plain launch per oversized problem)
             int rc = pack_weights(w[q], w_fwd[q], w_bwd[q], Co[q], Ci[q], K[q], st);
             if (rc) return rc;
-            a.p[q] = PackProb{nullptr, nullptr, nullptr, 0, 0, 1, blocks, 1};
+            a.p[q] = PackProb{nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, 1, blocks, 1};
             continue;
         }
         const int ci_tiles = cdiv(Ci[q], kPackCi);
-        a.p[q] = PackProb{w[q], w_fwd[q], w_bwd[q], Co[q], Ci[q], K[q], blocks, ci_tiles};
+        a.p[q] = PackProb{w[q], w_fwd[q], w_bwd[q], static_cast<unsigned short *>(wb_fwd ? wb_fwd[q] : nullptr),
+                          static_cast<unsigned short *>(wb_bwd ? wb_bwd[q] : nullptr), Co[q], Ci[q], K[q], blocks, ci_tiles};
         blocks += cdiv(Co[q], kPackCo) * ci_tiles;
     }
-    for (int q = count; q < kMaxPack; ++q) a.p[q] = PackProb{nullptr, nullptr, nullptr, 0, 0, 1, 1 << 30, 1};
+    for (int q = count; q < kMaxPack; ++q) a.p[q] = PackProb{nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, 1, 1 << 30, 1};
     if (blocks == 0) return ECG_OK;
     hipLaunchKernelGGL(pack_weights_grouped_kernel, dim3(blocks), dim3(256), 0, st, a);
     return check_launch("pack_weights_grouped_kernel");

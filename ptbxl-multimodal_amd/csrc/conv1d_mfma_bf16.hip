@@ -499,8 +499,8 @@ static void launch_bf16(const void *x, int ldx, bool xh, const u16 *wb, const fl
 }
 
 // conv1d_bf16_ring.hip: the round-3 kernel for long rows with bf16 activations on both sides
-struct RingPlan { bool ok; int co_t, t_t, res_ch, G; };
-RingPlan bf16_ring_plan(int N, int Cin, int Cout, int Lo, int K, int pad, int ldx, int ldyo);
+struct RingPlan { bool ok; int co_t, t_t, res_ch, G; bool xf32; };
+RingPlan bf16_ring_plan(int N, int Cin, int Cout, int Lo, int K, int pad, int ldx, int ldyo, bool xf32 = false);
 int bf16_ring_launch(const RingPlan &p, const void *x, int ldx, const void *wb, const float *bias, void *y, int ldyo,
                      float *partials, int P_stride, int N, int Cin, int Cout, int L, int Lo, int pad, hipStream_t st);
 
@@ -510,8 +510,10 @@ static int bf16_fwd_any(const void *x, int ldx, bool xh, const void *wb, const f
                         float *partials, int N, int Cin, int Cout, int L, int K, int pad, hipStream_t st) {
     const int Lo = L + 2 * pad - K + 1;
     const u16 *w = static_cast<const u16 *>(wb);
-    if (xh && yh && ((reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(wb)) & 15) == 0) {
-        const RingPlan rp = bf16_ring_plan(N, Cin, Cout, Lo, K, pad, ldx, ldyo);
+    // (fp32 input: the rows are [L] floats, read as aligned pairs)
+    if (yh && ((reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(wb)) & 15) == 0 &&
+        (xh || (reinterpret_cast<uintptr_t>(x) & 7) == 0)) {
+        const RingPlan rp = bf16_ring_plan(N, Cin, Cout, Lo, K, pad, ldx, ldyo, !xh);
         if (rp.ok) return bf16_ring_launch(rp, x, ldx, wb, bias, y, ldyo, partials, rp.G, N, Cin, Cout, L, Lo, pad, st);
     }
     const Bf16Cfg c = bf16_cfg(N, Cout, Lo);
@@ -638,8 +640,8 @@ ECG_API int ecg_conv1d_fwd_bf16_stat_partials(int N, int C_in, int C_out, int L,
 ECG_API int ecg_conv1d_fwd_bf16_yh_stat_partials(int N, int C_in, int C_out, int L, int K, int pad, int x_bf16, int ldx,
                                                  int ldy) {
     const int Lo = L + 2 * pad - K + 1;
-    if (x_bf16) {
-        const RingPlan rp = bf16_ring_plan(N, C_in, C_out, Lo, K, pad, ldx, ldy);
+    {
+        const RingPlan rp = bf16_ring_plan(N, C_in, C_out, Lo, K, pad, x_bf16 ? ldx : L, ldy, !x_bf16);
         if (rp.ok) return rp.G;
     }
     return bf16_fwd_stat_partials(N, C_out, Lo);

@@ -25,6 +25,7 @@ SIGNATURES = {
     "ecg_check_device": (_i, []),
     "ecg_conv1d_pack_weights": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),
     "ecg_pack_weights_grouped": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
+    "ecg_pack_weights_grouped_mixed": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
     "ecg_conv1d_fwd_stat_partials": (_i, [_i, _i, _i, _i, _i, _i]),
     "ecg_conv1d_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "ecg_conv1d_bwd_data": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
@@ -205,9 +206,9 @@ class kernel_timing:
         return False
 
 
-def ptr_table(tensors):
+def ptr_table(tensors, any_dtype=False):
     """Host array of device pointers (NULL for None) for the grouped entry points."""
-    arr = (ctypes.c_void_p * len(tensors))(*[f32(t) for t in tensors])
+    arr = (ctypes.c_void_p * len(tensors))(*[(ptr if any_dtype else f32)(t) for t in tensors])
     return arr
 
 

@@ -217,26 +217,44 @@ class WeightPacker:
         self._key = None
 
     def pack(self, convs, linears, need_bwd):
+        """-> (conv_packs, linear_T); conv_packs[i] = (w_fwd, w_bwd) fp32 operands, or in bf16 mode, for a conv the
+        bf16 kernels take, (w_fwd, w_bwd, wb_fwd, wb_bwd) with the fp32 pair None — the bf16 operands come out of the
+        same launch (one launch per step instead of one per layer plus the fp32 one)."""
         srcs = [c.weight for c in convs] + [l.weight for l in linears]
-        key = (need_bwd,) + tuple((w.data_ptr(), tuple(w.shape)) for w in srcs)
+        mixed = _conv_precision == "bf16"
+        key = (need_bwd, mixed) + tuple((w.data_ptr(), tuple(w.shape)) for w in srcs)
         if key != self._key:
             self._key = key
-            self.conv_packs, self.linear_T, fw, bw, co, ci, kk = [], [], [], [], [], [], []
+            self.conv_packs, self.linear_T, fw, bw, hf, hb, co, ci, kk = [], [], [], [], [], [], [], [], []
             for i, c in enumerate(convs):
                 w = _contig(c.weight)
                 Co, Ci, K = w.shape
-                wf = torch.empty_like(w).view(K, Ci, Co)
-                wb = torch.empty_like(w).view(K, Co, Ci) if (need_bwd and i > 0) else None   # block 0 has no input-grad
-                self.conv_packs.append((wf, wb))
-                fw.append(wf); bw.append(wb); co.append(Co); ci.append(Ci); kk.append(K)
+                want_bwd = need_bwd and i > 0                # block 0 has no input-grad
+                sup = _query("ecg_conv1d_bf16_supported", Ci, Co, K, c.padding[0]) if (mixed and K <= 15) else 0
+                if (sup & 1) and (not want_bwd or (sup & 2)):
+                    wf = wb = None
+                    hwf = torch.empty(_query("ecg_conv1d_bf16_packed_elems", Ci, Co, K), dtype=torch.bfloat16, device=w.device)
+                    hwb = (torch.empty(_query("ecg_conv1d_bf16_packed_elems", Co, Ci, K), dtype=torch.bfloat16,
+                                       device=w.device) if want_bwd else None)
+                    self.conv_packs.append((None, None, hwf, hwb))
+                else:
+                    hwf = hwb = None
+                    wf = torch.empty_like(w).view(K, Ci, Co)
+                    wb = torch.empty_like(w).view(K, Co, Ci) if want_bwd else None
+                    self.conv_packs.append((wf, wb))
+                fw.append(wf); bw.append(wb); hf.append(hwf); hb.append(hwb); co.append(Co); ci.append(Ci); kk.append(K)
             for l in linears:
                 w = _contig(l.weight)
                 wt = torch.empty(w.shape[1], w.shape[0], dtype=w.dtype, device=w.device)
                 self.linear_T.append(wt)
-                fw.append(wt); bw.append(None); co.append(w.shape[0]); ci.append(w.shape[1]); kk.append(1)
-            self._tables = (L.ptr_table([_contig(w) for w in srcs]), L.ptr_table(fw), L.ptr_table(bw),
-                            L.int_table(co), L.int_table(ci), L.int_table(kk), len(srcs))
-        _call("ecg_pack_weights_grouped", *self._tables, _st())
+                fw.append(wt); bw.append(None); hf.append(None); hb.append(None)
+                co.append(w.shape[0]); ci.append(w.shape[1]); kk.append(1)
+            self._mixed = any(t is not None for t in hf)
+            tabs = [L.ptr_table([_contig(w) for w in srcs]), L.ptr_table(fw), L.ptr_table(bw)]
+            if self._mixed:
+                tabs += [L.ptr_table(hf, any_dtype=True), L.ptr_table(hb, any_dtype=True)]
+            self._tables = tuple(tabs) + (L.int_table(co), L.int_table(ci), L.int_table(kk), len(srcs))
+        _call("ecg_pack_weights_grouped_mixed" if self._mixed else "ecg_pack_weights_grouped", *self._tables, _st())
         return self.conv_packs, self.linear_T
 
 
@@ -358,10 +376,12 @@ class ConvBlockFn(torch.autograd.Function):
         need_dx = need_grad and ctx.needs_input_grad[0]
         bf16 = bool(sup & 1) and (not need_dx or bool(sup & 2))     # block 0 (no input-grad) only needs the forward
         ctx.bf16 = bf16
-        if bf16:
+        if bf16 and packed is not None and len(packed) == 4 and (packed[3] is not None or not need_dx):
+            w_fwd, w_bwd = packed[2], packed[3]          # bf16 operands out of WeightPacker's one launch
+        elif bf16:
             w_fwd, w_bwd = conv1d_pack_bf16(w, need_bwd=need_grad and ctx.needs_input_grad[0])
-        elif packed is not None and (packed[1] is not None or not ctx.needs_input_grad[0]):
-            w_fwd, w_bwd = packed                        # packed by WeightPacker for the whole model
+        elif packed is not None and packed[0] is not None and (packed[1] is not None or not ctx.needs_input_grad[0]):
+            w_fwd, w_bwd = packed[0], packed[1]          # packed by WeightPacker for the whole model
         else:
             w_fwd, w_bwd = conv1d_pack(w, need_bwd=need_grad and ctx.needs_input_grad[0])
         if not use_batch and not need_grad and not bf16:

@@ -495,6 +495,41 @@ def test_grouped_pack_matches_single_packs(hip):
         assert torch.equal(t, l.weight.detach().t().contiguous())
 
 
+def test_grouped_pack_in_bf16_mode_matches_the_per_layer_bf16_packs(hip):
+    """ecg_pack_weights_grouped_mixed: the bf16 MFMA operands of every conv the bf16 kernels take come out of the SAME
+    launch as the fp32 packs of the others and the Linear transposes — bit for bit what ecg_conv1d_pack_weights_bf16 /
+    ecg_conv1d_pack_weights / a transpose write one layer at a time (C_in = 12 pads its chunk with zeros)."""
+    torch.manual_seed(4)
+    convs = [torch.nn.Conv1d(12, 32, 15, padding=7), torch.nn.Conv1d(32, 64, 15, padding=7),
+             torch.nn.Conv1d(64, 128, 15, padding=7), torch.nn.Conv1d(7, 5, 3, padding=1), torch.nn.Conv1d(24, 40, 15, padding=7)]
+    lins = [torch.nn.Linear(256, 256), torch.nn.Linear(64, 5)]
+    for m in convs + lins:
+        m.cuda()
+    with hip.conv_precision("bf16"):
+        packs, trans = hip.WeightPacker().pack(convs, lins, need_bwd=True)
+    took_bf16 = 0
+    for i, c in enumerate(convs):
+        w = c.weight.detach()
+        if len(packs[i]) == 4:
+            took_bf16 += 1
+            assert packs[i][0] is None and packs[i][1] is None
+            hf, hb = hip.conv1d_pack_bf16(w, need_bwd=True)
+            assert torch.equal(packs[i][2].view(torch.int16), hf.view(torch.int16)), i
+            if i == 0:
+                assert packs[i][3] is None
+            else:
+                assert torch.equal(packs[i][3].view(torch.int16), hb.view(torch.int16)), i
+        else:
+            wf, wb = hip.conv1d_pack(w)
+            assert torch.equal(packs[i][0], wf) and (i == 0 or torch.equal(packs[i][1], wb))
+    assert took_bf16 >= 3 and len(packs[3]) == 2          # K = 3 stays an fp32 layer
+    for l, t in zip(lins, trans):
+        assert torch.equal(t, l.weight.detach().t().contiguous())
+    # fp32 mode: the same packer hands out fp32 operands only
+    packs32, _ = hip.WeightPacker().pack(convs, lins, need_bwd=True)
+    assert all(len(pk) == 2 for pk in packs32)
+
+
 def test_return_features_and_feature_gradient(hip, oracle):
     """ECGCNN(return_features=True): z is a differentiable output of the fused tail."""
     from src.models.ecg_cnn import ECGCNN
@@ -726,15 +761,18 @@ def test_bf16_activation_storage_equals_the_fp32_passes_on_the_rounded_tensor(hi
     b = dev(rng.standard_normal(Co).astype(np.float32))
     gamma, beta = dev((rng.random(Co) + 0.5).astype(np.float32)), dev(rng.standard_normal(Co).astype(np.float32) * 0.3)
     wb_fwd, _ = hip.conv1d_pack_bf16(w, need_bwd=False)
-    y32, part32, P = hip.conv1d_forward_bf16_raw(x, wb_fwd, b, Co, 15, 7, want_stats=True)
+    y32, part32, _ = hip.conv1d_forward_bf16_raw(x, wb_fwd, b, Co, 15, 7, want_stats=True)
     ldy = (Lo + 7) & ~7
-    yh = torch.full((N, Co, ldy), float("nan"), dtype=torch.bfloat16, device="cuda")     # row padding stays NaN: must be ignored
+    yh = torch.full((N, Co, ldy), float("nan"), dtype=torch.bfloat16, device="cuda")     # row padding: NaN or zeros, must be ignored
+    P = L.query("ecg_conv1d_fwd_bf16_yh_stat_partials", N, Ci, Co, Lin, 15, 7, 0, 0, ldy)   # (the kernel is picked by row length too)
     part = torch.empty(Co * P * 2, device="cuda")
     L.call("ecg_conv1d_fwd_bf16_yh", L.f32(x), 0, 0, L.ptr(wb_fwd), L.f32(b), L.ptr(yh), ldy, L.f32(part), N, Ci, Co, Lin,
            15, 7, L.stream())
     yr = y32.to(torch.bfloat16)                       # nearest-even
     assert torch.equal(yh[:, :, :Lo], yr)
-    assert bool(torch.isnan(yh[:, :, Lo:].float()).all())
+    padv = yh[:, :, Lo:].float()
+    assert bool((torch.isnan(padv) | (padv == 0)).all())
+    yh[:, :, Lo:] = float("nan")                      # ... and whatever it holds, the passes below must not read it
     yr32 = yr.to(torch.float32).contiguous()
     # statistics of the rounded tensor (double reference)
     st = part.view(Co, P, 2).double().sum(dim=1).cpu().numpy()
@@ -1020,6 +1058,72 @@ def test_bf16_ring_forward_is_exact_on_bf16_rounded_operands(hip, oracle, case):
     L.call("ecg_conv1d_fwd_bf16_yh", L.f32(dev(x)), 0, 0, L.ptr(wb_fwd), L.f32(dev(b)), L.ptr(y_old), ldy, L.f32(part_old),
            N, Ci, Co, Lin, 15, 7, L.stream())
     assert np.mean(y_old.float().cpu().numpy()[:, :, :Lin] != got[:, :, :Lin]) < 0.01
+
+
+# the network input itself: fp32 [N][12][L] rows, ONE 16-channel chunk per tile (4 of its 16 channels are zero padding),
+# weights resident, 512-step tiles, two tiles per loop body; the row lengths leave ragged last tiles, (5, 8, 64, ..) has two
+# C_out tiles
+@pytest.mark.parametrize("case", [(2, 12, 32, 5000), (3, 12, 32, 2500), (5, 8, 64, 1530), (1, 16, 32, 3580)])
+def test_bf16_ring_forward_from_the_fp32_network_input(hip, oracle, case):
+    """Block 0 of the bf16-storage train step on long rows: ecg_conv1d_fwd_bf16_yh with x_bf16 = 0 takes the ring kernel's
+    fp32-input variant (x rounded to bf16 while it is staged).  Expected: the oracle's convolution of the bf16-ROUNDED x
+    and w, to one bf16 ulp; statistics = sums over the stored values; rows a 512-step tile would mostly pad stay on the
+    round-2 kernel."""
+    from ecg_hip import _lib as L
+    N, Ci, Co, Lin = case
+    rng = np.random.default_rng(Ci * 7 + Co + Lin)
+    x = rng.standard_normal((N, Ci, Lin)).astype(np.float32)
+    w = (rng.standard_normal((Co, Ci, 15)) / np.sqrt(Ci * 15)).astype(np.float32)
+    b = rng.standard_normal(Co).astype(np.float32)
+    ldy = (Lin + 7) & ~7
+    P = L.query("ecg_conv1d_fwd_bf16_yh_stat_partials", N, Ci, Co, Lin, 15, 7, 0, 0, ldy)
+    P_short = L.query("ecg_conv1d_fwd_bf16_yh_stat_partials", N, Ci, Co, 200, 15, 7, 0, 0, 200)
+    assert P_short == L.query("ecg_conv1d_fwd_bf16_stat_partials", N, Ci, Co, 200, 15, 7)      # a 512-step tile would be 60 % padding: round-2 kernel
+    assert P == min(512 // (Co // 32), N * -(-Lin // 512))           # one workgroup per 512-step tile at these sizes
+    wb_fwd, _ = hip.conv1d_pack_bf16(dev(w), need_bwd=False)
+    yh = torch.full((N, Co, ldy), float("nan"), dtype=torch.bfloat16, device="cuda")
+    part = torch.full((Co * P * 2,), float("nan"), device="cuda")
+    L.call("ecg_conv1d_fwd_bf16_yh", L.f32(dev(x)), 0, 0, L.ptr(wb_fwd), L.f32(dev(b)), L.ptr(yh), ldy, L.f32(part),
+           N, Ci, Co, Lin, 15, 7, L.stream())
+    torch.cuda.synchronize()
+    ry = oracle.conv1d_fwd(_bf16_round(x), _bf16_round(w), b, 7)
+    got = yh.float().cpu().numpy()
+    assert np.all(np.abs(got[:, :, :Lin] - ry) <= np.abs(ry) * 2.0 ** -7 + 1e-6), float(np.abs(got[:, :, :Lin] - ry).max())
+    assert np.mean(got[:, :, :Lin] != _bf16_round(ry)) < 0.01
+    padv = got[:, :, Lin:]
+    assert np.all((padv == 0) | np.isnan(padv))
+    ps = part.cpu().numpy().reshape(Co, P, 2).astype(np.float64).sum(axis=1)
+    v = got[:, :, :Lin].astype(np.float64)
+    np.testing.assert_allclose(ps[:, 0], v.sum(axis=(0, 2)), rtol=1e-5, atol=1e-3)
+    np.testing.assert_allclose(ps[:, 1], (v * v).sum(axis=(0, 2)), rtol=1e-5, atol=1e-3)
+
+
+def test_bf16_ring_fp32_input_full_size_config5_vs_torch(hip):
+    """Block 0 of BASELINE.json configs[4] at full size (B=256, 12x5000 -> 32 channels): five 512-step tiles per
+    persistent workgroup (an odd count through the two-tile loop body, two workgroups per CU), and the same layer with
+    256 output channels at N = 16 (eight C_out tiles, 54 workgroups of 2 or 3 tiles each).  Expected: torch's convolution of the bf16-rounded operands in fp32."""
+    from ecg_hip import _lib as L
+    for N, Co in ((256, 32), (16, 256)):
+        Ci, Lin = 12, 5000
+        g = torch.Generator().manual_seed(Co)
+        x = torch.randn(N, Ci, Lin, generator=g)
+        w = torch.randn(Co, Ci, 15, generator=g) / (Ci * 15) ** 0.5
+        b = torch.randn(Co, generator=g)
+        ldy = Lin
+        wb_fwd, _ = hip.conv1d_pack_bf16(w.cuda(), need_bwd=False)
+        P = L.query("ecg_conv1d_fwd_bf16_yh_stat_partials", N, Ci, Co, Lin, 15, 7, 0, 0, ldy)
+        assert P == {32: 512, 256: 54}[Co]               # 2560 tiles on 512 workgroups; 160 tiles on 54 (2 or 3 each)
+        yh = torch.empty(N, Co, ldy, dtype=torch.bfloat16, device="cuda")
+        part = torch.empty(Co * P * 2, device="cuda")
+        xd = x.cuda()
+        L.call("ecg_conv1d_fwd_bf16_yh", L.f32(xd), 0, 0, L.ptr(wb_fwd), L.f32(b.cuda()), L.ptr(yh), ldy, L.f32(part),
+               N, Ci, Co, Lin, 15, 7, L.stream())
+        ref = torch.nn.functional.conv1d(xd.to(torch.bfloat16).float(), w.to(torch.bfloat16).float().cuda(), b.cuda(), padding=7)
+        got = yh.float()
+        assert torch.all((got - ref).abs() <= ref.abs() * 2.0 ** -7 + 2e-5), float((got - ref).abs().max())
+        ps = part.view(Co, P, 2).double().sum(dim=1)
+        torch.testing.assert_close(ps[:, 0], got.double().sum(dim=(0, 2)), rtol=2e-5, atol=1e-2)
+        torch.testing.assert_close(ps[:, 1], (got.double() ** 2).sum(dim=(0, 2)), rtol=2e-5, atol=1e-2)
 
 
 @pytest.mark.parametrize("case", [(2, 64, 128, 1250), (1, 128, 256, 625), (2, 32, 64, 2500), (2, 64, 128, 2500)])

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Where does a workgroup of the bf16 ring kernel (csrc/conv1d_bf16_ring.hip) spend its time?  Runs the forward and
-input-gradient convs of BASELINE.json configs[4] (B=256, 12x5000, blocks 1-3) through the diagnostic build
+input-gradient convs of BASELINE.json configs[4] (B=256, 12x5000; block 0 = the fp32-input forward only) through the diagnostic build
 (make -C ptbxl-multimodal_amd/csrc STAMP=1) and prints per-phase medians in microseconds: prologue / the first tile's
 taps / the first tile's epilogue / everything after (further tiles + statistics)."""
 import ctypes
@@ -43,8 +43,6 @@ def main():
     N, K, pad = 256, 15, 7
     for b, (ci, co) in enumerate([(12, 32), (32, 64), (64, 128), (128, 256)]):
         Lc = 5000 >> b
-        if b == 0:
-            continue
         ld = (Lc + 7) & ~7
         PA = L.query("ecg_conv1d_n16_positions", Lc, K, pad, 0)
         xh = torch.zeros(N, ci, ld, dtype=torch.bfloat16, device=dev)
@@ -56,16 +54,17 @@ def main():
         dyh = torch.zeros(N, co, PA, dtype=torch.bfloat16, device=dev)
         dyh[:, :, :Lc] = torch.randn(N, co, Lc, device=dev).to(torch.bfloat16)
         dxh = torch.empty(N, ci, ld, dtype=torch.bfloat16, device=dev)
-        P = L.query("ecg_conv1d_fwd_bf16_yh_stat_partials", N, ci, co, Lc, K, pad, 1, ld, ld)
+        x32 = torch.randn(N, ci, Lc, device=dev) if b == 0 else None      # block 0 reads the fp32 network input
+        P = L.query("ecg_conv1d_fwd_bf16_yh_stat_partials", N, ci, co, Lc, K, pad, 0 if b == 0 else 1, ld, ld)
         part = torch.empty(co * P * 2, device=dev)
         stamps = torch.zeros(4096 * 8, dtype=torch.int64, device=dev)
         flops = 2.0 * N * co * ci * K * Lc
-        for name in ("fwd", "dgrad"):
+        for name in (("fwd",) if b == 0 else ("fwd", "dgrad")):
             for rep in range(3):
                 stamps.zero_()
                 setter(stamps.data_ptr())
                 if name == "fwd":
-                    L.call("ecg_conv1d_fwd_bf16_yh", L.ptr(xh), 1, ld, L.ptr(wf), L.f32(bias), L.ptr(yh), ld, L.f32(part), N, ci, co,
+                    L.call("ecg_conv1d_fwd_bf16_yh", L.f32(x32) if b == 0 else L.ptr(xh), 0 if b == 0 else 1, ld, L.ptr(wf), L.f32(bias), L.ptr(yh), ld, L.f32(part), N, ci, co,
                            Lc, K, pad, L.stream())
                 else:
                     L.call("ecg_conv1d_bwd_data_bf16hh", L.ptr(dyh), PA, L.ptr(wb), L.ptr(dxh), ld, N, ci, co, Lc, K, pad, L.stream())
