@@ -70,6 +70,35 @@ __device__ __forceinline__ void wait_lgkm() {           // lgkmcnt(N), vmcnt / e
     __builtin_amdgcn_s_waitcnt(0xC07F | (N << 8));
 }
 
+#ifdef ECG_WHATIF_MFMA16
+// WHAT-IF build (timing only, results are garbage): every v_mfma_f32_32x32x16_bf16 of the tap loop replaced by TWO
+// v_mfma_f32_16x16x32_bf16 on quarters of the same accumulator — the same operand registers, LDS reads and matrix-pipe
+// time, twice the matrix instructions: what a 16x16x32 build of this loop would cost / gain (guide rule 28).
+typedef float f32x4w __attribute__((ext_vector_type(4)));
+template <int Q>
+__device__ __forceinline__ void mfma16_q(f32x16 &acc, bf16x8 a, bf16x8 b) {
+    f32x4w q = __builtin_shufflevector(acc, acc, 4 * Q, 4 * Q + 1, 4 * Q + 2, 4 * Q + 3);
+    q = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, q, 0, 0, 0);
+    acc[4 * Q] = q[0]; acc[4 * Q + 1] = q[1]; acc[4 * Q + 2] = q[2]; acc[4 * Q + 3] = q[3];
+}
+template <int PAR>
+__device__ __forceinline__ f32x16 mfma_step(bf16x8 a, bf16x8 b, f32x16 acc) {
+#ifdef ECG_WHATIF_MFMA16_ALLQ       // all four quarters live (even taps 0 / 2, odd taps 1 / 3): hipcc then spills 200-240 bytes per lane
+    mfma16_q<PAR>(acc, a, b);
+    mfma16_q<PAR + 2>(acc, a, b);
+#else                               // optimistic: quarters 1 / 3 stay zero, 80 fewer live registers than a real 16x16x32 build
+    mfma16_q<0>(acc, a, b);
+    mfma16_q<2>(acc, a, b);
+#endif
+    return acc;
+}
+#else
+template <int PAR>
+__device__ __forceinline__ f32x16 mfma_step(bf16x8 a, bf16x8 b, f32x16 acc) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
+}
+#endif
+
 template <class F, int... Is>
 __device__ __forceinline__ void static_for_impl(F &&f, std::integer_sequence<int, Is...>) {
     (f(std::integral_constant<int, Is>{}), ...);
@@ -474,8 +503,8 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(MT == 2 ? 4 
                             constexpr int nread[5] = {1, 2, 2, 1, 1};             // LDS reads issued at step j
                             wait_lgkm<nread[j] + nread[(j + 4) % 5]>();
                             __builtin_amdgcn_sched_barrier(0);   // (hipcc hoists a register-only MFMA above a bare s_waitcnt)
-                            acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa[sj], wf[0], acc[0][j], 0, 0, 0);
-                            acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa[sj], wf[1], acc[1][j], 0, 0, 0);
+                            acc[0][j] = mfma_step<(u & 1)>(xa[sj], wf[0], acc[0][j]);
+                            acc[1][j] = mfma_step<(u & 1)>(xa[sj], wf[1], acc[1][j]);
                             __builtin_amdgcn_sched_barrier(0);
                         });
                         wf[0] = wn[0]; wf[1] = wn[1];
@@ -486,7 +515,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(MT == 2 ? 4 
                             // issued since fragment j was read: the other MT - 1 fragments and the next weight fragment
                             wait_lgkm<MT>();
                             __builtin_amdgcn_sched_barrier(0);
-                            acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa[j], wf[0], acc[0][j], 0, 0, 0);
+                            acc[0][j] = mfma_step<(u & 1)>(xa[j], wf[0], acc[0][j]);
                             xa[j] = ld_x(xbase_n, kn, j);
                             __builtin_amdgcn_sched_barrier(0);
                         }
