@@ -112,6 +112,107 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2))) void lo
     out[(size_t)blockIdx.x * NT + threadIdx.x] = s;
 }
 
+// ---- fp32 MFMA (the parity path: csrc/conv1d_mfma.hip): v_mfma_f32_32x32x2_f32 against v_mfma_f32_16x16x4_f32 ----
+// wave tile 64 x 64 (four 32x32 or sixteen 16x16 accumulators = 64 registers), four waves per workgroup, two workgroups
+// per CU (two waves per SIMD), operands read from LDS one float per lane and k step, as the product kernels do
+constexpr int FK = 64;                       // k steps held in LDS: A [FK][128] + B [FK][128] floats = 64 KB
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void loop_f32_32x32x2(const unsigned *src, float *out, int iters) {
+    __shared__ __attribute__((aligned(16))) float lds[2 * FK * 128];
+    for (int i = threadIdx.x; i < 2 * FK * 128; i += 256) lds[i] = __uint_as_float((src[i % ((XBYTES + WBYTES) / 4)] & 0x807FFFFFu) | 0x3F000000u);
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, half = lane >> 5, l31 = lane & 31;
+    const int wm = (wave & 1) * 64, wn = (wave >> 1) * 64;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    int ao = half * 128 + wm + l31, bo = FK * 128 + half * 128 + wn + l31;
+    for (int it = 0; it < iters; ++it) {
+        asm volatile("" : "+v"(ao), "+v"(bo));
+#pragma unroll
+        for (int k = 0; k < FK; k += 2) {
+            const float a0 = lds[ao + k * 128], a1 = lds[ao + k * 128 + 32];
+            const float b0 = lds[bo + k * 128], b1 = lds[bo + k * 128 + 32];
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+        }
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s += acc[i][j][r];
+    out[(size_t)blockIdx.x * 256 + threadIdx.x] = s;
+}
+
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void loop_f32_16x16x4(const unsigned *src, float *out, int iters) {
+    __shared__ __attribute__((aligned(16))) float lds[2 * FK * 128];
+    for (int i = threadIdx.x; i < 2 * FK * 128; i += 256) lds[i] = __uint_as_float((src[i % ((XBYTES + WBYTES) / 4)] & 0x807FFFFFu) | 0x3F000000u);
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, kq = lane >> 4, l15 = lane & 15;
+    const int wm = (wave & 1) * 64, wn = (wave >> 1) * 64;
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.f;
+    int ao = kq * 128 + wm + l15, bo = FK * 128 + kq * 128 + wn + l15;
+    for (int it = 0; it < iters; ++it) {
+        asm volatile("" : "+v"(ao), "+v"(bo));
+#pragma unroll
+        for (int k = 0; k < FK; k += 4) {
+            float a[4], b[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { a[i] = lds[ao + k * 128 + 16 * i]; b[i] = lds[bo + k * 128 + 16 * i]; }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) s += acc[i][j][r];
+    out[(size_t)blockIdx.x * 256 + threadIdx.x] = s;
+}
+
+static void run_f32(const unsigned *src, float *out, int iters) {
+    hipEvent_t e0, e1;
+    CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+    const int wgs = 512, reps = 10;
+    const double flops = 2.0 * 64 * 64 * FK * (double)iters * 4 * wgs;
+    for (int variant = 0; variant < 2; ++variant) {
+        float best = 1e30f, sum = 0.f;
+        for (int r = 0; r < reps + 2; ++r) {
+            CHECK(hipEventRecord(e0));
+            if (variant == 0) hipLaunchKernelGGL(loop_f32_32x32x2, dim3(wgs), dim3(256), 0, 0, src, out, iters);
+            else hipLaunchKernelGGL(loop_f32_16x16x4, dim3(wgs), dim3(256), 0, 0, src, out, iters);
+            CHECK(hipEventRecord(e1));
+            CHECK(hipEventSynchronize(e1));
+            float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
+            if (r >= 2) { sum += ms; if (ms < best) best = ms; }
+        }
+        const double avg = sum / reps;
+        printf("{\"loop\": \"%s\", \"wave_tile\": \"64x64\", \"waves_per_simd\": 2, \"iters\": %d, \"avg_ms\": %.4f, \"best_ms\": %.4f, "
+               "\"tflops_avg\": %.1f, \"tflops_best\": %.1f, \"frac_of_157.3\": %.3f}\n",
+               variant == 0 ? "v_mfma_f32_32x32x2_f32" : "v_mfma_f32_16x16x4_f32", iters, avg, best,
+               flops / avg / 1e9, flops / best / 1e9, flops / avg / 1e9 / 157.3);
+    }
+}
+
 int main(int argc, char **argv) {
     const int iters = argc > 1 ? atoi(argv[1]) : 400, wgs = 256, reps = 10;
     std::vector<unsigned> h((XBYTES + WBYTES) / 4);
@@ -145,5 +246,6 @@ int main(int argc, char **argv) {
                variant == 0 ? "v_mfma_f32_32x32x16_bf16" : "v_mfma_f32_16x16x32_bf16", iters, avg, best,
                flops / avg / 1e9, flops / best / 1e9, flops / avg / 1e9 / 2500.0);
     }
+    run_f32(src, out, iters);
     return 0;
 }
