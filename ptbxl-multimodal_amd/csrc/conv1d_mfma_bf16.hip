@@ -510,10 +510,15 @@ static int bf16_fwd_any(const void *x, int ldx, bool xh, const void *wb, const f
                         float *partials, int N, int Cin, int Cout, int L, int K, int pad, hipStream_t st) {
     const int Lo = L + 2 * pad - K + 1;
     const u16 *w = static_cast<const u16 *>(wb);
-    // (fp32 input: the rows are [L] floats, read as aligned pairs)
-    if (yh && ((reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(wb)) & 15) == 0 &&
-        (xh || (reinterpret_cast<uintptr_t>(x) & 7) == 0)) {
+    if (yh) {
         const RingPlan rp = bf16_ring_plan(N, Cin, Cout, Lo, K, pad, ldx, ldyo, !xh);
+        // The kernel is chosen by SHAPE only, so that ecg_conv1d_fwd_bf16_yh_stat_partials (which sees no pointers) always
+        // agrees with the launch about the number of partials; operands the chosen kernel cannot address are refused.
+        // (fp32 input: the rows are [L] floats read as aligned pairs; torch allocations and whole-sample slices satisfy both)
+        if (rp.ok)
+            ECG_REQUIRE(((reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(wb)) & 15) == 0 &&
+                            (reinterpret_cast<uintptr_t>(x) & (xh ? 3 : 7)) == 0,
+                        "conv1d bf16 (long rows): y / packed weights must be 16-byte aligned, x %d-byte aligned", xh ? 4 : 8);
         if (rp.ok) return bf16_ring_launch(rp, x, ldx, wb, bias, y, ldyo, partials, rp.G, N, Cin, Cout, L, Lo, pad, st);
     }
     const Bf16Cfg c = bf16_cfg(N, Cout, Lo);

@@ -1098,6 +1098,24 @@ def test_bf16_ring_forward_from_the_fp32_network_input(hip, oracle, case):
     np.testing.assert_allclose(ps[:, 1], (v * v).sum(axis=(0, 2)), rtol=1e-5, atol=1e-3)
 
 
+def test_bf16_ring_refuses_operands_it_cannot_address(hip):
+    """The long-row kernel is picked from the SHAPE alone (so the partials query and the launch always agree); an x that
+    is not 8-byte aligned (a [N][C][L] view at an odd float offset of a flat buffer) is refused, not rerouted."""
+    from ecg_hip import _lib as L
+    N, Ci, Co, Lin = 2, 12, 32, 2048
+    flat = torch.randn(N * Ci * Lin + 1, device="cuda")
+    x = flat[1:].view(N, Ci, Lin)
+    assert x.data_ptr() % 8 == 4
+    w = torch.randn(Co, Ci, 15, device="cuda") * 0.05
+    wb_fwd, _ = hip.conv1d_pack_bf16(w, need_bwd=False)
+    P = L.query("ecg_conv1d_fwd_bf16_yh_stat_partials", N, Ci, Co, Lin, 15, 7, 0, 0, Lin)
+    yh = torch.empty(N, Co, Lin, dtype=torch.bfloat16, device="cuda")
+    part = torch.empty(Co * P * 2, device="cuda")
+    with pytest.raises(L.EcgHipError, match="aligned"):
+        L.call("ecg_conv1d_fwd_bf16_yh", x.data_ptr(), 0, 0, L.ptr(wb_fwd), None, L.ptr(yh), Lin, L.f32(part), N, Ci, Co, Lin,
+               15, 7, L.stream())
+
+
 def test_bf16_ring_fp32_input_full_size_config5_vs_torch(hip):
     """Block 0 of BASELINE.json configs[4] at full size (B=256, 12x5000 -> 32 channels): five 512-step tiles per
     persistent workgroup (an odd count through the two-tile loop body, two workgroups per CU), and the same layer with
