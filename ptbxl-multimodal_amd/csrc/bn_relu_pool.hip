@@ -6,6 +6,8 @@
 // Replaces ATen native_batch_norm(_backward), threshold(_backward), max_pool2d_with_indices
 // (_backward) behind ConvBlock.net[1..3] (reference src/models/ecg_cnn.py:14-16).
 #include "common.h"
+#include <cstdlib>
+#include <mutex>
 
 namespace ecg {
 
@@ -401,6 +403,141 @@ __global__ __launch_bounds__(kBlock) void bn_bwd_dx_kernel(
 }
 
 // ---------------------------------------------------------------------------------------
+// The same backward in ONE launch with its operands RESIDENT IN REGISTERS (round 3).  The two-pass form reads dp and y
+// twice (reduce, then dx: 131 MB for 82 MB of tensors per block at B=256 12x1000) behind two launches.  When a block's
+// (dp, y) fits the register file of the chip — 49 MB against 131 MB, every block of the headline configuration — a grid
+// of C x S <= #CUs workgroups of 1024 threads loads its slice ONCE (up to 16 pooling pairs per thread, all loads in flight
+// together), reduces it, publishes its (sum da, sum da*xhat) partial, waits for the S - 1 workgroups that share its
+// channel, and writes dY from the registers.
+//   * The wait is a counter per channel in device memory: partials stored with agent-scope atomic stores, completed
+//     (vmcnt(0)), then atomicAdd; the waiter spins on an agent-scope atomic load (s_sleep between polls), then reads the S
+//     partials with agent-scope loads in split order (deterministic).  Every workgroup of the grid is resident (host: grid <= CU count, one 1024-thread workgroup per CU
+//     needs 128 registers and no LDS to speak of), so the wait ends; it is BOUNDED all the same (~1 s), after which the
+//     workgroup poisons its output with NaN instead of hanging the device.
+//   * The counters reset themselves: the last of the S workgroups to LEAVE the wait (a second counter) zeroes both.
+//   * S == 1 (C >= #CUs / 1: the last block) needs no wait at all.
+// Arithmetic: the per-element formulas of the two kernels above; the partial sums associate differently (1024 threads,
+// 16 waves), which the parity tests' tolerances cover like any other split count.
+constexpr int kResThreads = 1024, kResPairs = 16, kResMaxC = 1024, kResSpin = 1 << 20;
+
+template <bool AL8>
+__global__ __launch_bounds__(kResThreads) void bn_bwd_resident_kernel(
+    const float *__restrict__ y, const float *__restrict__ g, const float *__restrict__ gamma,
+    const float *__restrict__ beta, const float *__restrict__ mean, const float *__restrict__ invstd,
+    float *__restrict__ partials, int S, double M, float *__restrict__ dgamma, float *__restrict__ dbeta,
+    float *__restrict__ dy, int N, int C, int L, int ldy, float bcast, int train, unsigned *__restrict__ bar) {
+    __shared__ float redf[kResThreads / 64][2];
+    __shared__ float kk[2];
+    const int c = blockIdx.x, s = blockIdx.y, tl = threadIdx.x;
+    const int n0 = (int)((long long)N * s / S), n1 = (int)((long long)N * (s + 1) / S);
+    const float mu = mean[c], is = invstd[c], ga = gamma[c], sc = is * ga, gi = ga * is, be = beta[c];
+    const int Lp = L >> 1, Lr = (L + 1) >> 1;            // pooled positions; pairs per row incl. the odd tail sample
+    const int total = (n1 - n0) * Lr;
+
+    // ---- the slice, once: pair i of this thread = flat pair tl + 1024 i of (sample, pair) ----
+    float y0[kResPairs], y1[kResPairs], d[kResPairs];
+#pragma unroll
+    for (int i = 0; i < kResPairs; ++i) {
+        const int idx = tl + kResThreads * i;
+        const int ic = idx < total ? idx : 0;            // clamped: loads are unconditional (total >= 1)
+        const int nl = ic / Lr, j = ic - nl * Lr;
+        const size_t row = (size_t)(n0 + nl) * C + c;
+        const float *r = y + row * L;
+        if (AL8) ld_pair<true>(r + 2 * j, y0[i], y1[i]);
+        else { y0[i] = r[2 * j]; y1[i] = r[min(2 * j + 1, L - 1)]; }
+        d[i] = bcast != 0.f ? g[row] * bcast : (Lp > 0 ? g[row * (size_t)Lp + min(j, Lp - 1)] : 0.f);
+    }
+    float a = 0.f, q = 0.f;
+#pragma unroll
+    for (int i = 0; i < kResPairs; ++i) {
+        const int idx = tl + kResThreads * i;
+        const int nl = idx / Lr, j = idx - nl * Lr;
+        if (idx < total && j < Lp) {                     // (an odd tail sample never reaches the pool)
+            int am;
+            if (pool_route(y0[i], y1[i], mu, sc, be, am)) {
+                a += d[i];
+                q = __fmaf_rn(d[i], ((am ? y1[i] : y0[i]) - mu) * is, q);
+            }
+        }
+    }
+    a = wave_sum(a); q = wave_sum(q);
+    if ((tl & 63) == 0) { redf[tl >> 6][0] = a; redf[tl >> 6][1] = q; }
+    __syncthreads();
+    if (tl == 0) {
+        float pa = 0.f, pq = 0.f;
+#pragma unroll
+        for (int w = 0; w < kResThreads / 64; ++w) { pa += redf[w][0]; pq += redf[w][1]; }
+        // Agent-scope (sc1) atomic stores / loads for the partials and the counter: they are performed at the memory side,
+        // past the XCD's non-coherent L2, so no L2 write-back / invalidate (__threadfence: measured, it costs more than the
+        // second read of the operands it was meant to save) is needed — only that the two stores have COMPLETED before the
+        // arrival is counted (s_waitcnt vmcnt(0): this thread has nothing else in flight).
+        __hip_atomic_store(&partials[((size_t)c * S + s) * 2], pa, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&partials[((size_t)c * S + s) * 2 + 1], pq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        bool ok = true;
+        if (S > 1) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            atomicAdd(&bar[c], 1u);
+            int spins = 0;
+            while (__hip_atomic_load(&bar[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)S && spins < kResSpin) {
+                __builtin_amdgcn_s_sleep(2);
+                ++spins;
+            }
+            ok = spins < kResSpin;
+        }
+        double ta = 0.0, tq = 0.0;
+        float *pc = partials + (size_t)c * S * 2;
+        for (int p = 0; p < S; ++p) {
+            ta += (double)__hip_atomic_load(&pc[2 * p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            tq += (double)__hip_atomic_load(&pc[2 * p + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (S > 1) {
+            const unsigned left = atomicAdd(&bar[kResMaxC + c], 1u);
+            if (left == (unsigned)S - 1) {               // everybody has left the wait: the counters are free again
+                __hip_atomic_store(&bar[c], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&bar[kResMaxC + c], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        if (s == 0) {
+            if (dbeta) dbeta[c] = ok ? (float)ta : __int_as_float(0x7FC00000);
+            if (dgamma) dgamma[c] = ok ? (float)tq : __int_as_float(0x7FC00000);
+        }
+        kk[0] = !ok ? __int_as_float(0x7FC00000) : (train ? (float)(ta / M) : 0.f);
+        kk[1] = !ok ? __int_as_float(0x7FC00000) : (train ? (float)(tq / M) : 0.f);
+    }
+    __syncthreads();
+    const float k1 = kk[0], k2 = kk[1];
+
+    // ---- dY from the registers ----
+#pragma unroll
+    for (int i = 0; i < kResPairs; ++i) {
+        const int idx = tl + kResThreads * i;
+        if (idx >= total) continue;
+        const int nl = idx / Lr, j = idx - nl * Lr;
+        float *dr = dy + ((size_t)(n0 + nl) * C + c) * (size_t)ldy;
+        const int t = 2 * j;
+        const bool has1 = t + 1 < L;
+        float da0 = 0.f, da1 = 0.f;
+        if (has1) {
+            int am;
+            if (pool_route(y0[i], y1[i], mu, sc, be, am)) {
+                if (am) da1 = d[i]; else da0 = d[i];
+            }
+        }
+        const float o0 = gi * (da0 - k1 - (y0[i] - mu) * is * k2);
+        if (has1) {
+            const float o1 = gi * (da1 - k1 - (y1[i] - mu) * is * k2);
+            if (AL8 && (ldy & 1) == 0) *reinterpret_cast<float2 *>(dr + t) = make_float2(o0, o1);
+            else { dr[t] = o0; dr[t + 1] = o1; }
+        } else dr[t] = o0;
+    }
+    const int padw = ldy - L;                            // zero pad of the row-padded form
+    for (int e = tl; e < (n1 - n0) * padw; e += kResThreads) {
+        const int nl = e / padw, k = e - nl * padw;
+        dy[((size_t)(n0 + nl) * C + c) * (size_t)ldy + L + k] = 0.f;
+    }
+}
+
+// ---------------------------------------------------------------------------------------
 // mixed-precision producers: the same two passes, ALSO emitting their result in the layout the bf16
 // weight-gradient kernel consumes (conv1d_wgrad_bf16.hip): bf16 [sample group of 16][channel][position][16 samples]
 // ("n16"), zero-filled outside the row and past N.  That removes the separate fp32 -> n16 packing passes
@@ -783,11 +920,78 @@ ECG_API size_t ecg_bn_relu_pool_bwd_ws_floats(int N, int C, int L) {
 }
 ECG_API size_t ecg_bn_bwd_ws_floats(int N, int C, int L) { return ecg_bn_relu_pool_bwd_ws_floats(N, C, L); }
 
+// ---- the register-resident one-launch form: when it applies, and its per-(device, stream) counters ----
+struct ResPlan { bool ok; int S; unsigned *bar; };
+static ResPlan resident_plan(const float *y, int N, int C, int L, int ldy, hipStream_t st) {
+    ResPlan p{false, 0, nullptr};
+    static const int enabled = [] {
+        const char *e = getenv("ECG_BN_BWD_RESIDENT");
+        if (e && *e) return atoi(e);
+        // several ranks rehearsing on ONE device could fill it with waiting workgroups of different processes: the wait
+        // below is only free of deadlock when every workgroup of the grid is resident
+        const char *r = getenv("ECG_HIP_REHEARSE_ON_ONE_GPU");
+        return (r && *r == '1') ? 0 : 1;
+    }();
+    if (!enabled) return p;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return p;
+    static int cus[16] = {0};
+    if (!cus[dev]) {
+        int v = 0;
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return p;
+        cus[dev] = v > 0 ? v : -1;
+    }
+    if (cus[dev] < C || C > kResMaxC) return p;
+    int S = cus[dev] / C;
+    if (S > N) S = N;
+    if (S < 1 || S > stat_splits(N, C)) return p;                        // (the workspace holds stat_splits partials per channel)
+    // measured per call at B=256 12x1000 (two-pass -> resident): S = 1 32.1 -> 25.5 us, S = 2 30.2 -> 26.0, S = 4 29.1 -> 26.6,
+    // S = 8 28.4 -> 28.3: the wait costs what the second read saved
+    if (S > 4) return p;
+    const int Lr = (L + 1) / 2;
+    if ((long long)cdiv(N, S) * Lr > (long long)kResThreads * kResPairs) return p;
+    if ((long long)N * C * (ldy > L ? ldy : L) >= (1LL << 31)) return p;
+    (void)y;
+    // counters: one zeroed buffer per (device, stream), at most 8 streams per device; never allocated inside a capture
+    struct Slot { hipStream_t st; unsigned *bar; };
+    static Slot slots[16][8] = {};
+    static std::mutex mu;
+    std::lock_guard<std::mutex> lock(mu);
+    for (int i = 0; i < 8; ++i) {
+        Slot &sl = slots[dev][i];
+        if (sl.bar && sl.st == st) { p.bar = sl.bar; break; }
+        if (!sl.bar) {
+            hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+            if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return p;
+            unsigned *b = nullptr;
+            if (hipMalloc(&b, 2 * kResMaxC * sizeof(unsigned)) != hipSuccess) return p;
+            if (hipMemset(b, 0, 2 * kResMaxC * sizeof(unsigned)) != hipSuccess) { (void)hipFree(b); return p; }
+            sl.st = st; sl.bar = b; p.bar = b;
+            break;
+        }
+    }
+    if (!p.bar) return p;
+    p.ok = true; p.S = S;
+    return p;
+}
+
 template <bool FUSED>
 static int bn_bwd_impl(const float *y, const float *g, const float *gamma, const float *beta,
                        const float *mean, const float *invstd, float *dy, float *dgamma,
                        float *dbeta, float *ws, int N, int C, int L, int ldy, int train,
                        hipStream_t st, float bcast = 0.f) {
+    if (FUSED) {
+        const ResPlan rp = resident_plan(y, N, C, L, ldy, st);
+        if (rp.ok) {
+            if (pairs_aligned(y, L))
+                hipLaunchKernelGGL((bn_bwd_resident_kernel<true>), dim3(C, rp.S), dim3(kResThreads), 0, st, y, g, gamma, beta, mean,
+                                   invstd, ws, rp.S, (double)N * L, dgamma, dbeta, dy, N, C, L, ldy, bcast, train, rp.bar);
+            else
+                hipLaunchKernelGGL((bn_bwd_resident_kernel<false>), dim3(C, rp.S), dim3(kResThreads), 0, st, y, g, gamma, beta, mean,
+                                   invstd, ws, rp.S, (double)N * L, dgamma, dbeta, dy, N, C, L, ldy, bcast, train, rp.bar);
+            return check_launch("bn_bwd_resident_kernel");
+        }
+    }
     const int S = stat_splits(N, C);
     float *partials = ws;
     const bool al8 = FUSED && pairs_aligned(y, L);

@@ -730,15 +730,20 @@ def test_bn_relu_pool_n16_producers_match_the_plain_passes(hip, oracle, shape):
         L.call("ecg_bn_relu_pool_bwd_n16", L.f32(y), L.f32(dp), L.f32(gamma), L.f32(beta), L.f32(mean), L.f32(invstd),
                L.f32(dy) if with_dy else None, Lo, L.ptr(dyb), PA, L.f32(dg), L.f32(db), L.f32(ws), N, C, Lo, 1, 0,
                None if with_dy else L.ptr(dyh), L.stream())
+        # the plain pass may run as the one-launch register-resident kernel, whose partial sums associate differently from
+        # the two-pass n16 producer: the two agree to rounding; the producer's OWN outputs agree with each other exactly
         if with_dy:
-            assert torch.equal(dy, dy_ref)
+            torch.testing.assert_close(dy, dy_ref, rtol=1e-5, atol=1e-6)
+            dy_own, dg_own, db_own = dy.clone(), dg.clone(), db.clone()
         else:       # the bf16 [N][C][PA] copy for the input gradient: bf16-rounded dY, zeros past the row
             wanth = np.zeros((N, C, PA), np.float32)
-            wanth[:, :, :Lo] = _bf16_round(host(dy_ref))
+            wanth[:, :, :Lo] = _bf16_round(host(dy_own))
             assert np.array_equal(dyh.view(N, C, PA).to(torch.float32).cpu().numpy(), wanth)
-        assert torch.equal(dg, dg_ref) and torch.equal(db, db_ref)
+        torch.testing.assert_close(dg, dg_ref, rtol=1e-5, atol=1e-5)
+        torch.testing.assert_close(db, db_ref, rtol=1e-5, atol=1e-5)
+        assert torch.equal(dg, dg_own) and torch.equal(db, db_own)
         want = np.zeros((G * 16, C, PA), np.float32)
-        want[:N, :, :Lo] = _bf16_round(host(dy_ref))
+        want[:N, :, :Lo] = _bf16_round(host(dy_own))
         assert np.array_equal(_unpack_n16(dyb, G, C, PA), want)
 
 
