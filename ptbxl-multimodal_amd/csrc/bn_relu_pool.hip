@@ -418,7 +418,7 @@ __global__ __launch_bounds__(kBlock) void bn_bwd_dx_kernel(
 //   * S == 1 (C >= #CUs / 1: the last block) needs no wait at all.
 // Arithmetic: the per-element formulas of the two kernels above; the partial sums associate differently (1024 threads,
 // 16 waves), which the parity tests' tolerances cover like any other split count.
-constexpr int kResThreads = 1024, kResPairs = 16, kResMaxC = 1024, kResSpin = 1 << 20;
+constexpr int kResThreads = 1024, kResPairs = 16, kResMaxC = 1024, kResMaxS = 16, kResSpin = 1 << 20;
 
 template <bool AL8>
 __global__ __launch_bounds__(kResThreads) void bn_bwd_resident_kernel(
@@ -463,6 +463,8 @@ __global__ __launch_bounds__(kResThreads) void bn_bwd_resident_kernel(
     a = wave_sum(a); q = wave_sum(q);
     if ((tl & 63) == 0) { redf[tl >> 6][0] = a; redf[tl >> 6][1] = q; }
     __syncthreads();
+    __shared__ float sib[2 * kResMaxS];
+    __shared__ int okf;
     if (tl == 0) {
         float pa = 0.f, pq = 0.f;
 #pragma unroll
@@ -484,12 +486,17 @@ __global__ __launch_bounds__(kResThreads) void bn_bwd_resident_kernel(
             }
             ok = spins < kResSpin;
         }
+        okf = ok ? 1 : 0;
+    }
+    __syncthreads();
+    // the 2 S partials of this channel: one load per thread, ONE round trip (read one after the other by a single thread
+    // they cost a memory latency each: S = 8 then gained nothing over the two-pass form)
+    if (tl < 2 * S) sib[tl] = __hip_atomic_load(&partials[(size_t)c * S * 2 + tl], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    if (tl == 0) {
+        const bool ok = okf != 0;
         double ta = 0.0, tq = 0.0;
-        float *pc = partials + (size_t)c * S * 2;
-        for (int p = 0; p < S; ++p) {
-            ta += (double)__hip_atomic_load(&pc[2 * p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            tq += (double)__hip_atomic_load(&pc[2 * p + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
+        for (int p = 0; p < S; ++p) { ta += (double)sib[2 * p]; tq += (double)sib[2 * p + 1]; }     // split order: deterministic
         if (S > 1) {
             const unsigned left = atomicAdd(&bar[kResMaxC + c], 1u);
             if (left == (unsigned)S - 1) {               // everybody has left the wait: the counters are free again
@@ -922,35 +929,48 @@ ECG_API size_t ecg_bn_bwd_ws_floats(int N, int C, int L) { return ecg_bn_relu_po
 
 // ---- the register-resident one-launch form: when it applies, and its per-(device, stream) counters ----
 struct ResPlan { bool ok; int S; unsigned *bar; };
-static ResPlan resident_plan(const float *y, int N, int C, int L, int ldy, hipStream_t st) {
-    ResPlan p{false, 0, nullptr};
+static bool resident_enabled() {
     static const int enabled = [] {
         const char *e = getenv("ECG_BN_BWD_RESIDENT");
         if (e && *e) return atoi(e);
         // several ranks rehearsing on ONE device could fill it with waiting workgroups of different processes: the wait
-        // below is only free of deadlock when every workgroup of the grid is resident
+        // is only free of deadlock when every workgroup of the grid is resident
         const char *r = getenv("ECG_HIP_REHEARSE_ON_ONE_GPU");
         return (r && *r == '1') ? 0 : 1;
     }();
-    if (!enabled) return p;
+    return enabled != 0;
+}
+// the shape part of the decision: splits per channel (0 = two-pass form)
+static int resident_splits(int N, int C, int L, int ldy) {
+    if (!resident_enabled()) return 0;
     int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return p;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return 0;
     static int cus[16] = {0};
     if (!cus[dev]) {
         int v = 0;
-        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return p;
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
         cus[dev] = v > 0 ? v : -1;
     }
-    if (cus[dev] < C || C > kResMaxC) return p;
+    if (cus[dev] < C || C > kResMaxC) return 0;
     int S = cus[dev] / C;
     if (S > N) S = N;
-    if (S < 1 || S > stat_splits(N, C)) return p;                        // (the workspace holds stat_splits partials per channel)
+    if (S < 1 || S > stat_splits(N, C)) return 0;                        // (the workspace holds stat_splits partials per channel)
     // measured per call at B=256 12x1000 (two-pass -> resident): S = 1 32.1 -> 25.5 us, S = 2 30.2 -> 26.0, S = 4 29.1 -> 26.6,
-    // S = 8 28.4 -> 28.3: the wait costs what the second read saved
-    if (S > 4) return p;
+    // S = 8 27.6 -> 27.2: the wait costs what the second read saved; and at B=32 (an eighth of the bytes) the two short
+    // passes win (12-15 us against 14-19): the one-launch form is for slices that fill at least half of its registers
+    if (S > 4) return 0;
     const int Lr = (L + 1) / 2;
-    if ((long long)cdiv(N, S) * Lr > (long long)kResThreads * kResPairs) return p;
-    if ((long long)N * C * (ldy > L ? ldy : L) >= (1LL << 31)) return p;
+    const long long pairs = (long long)cdiv(N, S) * Lr;
+    if (pairs > (long long)kResThreads * kResPairs || pairs < (long long)kResThreads * kResPairs / 2) return 0;
+    if ((long long)N * C * (ldy > L ? ldy : L) >= (1LL << 31)) return 0;
+    return S;
+}
+static ResPlan resident_plan(const float *y, int N, int C, int L, int ldy, hipStream_t st) {
+    ResPlan p{false, 0, nullptr};
+    const int S = resident_splits(N, C, L, ldy);
+    if (!S) return p;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return p;
     (void)y;
     // counters: one zeroed buffer per (device, stream), at most 8 streams per device; never allocated inside a capture
     struct Slot { hipStream_t st; unsigned *bar; };
@@ -1014,6 +1034,10 @@ static int bn_bwd_impl(const float *y, const float *g, const float *gamma, const
         hipLaunchKernelGGL((bn_bwd_dx_kernel<FUSED, false>), dim3(C, S2), dim3(kBlock), 0, st, y, g, gamma, beta, mean,
                            invstd, partials, S, (double)N * L, dgamma, dbeta, dy, N, C, L, ldy, Lh, S2, bcast, train);
     return check_launch("bn_bwd_dx_kernel");
+}
+
+ECG_API int ecg_bn_relu_pool_bwd_launches(int N, int C, int L, int ldy) {
+    return resident_splits(N, C, L, ldy) ? 1 : 2;
 }
 
 ECG_API int ecg_bn_relu_pool_bwd_ld(const float *y, const float *dp, const float *gamma,

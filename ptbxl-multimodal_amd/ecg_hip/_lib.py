@@ -25,6 +25,7 @@ SIGNATURES = {
     "ecg_check_device": (_i, []),
     "ecg_conv1d_pack_weights": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),
     "ecg_pack_weights_grouped": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
+    "ecg_bn_relu_pool_bwd_launches": (_i, [_i, _i, _i, _i]),
     "ecg_pack_weights_grouped_mixed": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
     "ecg_conv1d_fwd_stat_partials": (_i, [_i, _i, _i, _i, _i, _i]),
     "ecg_conv1d_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),

@@ -280,6 +280,49 @@ def test_bn_relu_pool_bwd_writes_row_padded_dy(hip, oracle, shape, gap):
     np.testing.assert_allclose(d0, rdy, atol=2e-5)
 
 
+# (N, C, L, gap): blocks 1-3 of the headline configuration (S = 4, 2, 1 workgroups per channel; L = 125 is odd: scalar
+# loads, an unpooled tail sample per row), an uneven sample split, and block 0 (S = 8), which keeps the two passes
+@pytest.mark.parametrize("case", [(256, 64, 500, False), (256, 128, 250, False), (256, 256, 125, True), (256, 256, 125, False),
+                                  (201, 128, 250, False), (256, 32, 1000, False)])
+def test_bn_backward_in_one_launch_with_resident_operands_vs_oracle(hip, oracle, case):
+    """ecg_bn_relu_pool_bwd_ld / _gap_bwd_ld at the sizes where a block's (dp, y) fits the register file: one launch
+    (bn_bwd_resident_kernel: slice loaded once, per-channel exchange of the partial sums through a device counter, dY
+    from registers).  Same contract as the two-pass form: dY / dgamma / dbeta vs the oracle, the row-padded form writes
+    the same values plus a zero pad, two calls give identical bits (fixed summation order), and the counters are left
+    clean (a third call behaves like the first)."""
+    from ecg_hip import _lib as L
+    N, C, Lo, gap = case
+    ldy = (Lo + 63) // 64 * 64
+    assert L.query("ecg_bn_relu_pool_bwd_launches", N, C, Lo, ldy) == (2 if C == 32 else 1)
+    assert L.query("ecg_bn_relu_pool_bwd_launches", 32, C, Lo, ldy) == 2          # small batches keep the two short passes
+    rng = np.random.default_rng(N + C + Lo)
+    y = (rng.standard_normal((N, C, Lo)) * 1.5 + 0.3).astype(np.float32)
+    gamma = (1 + 0.2 * rng.standard_normal(C)).astype(np.float32)
+    beta = (0.2 * rng.standard_normal(C)).astype(np.float32)
+    mean, invstd = oracle.bn_stats(y)
+    g = rng.standard_normal((N, C) if gap else (N, C, Lo // 2)).astype(np.float32)
+    yd, gd, bd, md, isd, gg = map(dev, (y, gamma, beta, mean, invstd, g))
+    ws = torch.empty(L.query("ecg_bn_relu_pool_bwd_ws_floats", N, C, Lo), device="cuda")
+    outs = []
+    for stride in (Lo, ldy, ldy):
+        dy = torch.full((N, C, stride), float("nan"), device="cuda")
+        dgam, dbet = torch.full((C,), float("nan"), device="cuda"), torch.full((C,), float("nan"), device="cuda")
+        L.call("ecg_bn_relu_pool_gap_bwd_ld" if gap else "ecg_bn_relu_pool_bwd_ld",
+               *map(L.f32, (yd, gg, gd, bd, md, isd, dy)), stride, *map(L.f32, (dgam, dbet, ws)), N, C, Lo, 1, L.stream())
+        outs.append((host(dy), host(dgam), host(dbet)))
+    (d0, g0, b0), (d1, g1, b1), (d2, g2, b2) = outs
+    np.testing.assert_array_equal(d1[:, :, :Lo], d0)
+    assert not d1[:, :, Lo:].any()
+    np.testing.assert_array_equal(d2, d1)
+    for a, b in ((g0, g1), (b0, b1), (g1, g2), (b1, b2)):
+        np.testing.assert_array_equal(a, b)
+    dp = np.repeat(g[:, :, None] / (Lo // 2), Lo // 2, axis=2).astype(np.float32) if gap else g
+    rdy, rdg, rdb = oracle.bn_relu_pool_bwd(y, dp, gamma, beta, mean, invstd, True)
+    np.testing.assert_allclose(d0, rdy, atol=2e-5)
+    np.testing.assert_allclose(g0, rdg, rtol=2e-4, atol=2e-3)
+    np.testing.assert_allclose(b0, rdb, rtol=2e-4, atol=2e-3)
+
+
 def test_unfused_leaves_compose_to_fused(hip, oracle):
     """BatchNormFn -> ReLUFn -> MaxPool2Fn (hook path) equals the fused kernel, fwd and bwd."""
     torch.manual_seed(0)
