@@ -254,6 +254,11 @@ int ecg_bn_stats_relu_pool_fwd(const float *stat_partials, int P, long long coun
  * pass + dx pass.  The two forms associate the partial sums differently (both deterministic).  Same reference call
  * site: autograd of ConvBlock.net[1..3], src/models/ecg_cnn.py:14-16.  ECG_BN_BWD_RESIDENT=0 forces the two passes. */
 int ecg_bn_relu_pool_bwd_launches(int N, int C, int L, int ldy);
+/* Process-wide runtime switch for the one-launch form (returns the previous setting; the shape query above ignores it).
+ * Turn it OFF while collectives can run on another stream during backward (ecg_hip.optim.FlatAdamW / ecg_hip.ddp do that
+ * for their hook-issued all-reduces): a communication kernel waiting for a late peer keeps its CUs, and this kernel's
+ * bounded wait would then last as long as the peer is late. */
+int ecg_bn_bwd_one_launch_enable(int on);
 
 size_t ecg_bn_relu_pool_bwd_ws_floats(int N, int C, int L);
 /* Backward of the fused tail: dp [N][C][L/2] -> dy [N][C][L], dgamma[C], dbeta[C].

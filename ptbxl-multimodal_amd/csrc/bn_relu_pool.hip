@@ -6,6 +6,7 @@
 // Replaces ATen native_batch_norm(_backward), threshold(_backward), max_pool2d_with_indices
 // (_backward) behind ConvBlock.net[1..3] (reference src/models/ecg_cnn.py:14-16).
 #include "common.h"
+#include <atomic>
 #include <cstdlib>
 #include <mutex>
 
@@ -412,13 +413,13 @@ __global__ __launch_bounds__(kBlock) void bn_bwd_dx_kernel(
 //   * The wait is a counter per channel in device memory: partials stored with agent-scope atomic stores, completed
 //     (vmcnt(0)), then atomicAdd; the waiter spins on an agent-scope atomic load (s_sleep between polls), then reads the S
 //     partials with agent-scope loads in split order (deterministic).  Every workgroup of the grid is resident (host: grid <= CU count, one 1024-thread workgroup per CU
-//     needs 128 registers and no LDS to speak of), so the wait ends; it is BOUNDED all the same (~1 s), after which the
+//     needs 128 registers and no LDS to speak of), so the wait ends; it is BOUNDED all the same (a few seconds), after which the
 //     workgroup poisons its output with NaN instead of hanging the device.
 //   * The counters reset themselves: the last of the S workgroups to LEAVE the wait (a second counter) zeroes both.
 //   * S == 1 (C >= #CUs / 1: the last block) needs no wait at all.
 // Arithmetic: the per-element formulas of the two kernels above; the partial sums associate differently (1024 threads,
 // 16 waves), which the parity tests' tolerances cover like any other split count.
-constexpr int kResThreads = 1024, kResPairs = 16, kResMaxC = 1024, kResMaxS = 16, kResSpin = 1 << 20;
+constexpr int kResThreads = 1024, kResPairs = 16, kResMaxC = 1024, kResMaxS = 16, kResSpin = 1 << 22;
 
 template <bool AL8>
 __global__ __launch_bounds__(kResThreads) void bn_bwd_resident_kernel(
@@ -965,8 +966,14 @@ static int resident_splits(int N, int C, int L, int ldy) {
     if ((long long)N * C * (ldy > L ? ldy : L) >= (1LL << 31)) return 0;
     return S;
 }
+// Runtime switch (ecg_bn_bwd_one_launch_enable): the host turns the one-launch form OFF while collectives may run on
+// another stream DURING backward (the hook-issued bucket all-reduces of ecg_hip.optim / ecg_hip.ddp): an RCCL kernel that
+// waits for a late peer holds its CUs, a 1024-thread workgroup of this kernel cannot be placed beside it, and its
+// siblings would sit in the bounded wait for as long as the peer is late.
+static std::atomic<int> g_resident_runtime{1};
 static ResPlan resident_plan(const float *y, int N, int C, int L, int ldy, hipStream_t st) {
     ResPlan p{false, 0, nullptr};
+    if (!g_resident_runtime.load(std::memory_order_relaxed)) return p;
     const int S = resident_splits(N, C, L, ldy);
     if (!S) return p;
     int dev = 0;
@@ -1034,6 +1041,10 @@ static int bn_bwd_impl(const float *y, const float *g, const float *gamma, const
         hipLaunchKernelGGL((bn_bwd_dx_kernel<FUSED, false>), dim3(C, S2), dim3(kBlock), 0, st, y, g, gamma, beta, mean,
                            invstd, partials, S, (double)N * L, dgamma, dbeta, dy, N, C, L, ldy, Lh, S2, bcast, train);
     return check_launch("bn_bwd_dx_kernel");
+}
+
+ECG_API int ecg_bn_bwd_one_launch_enable(int on) {
+    return g_resident_runtime.exchange(on ? 1 : 0, std::memory_order_relaxed);
 }
 
 ECG_API int ecg_bn_relu_pool_bwd_launches(int N, int C, int L, int ldy) {

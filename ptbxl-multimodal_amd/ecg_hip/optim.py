@@ -101,11 +101,18 @@ class FlatAdamW(torch.optim.Optimizer):
             # Python to come back from backward() and reach step()
             for p in self._params[:self._n_early]:
                 p.register_post_accumulate_grad_hook(self._on_early_grad)
+            self._note_overlap()
 
     def __del__(self):
         try:
             from . import functional as F
             F.unregister_grad_sinks(self._sink_keys)
+        except Exception:
+            pass
+        try:
+            if getattr(self, "_overlap_active", False) and self.flat_param.is_cuda:
+                from . import _lib
+                _lib.collectives_during_backward(self, False)
         except Exception:
             pass
 
@@ -144,7 +151,15 @@ class FlatAdamW(torch.optim.Optimizer):
             raise RuntimeError("FlatAdamW.set_overlap: an exchange is in flight (call it between steps)")
         self._overlap_active = bool(on) and self._overlap
         self._late_pending = self._early_pending = 0
+        self._note_overlap()
         return self._overlap_active
+
+    def _note_overlap(self):
+        # all-reduces issued under backward share the device with the backward kernels: tell the library (it then keeps the
+        # BatchNorm backward in its two-pass form, whose progress never depends on a communication kernel leaving a CU)
+        if self.flat_param.is_cuda:
+            from . import _lib
+            _lib.collectives_during_backward(self, self._overlap_active)
 
     def calibrate_overlap(self, run_steps, steps=10, warm=3):
         """Pick the faster exchange form ON THIS NODE: `run_steps(n)` must run n complete train steps (forward,

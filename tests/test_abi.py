@@ -72,3 +72,22 @@ def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
     with pytest.raises(_lib.EcgHipError, match="missing"):
         _lib.load()
+
+
+def test_one_launch_batchnorm_backward_is_switched_off_while_hooks_issue_collectives(lib):
+    """ecg_bn_bwd_one_launch_enable is a process-wide switch returning the previous setting; the Python bookkeeping turns
+    it off while at least one owner (an optimizer whose gradient hooks issue all-reduces under backward) is active."""
+    from ecg_hip import _lib as L
+    f = lib.ecg_bn_bwd_one_launch_enable
+    assert f(1) in (0, 1)
+    assert f(0) == 1 and f(0) == 0 and f(1) == 0 and f(1) == 1
+    a, b = object(), object()
+    L.collectives_during_backward(a, True)
+    assert f(0) == 0                      # already off
+    L.collectives_during_backward(b, True)
+    L.collectives_during_backward(a, False)
+    assert f(0) == 0                      # b still active
+    L.collectives_during_backward(b, False)
+    assert f(1) == 1                      # back on once nobody overlaps
+    L.collectives_during_backward(b, False)            # idempotent
+    assert f(1) == 1
