@@ -12,6 +12,7 @@
 // workgroup needs are contiguous and wave-uniform, so they arrive through the scalar cache
 // (s_load_dwordx8/x16) and feed v_fma_f32 as SGPR operands — one LDS read of x feeds CO_T FMAs.
 #include "common.h"
+#include <cstdlib>
 
 namespace ecg {
 
@@ -287,9 +288,64 @@ __global__ __launch_bounds__(64 * G) void wgrad_reduce_kernel(const float *__res
     }
 }
 
+// The same sums, four consecutive outputs per lane (16-byte loads: a quarter of the load instructions, four times the
+// bytes in flight per wave) — when the slab and the bias row are whole float4s.  Per output the slabs are added in exactly
+// the order of the kernel above (wave w: slabs w, w+G, ...; then waves in order): bit-identical results.
+template <int G>
+__global__ __launch_bounds__(64 * G) void wgrad_reduce4_kernel(const float *__restrict__ slab, float *__restrict__ dw,
+                                                               float *__restrict__ db, size_t wslab, int Cout, int S) {
+    __shared__ double part[G][64][4];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const size_t i = ((size_t)blockIdx.x * 64 + lane) * 4;
+    const size_t total = wslab + Cout;
+    const bool live = i < total && (i < wslab || db);
+    double a[4] = {0.0, 0.0, 0.0, 0.0};
+    if (live) {
+        const float *src = i < wslab ? slab + i : slab + (size_t)S * wslab + (i - wslab);
+        const size_t stride = i < wslab ? wslab : (size_t)Cout;
+        int s = w;
+        for (; s + 3 * G < S; s += 4 * G) {
+            const float4 v0 = *reinterpret_cast<const float4 *>(src + (size_t)s * stride);
+            const float4 v1 = *reinterpret_cast<const float4 *>(src + (size_t)(s + G) * stride);
+            const float4 v2 = *reinterpret_cast<const float4 *>(src + (size_t)(s + 2 * G) * stride);
+            const float4 v3 = *reinterpret_cast<const float4 *>(src + (size_t)(s + 3 * G) * stride);
+            a[0] += (double)v0.x; a[0] += (double)v1.x; a[0] += (double)v2.x; a[0] += (double)v3.x;
+            a[1] += (double)v0.y; a[1] += (double)v1.y; a[1] += (double)v2.y; a[1] += (double)v3.y;
+            a[2] += (double)v0.z; a[2] += (double)v1.z; a[2] += (double)v2.z; a[2] += (double)v3.z;
+            a[3] += (double)v0.w; a[3] += (double)v1.w; a[3] += (double)v2.w; a[3] += (double)v3.w;
+        }
+        for (; s < S; s += G) {
+            const float4 v = *reinterpret_cast<const float4 *>(src + (size_t)s * stride);
+            a[0] += (double)v.x; a[1] += (double)v.y; a[2] += (double)v.z; a[3] += (double)v.w;
+        }
+    }
+    if (G > 1) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) part[w][lane][e] = a[e];
+        __syncthreads();
+        if (w != 0) return;
+#pragma unroll
+        for (int g = 1; g < G; ++g)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) a[e] += part[g][lane][e];
+    }
+    if (live) {
+        const float4 o = make_float4((float)a[0], (float)a[1], (float)a[2], (float)a[3]);
+        if (i < wslab) *reinterpret_cast<float4 *>(dw + i) = o; else *reinterpret_cast<float4 *>(db + (i - wslab)) = o;
+    }
+}
+
 int wgrad_reduce(const float *ws, float *dw, float *db, size_t wslab, int Cout, int S,
                  hipStream_t st) {
     const size_t total = wslab + Cout;
+    // the float4 form pays where a workgroup is ONE wave walking few, large slabs (blocks 2-3 of the model: block 3
+    // 262 -> 259 us per weight-gradient call); with G > 1 (many small slabs) its LDS combine is four times larger and it
+    // measured 2-3 us slower on block 0
+    if (wslab % 4 == 0 && Cout % 4 == 0 && (size_t)cdiv(total, 64) >= 1024 &&
+        ((reinterpret_cast<uintptr_t>(ws) | reinterpret_cast<uintptr_t>(dw) | reinterpret_cast<uintptr_t>(db)) & 15) == 0) {
+        hipLaunchKernelGGL((wgrad_reduce4_kernel<1>), dim3(cdiv(total / 4, 64)), dim3(64), 0, st, ws, dw, db, wslab, Cout, S);
+        return check_launch("wgrad_reduce4_kernel");
+    }
     const dim3 grid(cdiv(total, 64));
     // enough waves to fill the chip (~1024) without going below 8 slabs per wave
     int G = 1;
