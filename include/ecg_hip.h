@@ -250,7 +250,8 @@ int ecg_bn_stats_relu_pool_fwd(const float *stat_partials, int P, long long coun
 
 /* 1 when ecg_bn_relu_pool_bwd[_ld] / ecg_bn_relu_pool_gap_bwd[_ld] run as ONE launch for this shape (the operands of a
  * block fit the register file of the device: every workgroup loads its slice once, the workgroups of a channel exchange
- * their partial sums through a bounded wait on a device counter, dY is written from registers), 2 for the reduction
+ * their partial sums through a bounded wait on a device counter — a workgroup whose siblings do not arrive recomputes
+ * their sums itself, bit for bit — and dY is written from registers), 2 for the reduction
  * pass + dx pass.  The two forms associate the partial sums differently (both deterministic).  Same reference call
  * site: autograd of ConvBlock.net[1..3], src/models/ecg_cnn.py:14-16.  ECG_BN_BWD_RESIDENT=0 forces the two passes. */
 int ecg_bn_relu_pool_bwd_launches(int N, int C, int L, int ldy);

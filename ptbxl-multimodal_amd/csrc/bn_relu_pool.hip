@@ -413,20 +413,22 @@ __global__ __launch_bounds__(kBlock) void bn_bwd_dx_kernel(
 //   * The wait is a counter per channel in device memory: partials stored with agent-scope atomic stores, completed
 //     (vmcnt(0)), then atomicAdd; the waiter spins on an agent-scope atomic load (s_sleep between polls), then reads the S
 //     partials with agent-scope loads in split order (deterministic).  Every workgroup of the grid is resident (host: grid <= CU count, one 1024-thread workgroup per CU
-//     needs 128 registers and no LDS to speak of), so the wait ends; it is BOUNDED all the same (a few seconds), after which the
-//     workgroup poisons its output with NaN instead of hanging the device.
+//     needs 128 registers and no LDS to speak of), so the wait ends at once in the normal case; it is BOUNDED (~1 ms), after
+//     which the workgroup stops waiting and recomputes the missing partials itself (see SELF-SERVICE below): a co-tenant
+//     that keeps siblings from becoming resident costs time, never correctness, and no wait can be circular.
 //   * The counters reset themselves: the last of the S workgroups to LEAVE the wait (a second counter) zeroes both.
 //   * S == 1 (C >= #CUs / 1: the last block) needs no wait at all.
 // Arithmetic: the per-element formulas of the two kernels above; the partial sums associate differently (1024 threads,
 // 16 waves), which the parity tests' tolerances cover like any other split count.
-constexpr int kResThreads = 1024, kResPairs = 16, kResMaxC = 1024, kResMaxS = 16, kResSpin = 1 << 22;
+constexpr int kResThreads = 1024, kResPairs = 16, kResMaxC = 1024, kResMaxS = 16, kResSpin = 512;
 
 template <bool AL8>
 __global__ __launch_bounds__(kResThreads) void bn_bwd_resident_kernel(
     const float *__restrict__ y, const float *__restrict__ g, const float *__restrict__ gamma,
     const float *__restrict__ beta, const float *__restrict__ mean, const float *__restrict__ invstd,
     float *__restrict__ partials, int S, double M, float *__restrict__ dgamma, float *__restrict__ dbeta,
-    float *__restrict__ dy, int N, int C, int L, int ldy, float bcast, int train, unsigned *__restrict__ bar) {
+    float *__restrict__ dy, int N, int C, int L, int ldy, float bcast, int train, unsigned *__restrict__ bar,
+    int spin_limit) {
     __shared__ float redf[kResThreads / 64][2];
     __shared__ float kk[2];
     const int c = blockIdx.x, s = blockIdx.y, tl = threadIdx.x;
@@ -464,7 +466,7 @@ __global__ __launch_bounds__(kResThreads) void bn_bwd_resident_kernel(
     a = wave_sum(a); q = wave_sum(q);
     if ((tl & 63) == 0) { redf[tl >> 6][0] = a; redf[tl >> 6][1] = q; }
     __syncthreads();
-    __shared__ float sib[2 * kResMaxS];
+    __shared__ float sib[2 * kResMaxS], own[2];
     __shared__ int okf;
     if (tl == 0) {
         float pa = 0.f, pq = 0.f;
@@ -476,26 +478,68 @@ __global__ __launch_bounds__(kResThreads) void bn_bwd_resident_kernel(
         // arrival is counted (s_waitcnt vmcnt(0): this thread has nothing else in flight).
         __hip_atomic_store(&partials[((size_t)c * S + s) * 2], pa, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(&partials[((size_t)c * S + s) * 2 + 1], pq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        own[0] = pa; own[1] = pq;
         bool ok = true;
         if (S > 1) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             atomicAdd(&bar[c], 1u);
             int spins = 0;
-            while (__hip_atomic_load(&bar[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)S && spins < kResSpin) {
+            while (__hip_atomic_load(&bar[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)S && spins < spin_limit) {
                 __builtin_amdgcn_s_sleep(2);
                 ++spins;
             }
-            ok = spins < kResSpin;
+            ok = spins < spin_limit;                     // (spin_limit = 0, the test hook: always the self-service path)
         }
         okf = ok ? 1 : 0;
     }
     __syncthreads();
-    // the 2 S partials of this channel: one load per thread, ONE round trip (read one after the other by a single thread
-    // they cost a memory latency each: S = 8 then gained nothing over the two-pass form)
-    if (tl < 2 * S) sib[tl] = __hip_atomic_load(&partials[(size_t)c * S * 2 + tl], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (okf) {
+        // the 2 S partials of this channel: one load per thread, ONE round trip (read one after the other by a single
+        // thread they cost a memory latency each: S = 8 then gained nothing over the two-pass form)
+        if (tl < 2 * S) sib[tl] = __hip_atomic_load(&partials[(size_t)c * S * 2 + tl], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+        // SELF-SERVICE (uniform branch): a sibling has not arrived within ~1 ms — it is not resident (another process's
+        // workgroups, or a communication kernel waiting for a late peer, hold its CU).  Instead of waiting for it this
+        // workgroup recomputes the siblings' partials from memory itself: the same pair -> thread mapping, the same order
+        // of additions, the same combine — bit for bit the numbers the siblings will publish.  It then finishes and frees
+        // its CU, so any circular wait between co-tenants dissolves; the late siblings find the counter where they need
+        // it (every workgroup still arrives and leaves exactly once) and the counters reset as usual.
+        for (int s2 = 0; s2 < S; ++s2) {
+            if (s2 == s) { if (tl == 0) { sib[2 * s2] = own[0]; sib[2 * s2 + 1] = own[1]; } continue; }
+            const int m0 = (int)((long long)N * s2 / S), m1 = (int)((long long)N * (s2 + 1) / S);
+            const int tot2 = (m1 - m0) * Lr;
+            float a2 = 0.f, q2 = 0.f;
+            for (int i = 0; i < kResPairs; ++i) {
+                const int idx = tl + kResThreads * i;
+                if (idx >= tot2) break;
+                const int nl = idx / Lr, j = idx - nl * Lr;
+                if (j >= Lp) continue;
+                const size_t row = (size_t)(m0 + nl) * C + c;
+                const float *r = y + row * L;
+                float u0, u1;
+                if (AL8) ld_pair<true>(r + 2 * j, u0, u1);
+                else { u0 = r[2 * j]; u1 = r[min(2 * j + 1, L - 1)]; }
+                const float dd = bcast != 0.f ? g[row] * bcast : g[row * (size_t)Lp + j];
+                int am;
+                if (pool_route(u0, u1, mu, sc, be, am)) {
+                    a2 += dd;
+                    q2 = __fmaf_rn(dd, ((am ? u1 : u0) - mu) * is, q2);
+                }
+            }
+            a2 = wave_sum(a2); q2 = wave_sum(q2);
+            __syncthreads();
+            if ((tl & 63) == 0) { redf[tl >> 6][0] = a2; redf[tl >> 6][1] = q2; }
+            __syncthreads();
+            if (tl == 0) {
+                float pa = 0.f, pq = 0.f;
+#pragma unroll
+                for (int w = 0; w < kResThreads / 64; ++w) { pa += redf[w][0]; pq += redf[w][1]; }
+                sib[2 * s2] = pa; sib[2 * s2 + 1] = pq;
+            }
+        }
+    }
     __syncthreads();
     if (tl == 0) {
-        const bool ok = okf != 0;
         double ta = 0.0, tq = 0.0;
         for (int p = 0; p < S; ++p) { ta += (double)sib[2 * p]; tq += (double)sib[2 * p + 1]; }     // split order: deterministic
         if (S > 1) {
@@ -506,11 +550,11 @@ __global__ __launch_bounds__(kResThreads) void bn_bwd_resident_kernel(
             }
         }
         if (s == 0) {
-            if (dbeta) dbeta[c] = ok ? (float)ta : __int_as_float(0x7FC00000);
-            if (dgamma) dgamma[c] = ok ? (float)tq : __int_as_float(0x7FC00000);
+            if (dbeta) dbeta[c] = (float)ta;
+            if (dgamma) dgamma[c] = (float)tq;
         }
-        kk[0] = !ok ? __int_as_float(0x7FC00000) : (train ? (float)(ta / M) : 0.f);
-        kk[1] = !ok ? __int_as_float(0x7FC00000) : (train ? (float)(tq / M) : 0.f);
+        kk[0] = train ? (float)(ta / M) : 0.f;
+        kk[1] = train ? (float)(tq / M) : 0.f;
     }
     __syncthreads();
     const float k1 = kk[0], k2 = kk[1];
@@ -1010,12 +1054,14 @@ static int bn_bwd_impl(const float *y, const float *g, const float *gamma, const
     if (FUSED) {
         const ResPlan rp = resident_plan(y, N, C, L, ldy, st);
         if (rp.ok) {
+            // ECG_BN_BWD_RESIDENT_SPIN (tests): polls before a workgroup stops waiting for its siblings; 0 = never wait
+            static const int spin_limit = [] { const char *e = getenv("ECG_BN_BWD_RESIDENT_SPIN"); return e && *e ? atoi(e) : kResSpin; }();
             if (pairs_aligned(y, L))
                 hipLaunchKernelGGL((bn_bwd_resident_kernel<true>), dim3(C, rp.S), dim3(kResThreads), 0, st, y, g, gamma, beta, mean,
-                                   invstd, ws, rp.S, (double)N * L, dgamma, dbeta, dy, N, C, L, ldy, bcast, train, rp.bar);
+                                   invstd, ws, rp.S, (double)N * L, dgamma, dbeta, dy, N, C, L, ldy, bcast, train, rp.bar, spin_limit);
             else
                 hipLaunchKernelGGL((bn_bwd_resident_kernel<false>), dim3(C, rp.S), dim3(kResThreads), 0, st, y, g, gamma, beta, mean,
-                                   invstd, ws, rp.S, (double)N * L, dgamma, dbeta, dy, N, C, L, ldy, bcast, train, rp.bar);
+                                   invstd, ws, rp.S, (double)N * L, dgamma, dbeta, dy, N, C, L, ldy, bcast, train, rp.bar, spin_limit);
             return check_launch("bn_bwd_resident_kernel");
         }
     }

@@ -1,6 +1,8 @@
 """GPU parity of every kernel, called through the C ABI (ecg_hip._lib / functional raw
 launches), against the CPU oracle on the same seeded inputs and against the golden fixtures.
 Tolerances: fp32 kernels vs a double-accumulating oracle; north_star bar is 1e-4 on logits."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -321,6 +323,44 @@ def test_bn_backward_in_one_launch_with_resident_operands_vs_oracle(hip, oracle,
     np.testing.assert_allclose(d0, rdy, atol=2e-5)
     np.testing.assert_allclose(g0, rdg, rtol=2e-4, atol=2e-3)
     np.testing.assert_allclose(b0, rdb, rtol=2e-4, atol=2e-3)
+
+
+def test_bn_backward_one_launch_self_service_gives_the_same_bits(tmp_path):
+    """A workgroup of the one-launch BatchNorm backward that does not see its siblings arrive (they are not resident: a
+    co-tenant holds their CUs) stops waiting and recomputes their partial sums itself.  Forced here for EVERY workgroup
+    (ECG_BN_BWD_RESIDENT_SPIN=0: nobody waits): dY, dgamma, dbeta must be bit-identical to the run in which the
+    workgroups exchange their partials, on the first call and on the second (counters left clean)."""
+    import subprocess
+    import sys
+    worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "bn_resident_worker.py")
+    outs = []
+    for spin in (None, "0"):
+        env = dict(os.environ)
+        env.pop("ECG_BN_BWD_RESIDENT", None), env.pop("ECG_HIP_REHEARSE_ON_ONE_GPU", None)
+        if spin is not None:
+            env["ECG_BN_BWD_RESIDENT_SPIN"] = spin
+        out = tmp_path / f"spin_{spin}.npz"
+        r = subprocess.run([sys.executable, worker, str(out)], env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append(dict(np.load(out)))
+    assert outs[0].keys() == outs[1].keys() and len(outs[0]) == 24
+    for k in outs[0]:
+        assert not np.isnan(outs[0][k]).any(), k
+        np.testing.assert_array_equal(outs[0][k], outs[1][k], err_msg=k)
+        if k.endswith("_1"):
+            np.testing.assert_array_equal(outs[0][k], outs[0][k[:-1] + "0"], err_msg=k)
+    # two co-tenant processes on the device at once (each kernel wants one workgroup on EVERY CU): whoever does not
+    # become fully resident serves itself; both must still produce the solo run's bits
+    env = dict(os.environ)
+    env.pop("ECG_BN_BWD_RESIDENT", None), env.pop("ECG_HIP_REHEARSE_ON_ONE_GPU", None), env.pop("ECG_BN_BWD_RESIDENT_SPIN", None)
+    procs = [subprocess.Popen([sys.executable, worker, str(tmp_path / f"co_{i}.npz")], env=env, stdout=subprocess.PIPE,
+                              stderr=subprocess.PIPE, text=True) for i in range(2)]
+    for i, pr in enumerate(procs):
+        _, err = pr.communicate(timeout=300)
+        assert pr.returncode == 0, err[-2000:]
+        got = dict(np.load(tmp_path / f"co_{i}.npz"))
+        for k in outs[0]:
+            np.testing.assert_array_equal(got[k], outs[0][k], err_msg=f"co-tenant {i}: {k}")
 
 
 def test_unfused_leaves_compose_to_fused(hip, oracle):
