@@ -258,7 +258,7 @@ int ecg_bn_relu_pool_bwd_launches(int N, int C, int L, int ldy);
 /* Process-wide runtime switch for the one-launch form (returns the previous setting; the shape query above ignores it).
  * Turn it OFF while collectives can run on another stream during backward (ecg_hip.optim.FlatAdamW / ecg_hip.ddp do that
  * for their hook-issued all-reduces): a communication kernel waiting for a late peer keeps its CUs, and this kernel's
- * bounded wait would then last as long as the peer is late. */
+ * workgroups would then run out their (bounded) wait and take the slow self-service path on every call. */
 int ecg_bn_bwd_one_launch_enable(int on);
 
 size_t ecg_bn_relu_pool_bwd_ws_floats(int N, int C, int L);
