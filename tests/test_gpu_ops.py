@@ -283,9 +283,11 @@ def test_bn_relu_pool_bwd_writes_row_padded_dy(hip, oracle, shape, gap):
 
 
 # (N, C, L, gap): blocks 1-3 of the headline configuration (S = 4, 2, 1 workgroups per channel; L = 125 is odd: scalar
-# loads, an unpooled tail sample per row), an uneven sample split, and block 0 (S = 8), which keeps the two passes
+# loads, an unpooled tail sample per row), an uneven sample split, block 0 (S = 8), which keeps the two passes, and
+# shapes off the model's grid (channel counts that do not divide the CU count, odd rows, ragged splits)
 @pytest.mark.parametrize("case", [(256, 64, 500, False), (256, 128, 250, False), (256, 256, 125, True), (256, 256, 125, False),
-                                  (201, 128, 250, False), (256, 32, 1000, False)])
+                                  (201, 128, 250, False), (256, 32, 1000, False),
+                                  (180, 100, 301, False), (97, 200, 222, True), (64, 256, 500, False)])
 def test_bn_backward_in_one_launch_with_resident_operands_vs_oracle(hip, oracle, case):
     """ecg_bn_relu_pool_bwd_ld / _gap_bwd_ld at the sizes where a block's (dp, y) fits the register file: one launch
     (bn_bwd_resident_kernel: slice loaded once, per-channel exchange of the partial sums through a device counter, dY
