@@ -448,7 +448,8 @@ __global__ __launch_bounds__(kResThreads) void bn_bwd_resident_kernel(
         const float *r = y + row * L;
         if (AL8) ld_pair<true>(r + 2 * j, y0[i], y1[i]);
         else { y0[i] = r[2 * j]; y1[i] = r[min(2 * j + 1, L - 1)]; }
-        d[i] = bcast != 0.f ? g[row] * bcast : (Lp > 0 ? g[row * (size_t)Lp + min(j, Lp - 1)] : 0.f);
+        d[i] = bcast != 0.f ? __fmul_rn(g[row], bcast) : (Lp > 0 ? g[row * (size_t)Lp + min(j, Lp - 1)] : 0.f);   // (a product that can
+        // never be contracted into the sums below: the self-service path must reproduce these numbers bit for bit)
     }
     float a = 0.f, q = 0.f;
 #pragma unroll
@@ -519,7 +520,7 @@ __global__ __launch_bounds__(kResThreads) void bn_bwd_resident_kernel(
                 float u0, u1;
                 if (AL8) ld_pair<true>(r + 2 * j, u0, u1);
                 else { u0 = r[2 * j]; u1 = r[min(2 * j + 1, L - 1)]; }
-                const float dd = bcast != 0.f ? g[row] * bcast : g[row * (size_t)Lp + j];
+                const float dd = bcast != 0.f ? __fmul_rn(g[row], bcast) : g[row * (size_t)Lp + j];
                 int am;
                 if (pool_route(u0, u1, mu, sc, be, am)) {
                     a2 += dd;

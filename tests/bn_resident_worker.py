@@ -16,7 +16,8 @@ def main(out):
     from ecg_hip import _lib as L
     L.load()
     res = {}
-    for N, C, Lo, gap in ((256, 64, 500, False), (201, 128, 250, False), (256, 256, 125, True), (256, 128, 250, False)):
+    for N, C, Lo, gap in ((256, 64, 500, False), (201, 128, 250, False), (256, 256, 125, True), (256, 128, 250, False),
+                          (180, 100, 301, True)):
         g = torch.Generator().manual_seed(N + C + Lo)
         y = (torch.randn(N, C, Lo, generator=g) * 1.5 + 0.3).cuda()
         dp = torch.randn((N, C) if gap else (N, C, Lo // 2), generator=g).cuda()

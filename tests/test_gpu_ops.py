@@ -345,7 +345,7 @@ def test_bn_backward_one_launch_self_service_gives_the_same_bits(tmp_path):
         r = subprocess.run([sys.executable, worker, str(out)], env=env, capture_output=True, text=True, timeout=300)
         assert r.returncode == 0, r.stderr[-2000:]
         outs.append(dict(np.load(out)))
-    assert outs[0].keys() == outs[1].keys() and len(outs[0]) == 24
+    assert outs[0].keys() == outs[1].keys() and len(outs[0]) == 30
     for k in outs[0]:
         assert not np.isnan(outs[0][k]).any(), k
         np.testing.assert_array_equal(outs[0][k], outs[1][k], err_msg=k)
