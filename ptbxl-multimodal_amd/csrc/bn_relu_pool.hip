@@ -44,8 +44,14 @@ __device__ __forceinline__ void ld_pair_y(const float *y, size_t row, int ld, in
 // workgroup pays the folded statistics combine once, none waits for a slot).  Measured per train step at B=256 12x1000:
 // 1024: +9 us, 1536: -3, 2048: -10, 2560: +6, 3072: +3, 4096: 0 (round 1's value), 8192: +42.
 constexpr int kStreamBlocks = 2048;
-static int stat_splits(int N, int C) {
-    int s = cdiv(1024, C);             // (2048 measured the same, 512 slower)
+// workgroups of the reduce passes per channel.  fp32 operands: 1024 in all (2048 measured the same at 12x1000, 512 slower).
+// bf16 operands (the bf16-storage backward, `wide`): 2048 — that pass is bound by the latency of its dependent load rounds
+// (6 bytes per position: the number of loads in flight per thread, the per-position instruction count and the walk order
+// were all varied without effect), and twice the workgroups took 4-11 us off every backward call of 12x5000 (config-5 step
+// 1.449 -> 1.415 ms); 4096 adds nothing.  ECG_BN_SPLITS overrides both (tuning).
+static int stat_splits(int N, int C, bool wide = false) {
+    static const int forced = [] { const char *e = getenv("ECG_BN_SPLITS"); return e && *e ? atoi(e) : 0; }();
+    int s = cdiv(forced ? forced : (wide ? 2048 : 1024), C);
     if (s > N) s = N;
     if (s < 1) s = 1;
     return s;
@@ -969,7 +975,7 @@ ECG_API int ecg_bn_stats_relu_pool_fwd_yh(const float *stat_partials, int P, lon
 
 ECG_API size_t ecg_bn_relu_pool_bwd_ws_floats(int N, int C, int L) {
     (void)L;
-    return (size_t)C * stat_splits(N, C) * 2 + (size_t)C * 2;
+    return (size_t)C * stat_splits(N, C, true) * 2 + (size_t)C * 2;      // (room for the bf16-storage pass's split count)
 }
 ECG_API size_t ecg_bn_bwd_ws_floats(int N, int C, int L) { return ecg_bn_relu_pool_bwd_ws_floats(N, C, L); }
 
@@ -1218,7 +1224,7 @@ static int bwd_n16_impl(const char *who, const float *y, bool yh, int ldyy, cons
     ECG_REQUIRE(!dh || (yh && !gap && ldp >= L / 2), "%s: a bf16 dp needs a bf16 y, no global average pool and a row stride >= L/2",
                 who);
     const float bcast = gap ? 1.0f / (float)(L / 2) : 0.f;
-    const int S = stat_splits(N, C);
+    const int S = stat_splits(N, C, true);       // (the whole n16 family: its bf16- and fp32-operand forms then add the same numbers in the same order)
     const bool al8 = !yh && pairs_aligned(y, L);
 #define ECG_RED(AL8, YH, DH) hipLaunchKernelGGL((bn_bwd_reduce_kernel<true, AL8, YH, DH>), dim3(C, S), dim3(kBlock), 0, st, y, \
                                                 dp, gamma, beta, mean, invstd, ws, N, C, L, S, bcast, yh ? ldyy : L, ldp)
