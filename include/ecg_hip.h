@@ -16,7 +16,8 @@
  *   - Every entry point returns 0 on success and a nonzero ECG_E* code otherwise; the
  *     message is available from ecg_last_error() (thread-local).  No exception crosses
  *     the ABI.  Shapes are validated on the host before any launch.
- *   - Entry points are re-entrant, keep no global mutable state and launch on the
+ *   - Entry points are re-entrant, keep no global mutable state (the only thing cached is
+ *     the CU count of a device), read no environment variable and launch on the
  *     stream handed in (a hipStream_t passed as void*; NULL = the null stream).  They
  *     never synchronise the device.  Forward is called on the Python main thread,
  *     backward on torch's autograd engine thread.
@@ -248,18 +249,31 @@ int ecg_bn_stats_relu_pool_fwd(const float *stat_partials, int P, long long coun
                                float *invstd, float *out, void *p_n16, int N, int C, int L, int PX, int shift,
                                int mode, ecg_stream_t stream);
 
-/* 1 when ecg_bn_relu_pool_bwd[_ld] / ecg_bn_relu_pool_gap_bwd[_ld] run as ONE launch for this shape (the operands of a
- * block fit the register file of the device: every workgroup loads its slice once, the workgroups of a channel exchange
- * their partial sums through a bounded wait on a device counter — a workgroup whose siblings do not arrive recomputes
- * their sums itself, bit for bit — and dY is written from registers), 2 for the reduction
- * pass + dx pass.  The two forms associate the partial sums differently (both deterministic).  Same reference call
- * site: autograd of ConvBlock.net[1..3], src/models/ecg_cnn.py:14-16.  ECG_BN_BWD_RESIDENT=0 forces the two passes. */
-int ecg_bn_relu_pool_bwd_launches(int N, int C, int L, int ldy);
-/* Process-wide runtime switch for the one-launch form (returns the previous setting; the shape query above ignores it).
- * Turn it OFF while collectives can run on another stream during backward (ecg_hip.optim.FlatAdamW / ecg_hip.ddp do that
- * for their hook-issued all-reduces): a communication kernel waiting for a late peer keeps its CUs, and this kernel's
- * workgroups would then run out their (bounded) wait and take the slow self-service path on every call. */
-int ecg_bn_bwd_one_launch_enable(int on);
+/* ONE-LAUNCH form of ecg_bn_relu_pool_bwd_ld / ecg_bn_relu_pool_gap_bwd_ld (same reference call site: autograd of
+ * ConvBlock.net[1..3], src/models/ecg_cnn.py:14-16): when the (dp, y) slice of a block fits the register file of the
+ * device, C x S <= #CUs workgroups load their slice once, the S workgroups of a channel exchange their partial sums, and
+ * dY is written from registers (one read of the operands instead of two, one launch instead of two).
+ *   ..._splits(N, C, L, ldy)          S >= 1 when the shape takes this form on the current device, 0 when it does not
+ *                                     (then call the two-pass entry points).  The CALLER decides which form to use.
+ *   ..._counter_uints(N, C, L, ldy)   uint32 words of `counters` the launch needs (0 when S <= 1).
+ *   counters                          CALLER-OWNED exchange words (8-byte aligned): all zero before the first launch, left
+ *                                     all zero by every launch, so one buffer serves any sequence of launches that are
+ *                                     ordered on a stream; launches that may run CONCURRENTLY need separate buffers.  The
+ *                                     library allocates nothing and keeps no state between calls.
+ *   The exchange: each partial sum travels with its own "valid" tag in one 64-bit word (a single agent-scope atomic store;
+ *   pollers use agent-scope atomic loads), so no ordering between different locations is assumed.  The wait is bounded:
+ *   after `spin_polls` polls (< 0: the default, about 1 ms; 0: never wait) a workgroup recomputes its siblings' sums from
+ *   memory itself, bit for bit what they publish — a co-tenant that keeps siblings off the device (another process, a
+ *   communication kernel waiting for a late peer) costs time, never correctness.  Use the two-pass form while collectives
+ *   run on the device during backward (ecg_hip.functional.declare_backward_collectives).
+ *   gap != 0: dp is dg [N][C] (the global-average-pool form).  The two forms associate the partial sums differently
+ *   (both deterministic). */
+int ecg_bn_relu_pool_bwd_one_launch_splits(int N, int C, int L, int ldy);
+size_t ecg_bn_relu_pool_bwd_one_launch_counter_uints(int N, int C, int L, int ldy);
+int ecg_bn_relu_pool_bwd_one_launch(const float *y, const float *dp, const float *gamma, const float *beta,
+                                    const float *mean, const float *invstd, float *dy, int ldy,
+                                    float *dgamma, float *dbeta, uint32_t *counters, int N, int C, int L,
+                                    int train, int gap, int spin_polls, ecg_stream_t stream);
 
 size_t ecg_bn_relu_pool_bwd_ws_floats(int N, int C, int L);
 /* Backward of the fused tail: dp [N][C][L/2] -> dy [N][C][L], dgamma[C], dbeta[C].

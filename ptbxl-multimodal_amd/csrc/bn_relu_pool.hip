@@ -8,7 +8,6 @@
 #include "common.h"
 #include <atomic>
 #include <cstdlib>
-#include <mutex>
 
 namespace ecg {
 
@@ -50,8 +49,7 @@ constexpr int kStreamBlocks = 2048;
 // were all varied without effect), and twice the workgroups took 4-11 us off every backward call of 12x5000 (config-5 step
 // 1.449 -> 1.415 ms); 4096 adds nothing.  ECG_BN_SPLITS overrides both (tuning).
 static int stat_splits(int N, int C, bool wide = false) {
-    static const int forced = [] { const char *e = getenv("ECG_BN_SPLITS"); return e && *e ? atoi(e) : 0; }();
-    int s = cdiv(forced ? forced : (wide ? 2048 : 1024), C);
+    int s = cdiv(wide ? 2048 : 1024, C);
     if (s > N) s = N;
     if (s < 1) s = 1;
     return s;
@@ -416,25 +414,36 @@ __global__ __launch_bounds__(kBlock) void bn_bwd_dx_kernel(
 // of C x S <= #CUs workgroups of 1024 threads loads its slice ONCE (up to 16 pooling pairs per thread, all loads in flight
 // together), reduces it, publishes its (sum da, sum da*xhat) partial, waits for the S - 1 workgroups that share its
 // channel, and writes dY from the registers.
-//   * The wait is a counter per channel in device memory: partials stored with agent-scope atomic stores, completed
-//     (vmcnt(0)), then atomicAdd; the waiter spins on an agent-scope atomic load (s_sleep between polls), then reads the S
-//     partials with agent-scope loads in split order (deterministic).  Every workgroup of the grid is resident (host: grid <= CU count, one 1024-thread workgroup per CU
-//     needs 128 registers and no LDS to speak of), so the wait ends at once in the normal case; it is BOUNDED (~1 ms), after
+//   * The exchange needs NO ordering between different memory locations: a partial sum travels in ONE 64-bit word
+//     together with its own "valid" tag — {float bits, 1} stored by a single agent-scope atomic store (performed at the
+//     memory side, past the XCD's non-coherent L2; single-copy atomic for an aligned 8-byte word).  A waiter polls the 2 S
+//     words of its channel with agent-scope atomic loads, one word per thread (s_sleep between polls), until every tag is
+//     set: whoever sees the tag has the value.  (Round 3 published plain partials + a counter and relied on
+//     s_waitcnt vmcnt(0) between them — an argument from hardware behaviour, not from the memory model.)
+//     Every workgroup of the grid is resident (host: grid <= CU count; one 1024-thread workgroup per CU needs 128
+//     registers and no LDS to speak of), so the wait ends at once in the normal case; it is BOUNDED (spin_polls), after
 //     which the workgroup stops waiting and recomputes the missing partials itself (see SELF-SERVICE below): a co-tenant
 //     that keeps siblings from becoming resident costs time, never correctness, and no wait can be circular.
-//   * The counters reset themselves: the last of the S workgroups to LEAVE the wait (a second counter) zeroes both.
-//   * S == 1 (C >= #CUs / 1: the last block) needs no wait at all.
+//   * The words live in CALLER-OWNED memory (`counters`: ecg_bn_relu_pool_bwd_one_launch_counter_uints() uint32, zero before
+//     the first launch) and return to zero by themselves: every workgroup counts itself out (`left[c]`, after the values it
+//     polled have been consumed into LDS) and the last of the S to leave clears the 2 S words and the count.  The library
+//     allocates nothing and keeps nothing between calls; two launches that may run concurrently need two buffers.
+//   * S == 1 (C >= #CUs: the last block) needs no exchange at all and never touches `counters`.
 // Arithmetic: the per-element formulas of the two kernels above; the partial sums associate differently (1024 threads,
 // 16 waves), which the parity tests' tolerances cover like any other split count.
-constexpr int kResThreads = 1024, kResPairs = 16, kResMaxC = 1024, kResMaxS = 16, kResSpin = 512;
+constexpr int kResThreads = 1024, kResPairs = 16, kResMaxC = 1024, kResMaxS = 4, kResSpin = 512;
+
+__device__ __forceinline__ unsigned long long res_word(float v) {      // {value bits, tag = 1}
+    return (1ull << 32) | (unsigned long long)__float_as_uint(v);
+}
 
 template <bool AL8>
 __global__ __launch_bounds__(kResThreads) void bn_bwd_resident_kernel(
     const float *__restrict__ y, const float *__restrict__ g, const float *__restrict__ gamma,
     const float *__restrict__ beta, const float *__restrict__ mean, const float *__restrict__ invstd,
-    float *__restrict__ partials, int S, double M, float *__restrict__ dgamma, float *__restrict__ dbeta,
-    float *__restrict__ dy, int N, int C, int L, int ldy, float bcast, int train, unsigned *__restrict__ bar,
-    int spin_limit) {
+    int S, double M, float *__restrict__ dgamma, float *__restrict__ dbeta,
+    float *__restrict__ dy, int N, int C, int L, int ldy, float bcast, int train,
+    unsigned long long *__restrict__ words, unsigned *__restrict__ left, int spin_limit) {
     __shared__ float redf[kResThreads / 64][2];
     __shared__ float kk[2];
     const int c = blockIdx.x, s = blockIdx.y, tl = threadIdx.x;
@@ -474,36 +483,34 @@ __global__ __launch_bounds__(kResThreads) void bn_bwd_resident_kernel(
     if ((tl & 63) == 0) { redf[tl >> 6][0] = a; redf[tl >> 6][1] = q; }
     __syncthreads();
     __shared__ float sib[2 * kResMaxS], own[2];
-    __shared__ int okf;
     if (tl == 0) {
         float pa = 0.f, pq = 0.f;
 #pragma unroll
         for (int w = 0; w < kResThreads / 64; ++w) { pa += redf[w][0]; pq += redf[w][1]; }
-        // Agent-scope (sc1) atomic stores / loads for the partials and the counter: they are performed at the memory side,
-        // past the XCD's non-coherent L2, so no L2 write-back / invalidate (__threadfence: measured, it costs more than the
-        // second read of the operands it was meant to save) is needed — only that the two stores have COMPLETED before the
-        // arrival is counted (s_waitcnt vmcnt(0): this thread has nothing else in flight).
-        __hip_atomic_store(&partials[((size_t)c * S + s) * 2], pa, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(&partials[((size_t)c * S + s) * 2 + 1], pq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         own[0] = pa; own[1] = pq;
-        bool ok = true;
-        if (S > 1) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            atomicAdd(&bar[c], 1u);
-            int spins = 0;
-            while (__hip_atomic_load(&bar[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)S && spins < spin_limit) {
-                __builtin_amdgcn_s_sleep(2);
-                ++spins;
-            }
-            ok = spins < spin_limit;                     // (spin_limit = 0, the test hook: always the self-service path)
+        if (S > 1) {            // value and tag in one word: nothing has to be ordered against anything else
+            __hip_atomic_store(&words[((size_t)c * S + s) * 2], res_word(pa), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&words[((size_t)c * S + s) * 2 + 1], res_word(pq), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        okf = ok ? 1 : 0;
     }
-    __syncthreads();
+    int mine_ok = 1;
+    if (S > 1 && tl < 2 * S) {
+        // one word per thread, all 2 S polled at once: ONE round trip in the normal case
+        const unsigned long long *wp = &words[(size_t)c * S * 2 + tl];
+        unsigned long long v = 0;
+        int polls = 0;
+        mine_ok = 0;
+        while (polls < spin_limit) {                     // (spin_limit = 0, the test hook: nobody waits — always self-service)
+            v = __hip_atomic_load(wp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if ((unsigned)(v >> 32) != 0u) { mine_ok = 1; break; }
+            __builtin_amdgcn_s_sleep(2);
+            ++polls;
+        }
+        if (mine_ok) sib[tl] = __uint_as_float((unsigned)v);
+    }
+    const int okf = __syncthreads_and(mine_ok);          // (also publishes own[] and sib[] to the workgroup)
     if (okf) {
-        // the 2 S partials of this channel: one load per thread, ONE round trip (read one after the other by a single
-        // thread they cost a memory latency each: S = 8 then gained nothing over the two-pass form)
-        if (tl < 2 * S) sib[tl] = __hip_atomic_load(&partials[(size_t)c * S * 2 + tl], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (S == 1 && tl == 0) { sib[0] = own[0]; sib[1] = own[1]; }
     } else {
         // SELF-SERVICE (uniform branch): a sibling has not arrived within ~1 ms — it is not resident (another process's
         // workgroups, or a communication kernel waiting for a late peer, hold its CU).  Instead of waiting for it this
@@ -550,10 +557,14 @@ __global__ __launch_bounds__(kResThreads) void bn_bwd_resident_kernel(
         double ta = 0.0, tq = 0.0;
         for (int p = 0; p < S; ++p) { ta += (double)sib[2 * p]; tq += (double)sib[2 * p + 1]; }     // split order: deterministic
         if (S > 1) {
-            const unsigned left = atomicAdd(&bar[kResMaxC + c], 1u);
-            if (left == (unsigned)S - 1) {               // everybody has left the wait: the counters are free again
-                __hip_atomic_store(&bar[c], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(&bar[kResMaxC + c], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            // count this workgroup out.  Its polled values have been CONSUMED (they sit in LDS, behind a barrier), and every
+            // workgroup publishes before it leaves: when the count reaches S all 2 S words are set and nobody will read them
+            // again, so the last one out clears them (and the count) for the next launch that is handed this buffer.
+            const unsigned gone = __hip_atomic_fetch_add(&left[c], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (gone == (unsigned)S - 1) {
+                for (int p = 0; p < 2 * S; ++p)
+                    __hip_atomic_store(&words[(size_t)c * S * 2 + p], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&left[c], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
         if (s == 0) {
@@ -979,78 +990,33 @@ ECG_API size_t ecg_bn_relu_pool_bwd_ws_floats(int N, int C, int L) {
 }
 ECG_API size_t ecg_bn_bwd_ws_floats(int N, int C, int L) { return ecg_bn_relu_pool_bwd_ws_floats(N, C, L); }
 
-// ---- the register-resident one-launch form: when it applies, and its per-(device, stream) counters ----
-struct ResPlan { bool ok; int S; unsigned *bar; };
-static bool resident_enabled() {
-    static const int enabled = [] {
-        const char *e = getenv("ECG_BN_BWD_RESIDENT");
-        if (e && *e) return atoi(e);
-        // several ranks rehearsing on ONE device could fill it with waiting workgroups of different processes: the wait
-        // is only free of deadlock when every workgroup of the grid is resident
-        const char *r = getenv("ECG_HIP_REHEARSE_ON_ONE_GPU");
-        return (r && *r == '1') ? 0 : 1;
-    }();
-    return enabled != 0;
-}
-// the shape part of the decision: splits per channel (0 = two-pass form)
+// ---- the register-resident one-launch form: when a shape takes it (the caller owns the decision and the counters) ----
+// Splits per channel, 0 = the shape does not qualify.  The only state is the CU count of each device, cached on first use
+// (a device attribute, not a setting).
 static int resident_splits(int N, int C, int L, int ldy) {
-    if (!resident_enabled()) return 0;
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return 0;
-    static int cus[16] = {0};
-    if (!cus[dev]) {
+    static std::atomic<int> cus[16];
+    int ncu = cus[dev].load(std::memory_order_relaxed);
+    if (!ncu) {
         int v = 0;
         if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
-        cus[dev] = v > 0 ? v : -1;
+        ncu = v > 0 ? v : -1;
+        cus[dev].store(ncu, std::memory_order_relaxed);
     }
-    if (cus[dev] < C || C > kResMaxC) return 0;
-    int S = cus[dev] / C;
+    if (ncu < C || C > kResMaxC) return 0;
+    int S = ncu / C;
     if (S > N) S = N;
-    if (S < 1 || S > stat_splits(N, C)) return 0;                        // (the workspace holds stat_splits partials per channel)
+    if (S < 1) return 0;
     // measured per call at B=256 12x1000 (two-pass -> resident): S = 1 32.1 -> 25.5 us, S = 2 30.2 -> 26.0, S = 4 29.1 -> 26.6,
     // S = 8 27.6 -> 27.2: the wait costs what the second read saved; and at B=32 (an eighth of the bytes) the two short
     // passes win (12-15 us against 14-19): the one-launch form is for slices that fill at least half of its registers
-    if (S > 4) return 0;
+    if (S > kResMaxS) return 0;
     const int Lr = (L + 1) / 2;
     const long long pairs = (long long)cdiv(N, S) * Lr;
     if (pairs > (long long)kResThreads * kResPairs || pairs < (long long)kResThreads * kResPairs / 2) return 0;
     if ((long long)N * C * (ldy > L ? ldy : L) >= (1LL << 31)) return 0;
     return S;
-}
-// Runtime switch (ecg_bn_bwd_one_launch_enable): the host turns the one-launch form OFF while collectives may run on
-// another stream DURING backward (the hook-issued bucket all-reduces of ecg_hip.optim / ecg_hip.ddp): an RCCL kernel that
-// waits for a late peer holds its CUs, a 1024-thread workgroup of this kernel cannot be placed beside it, and its
-// siblings would sit in the bounded wait for as long as the peer is late.
-static std::atomic<int> g_resident_runtime{1};
-static ResPlan resident_plan(const float *y, int N, int C, int L, int ldy, hipStream_t st) {
-    ResPlan p{false, 0, nullptr};
-    if (!g_resident_runtime.load(std::memory_order_relaxed)) return p;
-    const int S = resident_splits(N, C, L, ldy);
-    if (!S) return p;
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess) return p;
-    (void)y;
-    // counters: one zeroed buffer per (device, stream), at most 8 streams per device; never allocated inside a capture
-    struct Slot { hipStream_t st; unsigned *bar; };
-    static Slot slots[16][8] = {};
-    static std::mutex mu;
-    std::lock_guard<std::mutex> lock(mu);
-    for (int i = 0; i < 8; ++i) {
-        Slot &sl = slots[dev][i];
-        if (sl.bar && sl.st == st) { p.bar = sl.bar; break; }
-        if (!sl.bar) {
-            hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-            if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return p;
-            unsigned *b = nullptr;
-            if (hipMalloc(&b, 2 * kResMaxC * sizeof(unsigned)) != hipSuccess) return p;
-            if (hipMemset(b, 0, 2 * kResMaxC * sizeof(unsigned)) != hipSuccess) { (void)hipFree(b); return p; }
-            sl.st = st; sl.bar = b; p.bar = b;
-            break;
-        }
-    }
-    if (!p.bar) return p;
-    p.ok = true; p.S = S;
-    return p;
 }
 
 template <bool FUSED>
@@ -1058,20 +1024,6 @@ static int bn_bwd_impl(const float *y, const float *g, const float *gamma, const
                        const float *mean, const float *invstd, float *dy, float *dgamma,
                        float *dbeta, float *ws, int N, int C, int L, int ldy, int train,
                        hipStream_t st, float bcast = 0.f) {
-    if (FUSED) {
-        const ResPlan rp = resident_plan(y, N, C, L, ldy, st);
-        if (rp.ok) {
-            // ECG_BN_BWD_RESIDENT_SPIN (tests): polls before a workgroup stops waiting for its siblings; 0 = never wait
-            static const int spin_limit = [] { const char *e = getenv("ECG_BN_BWD_RESIDENT_SPIN"); return e && *e ? atoi(e) : kResSpin; }();
-            if (pairs_aligned(y, L))
-                hipLaunchKernelGGL((bn_bwd_resident_kernel<true>), dim3(C, rp.S), dim3(kResThreads), 0, st, y, g, gamma, beta, mean,
-                                   invstd, ws, rp.S, (double)N * L, dgamma, dbeta, dy, N, C, L, ldy, bcast, train, rp.bar, spin_limit);
-            else
-                hipLaunchKernelGGL((bn_bwd_resident_kernel<false>), dim3(C, rp.S), dim3(kResThreads), 0, st, y, g, gamma, beta, mean,
-                                   invstd, ws, rp.S, (double)N * L, dgamma, dbeta, dy, N, C, L, ldy, bcast, train, rp.bar, spin_limit);
-            return check_launch("bn_bwd_resident_kernel");
-        }
-    }
     const int S = stat_splits(N, C);
     float *partials = ws;
     const bool al8 = FUSED && pairs_aligned(y, L);
@@ -1096,12 +1048,42 @@ static int bn_bwd_impl(const float *y, const float *g, const float *gamma, const
     return check_launch("bn_bwd_dx_kernel");
 }
 
-ECG_API int ecg_bn_bwd_one_launch_enable(int on) {
-    return g_resident_runtime.exchange(on ? 1 : 0, std::memory_order_relaxed);
+ECG_API int ecg_bn_relu_pool_bwd_one_launch_splits(int N, int C, int L, int ldy) {
+    if (N <= 0 || C <= 0 || L <= 0 || ldy < L) return 0;
+    return resident_splits(N, C, L, ldy);
 }
 
-ECG_API int ecg_bn_relu_pool_bwd_launches(int N, int C, int L, int ldy) {
-    return resident_splits(N, C, L, ldy) ? 1 : 2;
+ECG_API size_t ecg_bn_relu_pool_bwd_one_launch_counter_uints(int N, int C, int L, int ldy) {
+    const int S = ecg_bn_relu_pool_bwd_one_launch_splits(N, C, L, ldy);
+    return S > 1 ? (size_t)C * (4 * (size_t)S + 1) : 0;      // 2 S 64-bit words per channel + one leave count per channel
+}
+
+ECG_API int ecg_bn_relu_pool_bwd_one_launch(const float *y, const float *dp, const float *gamma, const float *beta,
+                                            const float *mean, const float *invstd, float *dy, int ldy,
+                                            float *dgamma, float *dbeta, uint32_t *counters, int N, int C, int L,
+                                            int train, int gap, int spin_polls, ecg_stream_t stream) {
+    int rc = check_ncl("bn_relu_pool_bwd_one_launch", N, C, L);
+    if (rc) return rc;
+    ECG_REQUIRE(y && dp && gamma && beta && mean && invstd && dy, "bn_relu_pool_bwd_one_launch: null pointer");
+    ECG_REQUIRE(ldy >= L, "bn_relu_pool_bwd_one_launch: dY row stride %d < row length %d", ldy, L);
+    const int S = resident_splits(N, C, L, ldy);
+    ECG_REQUIRE(S > 0, "bn_relu_pool_bwd_one_launch: N=%d C=%d L=%d does not take the one-launch form on this device "
+                "(ask ecg_bn_relu_pool_bwd_one_launch_splits first)", N, C, L);
+    ECG_REQUIRE(S == 1 || (counters && (reinterpret_cast<uintptr_t>(counters) & 7) == 0),
+                "bn_relu_pool_bwd_one_launch: %d workgroups per channel need the caller's 8-byte aligned counter buffer", S);
+    unsigned long long *words = reinterpret_cast<unsigned long long *>(counters);
+    unsigned *left = S > 1 ? reinterpret_cast<unsigned *>(counters) + (size_t)C * 4 * S : nullptr;
+    const int spin = spin_polls < 0 ? kResSpin : spin_polls;
+    const float bcast = gap ? 1.0f / (float)(L / 2) : 0.f;
+    ECG_REQUIRE(!gap || L >= 2, "bn_relu_pool_bwd_one_launch: L=%d leaves an empty pooled row", L);
+    hipStream_t st = as_stream(stream);
+    if (pairs_aligned(y, L))
+        hipLaunchKernelGGL((bn_bwd_resident_kernel<true>), dim3(C, S), dim3(kResThreads), 0, st, y, dp, gamma, beta, mean,
+                           invstd, S, (double)N * L, dgamma, dbeta, dy, N, C, L, ldy, bcast, train, words, left, spin);
+    else
+        hipLaunchKernelGGL((bn_bwd_resident_kernel<false>), dim3(C, S), dim3(kResThreads), 0, st, y, dp, gamma, beta, mean,
+                           invstd, S, (double)N * L, dgamma, dbeta, dy, N, C, L, ldy, bcast, train, words, left, spin);
+    return check_launch("bn_bwd_resident_kernel");
 }
 
 ECG_API int ecg_bn_relu_pool_bwd_ld(const float *y, const float *dp, const float *gamma,

@@ -70,34 +70,12 @@ __device__ __forceinline__ void wait_lgkm() {           // lgkmcnt(N), vmcnt / e
     __builtin_amdgcn_s_waitcnt(0xC07F | (N << 8));
 }
 
-#ifdef ECG_WHATIF_MFMA16
-// WHAT-IF build (timing only, results are garbage): every v_mfma_f32_32x32x16_bf16 of the tap loop replaced by TWO
-// v_mfma_f32_16x16x32_bf16 on quarters of the same accumulator — the same operand registers, LDS reads and matrix-pipe
-// time, twice the matrix instructions: what a 16x16x32 build of this loop would cost / gain (guide rule 28).
-typedef float f32x4w __attribute__((ext_vector_type(4)));
-template <int Q>
-__device__ __forceinline__ void mfma16_q(f32x16 &acc, bf16x8 a, bf16x8 b) {
-    f32x4w q = __builtin_shufflevector(acc, acc, 4 * Q, 4 * Q + 1, 4 * Q + 2, 4 * Q + 3);
-    q = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, q, 0, 0, 0);
-    acc[4 * Q] = q[0]; acc[4 * Q + 1] = q[1]; acc[4 * Q + 2] = q[2]; acc[4 * Q + 3] = q[3];
-}
-template <int PAR>
-__device__ __forceinline__ f32x16 mfma_step(bf16x8 a, bf16x8 b, f32x16 acc) {
-#ifdef ECG_WHATIF_MFMA16_ALLQ       // all four quarters live (even taps 0 / 2, odd taps 1 / 3): hipcc then spills 200-240 bytes per lane
-    mfma16_q<PAR>(acc, a, b);
-    mfma16_q<PAR + 2>(acc, a, b);
-#else                               // optimistic: quarters 1 / 3 stay zero, 80 fewer live registers than a real 16x16x32 build
-    mfma16_q<0>(acc, a, b);
-    mfma16_q<2>(acc, a, b);
-#endif
-    return acc;
-}
-#else
+// (The timing-only 16x16x32 what-if variant of this step — profiles/r03_mfma_shape_whatif.txt — lived here in round 3;
+// it was removed from the product source once measured: 3-7 % at best against a certain spill.)
 template <int PAR>
 __device__ __forceinline__ f32x16 mfma_step(bf16x8 a, bf16x8 b, f32x16 acc) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
 }
-#endif
 
 template <class F, int... Is>
 __device__ __forceinline__ void static_for_impl(F &&f, std::integer_sequence<int, Is...>) {
@@ -589,10 +567,10 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(MT == 2 ? 4 
 // ---------------------------------------------------------------------------------------------------------
 struct RingPlan { bool ok; int co_t, t_t, res_ch, G; bool xf32; };
 
-static int ring_enabled() {
-    static const int v = [] { const char *e = getenv("ECG_BF16_RING"); return e && *e ? atoi(e) : 1; }();
-    return v;
-}
+#ifndef ECG_BF16_RING
+#define ECG_BF16_RING 1      // compile-time A/B knob (make VARIANT=noring EXTRA="-DECG_BF16_RING=0"): no environment is read
+#endif
+static constexpr int ring_enabled() { return ECG_BF16_RING; }
 
 // Which shapes the ring kernel takes: bf16 in and out (x_bf16 / y_bf16 of the callers), K = 15, odd pad, even ldx,
 // ldy % 4 == 0, and rows long enough that 640-step tiles waste no more than the 256-step tiles of the old kernel.

@@ -28,7 +28,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));   // native vector: sta
 
 constexpr int kKM = 15;   // largest kernel size the MFMA path stages (the reference uses 15)
 
-// In-kernel stamps (diagnostic build only: make STAMP=1 -> lib/libecg_hip_stamp.so; the product library has none).
+// In-kernel stamps (diagnostic build only: make STAMP=1 -> tools/_build/libecg_hip_stamp.so; the product library has none).
 // Wave 0 of every workgroup writes s_memtime at a few points into a buffer no other code reads.
 #ifdef ECG_STAMP
 __device__ unsigned long long *g_stamps = nullptr;
@@ -102,6 +102,9 @@ __device__ __forceinline__ int acc_row(int r, int half) { return (r & 3) + 8 * (
 // the inference path writes only the pooled activation (one launch per ConvBlock); EPI_EVAL_GAP also folds
 // the global average pool behind it (last block, whole row inside one t tile): only g [N][C_out] is written.
 enum { EPI_PLAIN = 0, EPI_STATS = 1, EPI_EVAL = 2, EPI_EVAL_GAP = 3 };
+#ifndef ECG_FWD_FL
+#define ECG_FWD_FL 1         // two-level accumulation (below); tools build -DECG_FWD_FL=0 to A/B its cost and effect
+#endif
 
 // XCD-aware block order.  Workgroups are dealt round-robin over the 8 XCDs (b and b+8 share an L2),
 // so neighbouring block ids — which here would be the tiles that read the SAME input panel — land on
@@ -153,13 +156,21 @@ __global__ __launch_bounds__(256, 2) void conv1d_mfma_fwd_kernel(
     const int wco = (wave / WT) * (CO_T / WCO), wt = (wave % WT) * (T_T / WT);
     const float *xn = x + (size_t)n * Cin * ldx;     // ldx >= L: row stride of the input tensor
 
-    f32x16 acc[MC][MT];
+    // TWO-LEVEL ACCUMULATION (ECG_FWD_FL): v_mfma_f32_32x32x2_f32 is one k-ordered fp32 fma chain, C_in * 15 terms long
+    // (up to 3 840 in the block-3 input gradient): its rounding error grew with the square root of that — 2.8x (forward)
+    // and 3.9x (input gradient) what oneDNN's blocked sums leave on the block-3 shapes (tools/wgrad_error.py), and with
+    // it the number of ReLU / pooling decisions that differ from an exact forward pass.  The first MFMA of every chunk
+    // therefore starts from the inline constant 0 and the chunk's 60-term sum joins a second register set at the end of
+    // the chunk: chains of 60 + C_in / 4 terms, same fixed order for every launch.
+    constexpr bool FL = (ECG_FWD_FL != 0);
+    f32x16 acc[MC][MT], acc2[MC][MT];
+    f32x16 zero16;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) zero16[r] = 0.f;
 #pragma unroll
     for (int a = 0; a < MC; ++a)
 #pragma unroll
-        for (int b = 0; b < MT; ++b)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+        for (int b = 0; b < MT; ++b) { acc[a][b] = zero16; acc2[a][b] = zero16; }
 
     // ---- per-channel epilogue parameters, lane-indexed: lane (r + 32*half), r < 16, holds those of accumulator
     // row (r, half) of each 32-channel group.  They are loaded HERE, before the main loop: vmcnt is in-order, so
@@ -265,16 +276,29 @@ __global__ __launch_bounds__(256, 2) void conv1d_mfma_fwd_kernel(
 #pragma unroll
             for (int i = 0; i < MC; ++i)
 #pragma unroll
-                for (int j = 0; j < MT; ++j) acc[i][j] = mfma32(a_c[i], b_c[j], acc[i][j]);
+                for (int j = 0; j < MT; ++j)
+                    acc[i][j] = mfma32(a_c[i], b_c[j], (FL && st == 0) ? zero16 : acc[i][j]);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int i = 0; i < MC; ++i) a_c[i] = a_n[i];
 #pragma unroll
             for (int i = 0; i < MT; ++i) b_c[i] = b_n[i];
         }
+        if (FL) {
+#pragma unroll
+            for (int i = 0; i < MC; ++i)
+#pragma unroll
+                for (int j = 0; j < MT; ++j) acc2[i][j] += acc[i][j];
+        }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();      // image c&1 free again; image (c+1)&1 complete (vmcnt(0) + barrier)
         if (c == 0) ECG_STAMP_AT(2);
+    }
+    if (FL) {
+#pragma unroll
+        for (int i = 0; i < MC; ++i)
+#pragma unroll
+            for (int j = 0; j < MT; ++j) acc[i][j] = acc2[i][j];
     }
     ECG_STAMP_AT(3);
     float *red = lds;         // all images are dead: reuse image 0 for the statistics scratch
@@ -465,7 +489,8 @@ bool mfma_fwd_eval_gap_supported(int Cin, int Cout, int L, int K, int pad) {
 // (i+1)&1 (first half of the steps) and the loads of stage i+2 are issued (second half), one
 // staging operation per MFMA group; ONE barrier closes the stage.  Per-thread global offsets are
 // loop-invariant; a stage only moves uniform base pointers.
-template <int M_T, int R_T, int WM, int WR, int WK, int T_T, int KK>
+// FL: two-level accumulation (see conv1d_mfma_wgrad_dma_kernel below).
+template <int M_T, int R_T, int WM, int WR, int WK, int T_T, int KK, int FL = 1>
 __global__ __launch_bounds__(256, 2) void conv1d_mfma_wgrad_kernel(
     const float *__restrict__ dy, const float *__restrict__ x, float *__restrict__ slab, int N,
     int Cin, int Cout, int L, int Lo, int ldy, int pad, int S) {
@@ -482,7 +507,7 @@ __global__ __launch_bounds__(256, 2) void conv1d_mfma_wgrad_kernel(
     constexpr int NOPS = DLOADS + XLOADS;               // staging operations per stage (per thread)
     constexpr int IMG = M_T * DS + XEL;
     constexpr int ACCF = MC * MR * 16 * 64;             // floats of one wave's accumulators
-    constexpr int LDSF = (WK > 1 && ACCF > 2 * IMG) ? ACCF : 2 * IMG;
+    constexpr int LDSF = (WK > 1 && WM * WR * ACCF > 2 * IMG) ? WM * WR * ACCF : 2 * IMG;
     static_assert(XS >= XSPAN, "x row stride too small");
     static_assert(DEL % 256 == 0, "dY tile must be a whole number of 256-thread passes");
     static_assert(256 % T_T == 0 || T_T % 256 == 0, "dY tile rows per pass");
@@ -513,16 +538,17 @@ __global__ __launch_bounds__(256, 2) void conv1d_mfma_wgrad_kernel(
         xcol[j] = (ci - ci_base) * XS + (r - ci * KK);
     }
 
-    f32x16 acc[MC][MR];
+    f32x16 acc[MC][MR], acc2[MC][MR];      // acc2: the second level (FL), dead otherwise
+    f32x16 zero16;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) zero16[r] = 0.f;
 #pragma unroll
     for (int a = 0; a < MC; ++a)
 #pragma unroll
-        for (int b = 0; b < MR; ++b)
+        for (int b = 0; b < MR; ++b) { acc[a][b] = zero16; acc2[a][b] = zero16; }
+    float bsum[MC], bsum2[MC];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
-    float bsum[MC];
-#pragma unroll
-    for (int a = 0; a < MC; ++a) bsum[a] = 0.f;
+    for (int a = 0; a < MC; ++a) bsum[a] = bsum2[a] = 0.f;
     const bool want_bias = (tile_r == 0) && (wr == 0);
 
     // ---- staging: loop-invariant per-thread pieces ------------------------------------------
@@ -635,23 +661,41 @@ __global__ __launch_bounds__(256, 2) void conv1d_mfma_wgrad_kernel(
             }
             __builtin_amdgcn_sched_barrier(0);         // keep reads + staging ABOVE these MFMAs
 #pragma unroll
-            for (int i = 0; i < MC; ++i) bsum[i] += a_c[i];     // bias-grad rides on the A fragments
+            for (int i = 0; i < MC; ++i) bsum[i] = (FL && st == 0) ? a_c[i] : bsum[i] + a_c[i];   // bias-grad rides on the A fragments
 #pragma unroll
             for (int i = 0; i < MC; ++i)
 #pragma unroll
-                for (int j = 0; j < MR; ++j) acc[i][j] = mfma32(a_c[i], b_c[j], acc[i][j]);
+                for (int j = 0; j < MR; ++j)
+                    acc[i][j] = mfma32(a_c[i], b_c[j], (FL && st == 0) ? zero16 : acc[i][j]);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int i = 0; i < MC; ++i) a_c[i] = a_n[i];
 #pragma unroll
             for (int j = 0; j < MR; ++j) b_c[j] = b_n[j];
         }
+        if (FL) {               // second level: the stage's sums join the running totals
+#pragma unroll
+            for (int i = 0; i < MC; ++i)
+#pragma unroll
+                for (int j = 0; j < MR; ++j) acc2[i][j] += acc[i][j];
+#pragma unroll
+            for (int i = 0; i < MC; ++i) bsum2[i] += bsum[i];
+        }
         __syncthreads();      // image it&1 free again; image (it+1)&1 complete
     }
 
+    if (FL) {
+#pragma unroll
+        for (int i = 0; i < MC; ++i) {
+            bsum[i] = bsum2[i];
+#pragma unroll
+            for (int j = 0; j < MR; ++j) acc[i][j] = acc2[i][j];
+        }
+    }
     // ---- combine the WK t-split waves through LDS (fixed order), then write the slab ---------
     if (WK > 1) {
         float *bred = lds + LDSF;      // [4][32] bias partials
+        float *ex = lds + (wr + WR * wm) * ACCF;      // one exchange area per group of WK waves that share an output tile
         for (int w = 1; w < WK; ++w) {
             __syncthreads();
             if (wk == w) {
@@ -661,7 +705,7 @@ __global__ __launch_bounds__(256, 2) void conv1d_mfma_wgrad_kernel(
                     for (int j = 0; j < MR; ++j)
 #pragma unroll
                         for (int r = 0; r < 16; ++r)
-                            lds[((i * MR + j) * 16 + r) * 64 + lane] = acc[i][j][r];
+                            ex[((i * MR + j) * 16 + r) * 64 + lane] = acc[i][j][r];
             }
             __syncthreads();
             if (wk == 0) {
@@ -671,16 +715,18 @@ __global__ __launch_bounds__(256, 2) void conv1d_mfma_wgrad_kernel(
                     for (int j = 0; j < MR; ++j)
 #pragma unroll
                         for (int r = 0; r < 16; ++r)
-                            acc[i][j][r] += lds[((i * MR + j) * 16 + r) * 64 + lane];
+                            acc[i][j][r] += ex[((i * MR + j) * 16 + r) * 64 + lane];
             }
         }
-        if (want_bias) {
-            // WK > 1 is only instantiated with WM == WR == 1, MC == 1: 32 channels, 4 waves
-            float b = bsum[0] + __shfl_xor(bsum[0], 32, 64);
+        static_assert(WK == 1 || (WM == 1 && MC == 1), "the bias exchange below assumes one 32-channel row, wk fastest in the wave index");
+        {
+            // WK > 1 is only instantiated with WM == 1, MC == 1: 32 channels; waves 0 .. WK-1 are (wr = 0, wk = 0 .. WK-1).
+            // The barriers are unconditional: want_bias differs between the waves of a workgroup when WR > 1.
+            const float b = bsum[0] + __shfl_xor(bsum[0], 32, 64);
             __syncthreads();
-            if (half == 0) bred[wave * 32 + l31] = b;
+            if (want_bias && half == 0) bred[wave * 32 + l31] = b;
             __syncthreads();
-            if (wave == 0 && half == 0) {
+            if (want_bias && wave == 0 && half == 0) {
                 float t = bred[l31];
                 for (int w = 1; w < WK; ++w) t += bred[w * 32 + l31];
                 bsum[0] = t;
@@ -727,7 +773,15 @@ __global__ __launch_bounds__(256, 2) void conv1d_mfma_wgrad_kernel(
 //   read per lane feeds four MFMA steps.  The x tile (B operand) is register-staged as in the
 //   kernel above and read at +4h+j.
 // grid = (ceil(R/R_T), Cout/M_T, S); T_T = 64; slab layout as above.
-template <int M_T, int R_T, int WM, int WR, int WK, int KK>
+//
+// TWO-LEVEL ACCUMULATION (FL != 0).  v_mfma_f32_32x32x2_f32 is one k-ordered fp32 fma chain, so a workgroup that
+// multiplies `total` stages into one accumulator builds a chain of 64 * total terms (512 ... 1 900 at B = 256): its
+// rounding error grows with the square root of that length and at the headline batch exceeded what oneDNN's blocked
+// sums leave (tests/test_gpu_model.py: float64 trajectory).  With FL the first MFMA of every stage starts from the
+// inline constant 0 and the stage's 64-term sum is added to a second register set at the end of the stage: chains of
+// 64 + total terms, fixed order (bitwise reproducible), no extra memory traffic; cost = one v_pk_add_f32 per two
+// accumulator registers per stage (32 MFMAs of 64 cycles per register pair).
+template <int M_T, int R_T, int WM, int WR, int WK, int KK, int FL = 1>
 __global__ __launch_bounds__(256, 2) void conv1d_mfma_wgrad_dma_kernel(
     const float *__restrict__ dy, const float *__restrict__ x, float *__restrict__ slab, int N,
     int Cin, int Cout, int L, int Lo, int ldy, int pad, int S) {
@@ -780,16 +834,17 @@ __global__ __launch_bounds__(256, 2) void conv1d_mfma_wgrad_dma_kernel(
         xcol[j] = (ci - ci_base) * XS + (r - ci * KK);
     }
 
-    f32x16 acc[MC][MR];
+    f32x16 acc[MC][MR], acc2[MC][MR];      // acc2: the second level (FL), dead otherwise
+    f32x16 zero16;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) zero16[r] = 0.f;
 #pragma unroll
     for (int a = 0; a < MC; ++a)
 #pragma unroll
-        for (int b = 0; b < MR; ++b)
+        for (int b = 0; b < MR; ++b) { acc[a][b] = zero16; acc2[a][b] = zero16; }
+    float bsum[MC], bsum2[MC];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
-    float bsum[MC];
-#pragma unroll
-    for (int a = 0; a < MC; ++a) bsum[a] = 0.f;
+    for (int a = 0; a < MC; ++a) bsum[a] = bsum2[a] = 0.f;
     const bool want_bias = (tile_r == 0) && (wr == 0);
 
     // ---- staging: loop-invariant per-thread pieces ------------------------------------------
@@ -891,11 +946,12 @@ __global__ __launch_bounds__(256, 2) void conv1d_mfma_wgrad_dma_kernel(
             else if (st < 2 * XLOADS + DPW) dma_a(st - 2 * XLOADS, nxt);
             __builtin_amdgcn_sched_barrier(0);         // keep reads + staging ABOVE these MFMAs
 #pragma unroll
-            for (int i = 0; i < MC; ++i) bsum[i] += aq_c[i][j4];
+            for (int i = 0; i < MC; ++i) bsum[i] = (FL && st == 0) ? aq_c[i][j4] : bsum[i] + aq_c[i][j4];
 #pragma unroll
             for (int i = 0; i < MC; ++i)
 #pragma unroll
-                for (int j = 0; j < MR; ++j) acc[i][j] = mfma32(aq_c[i][j4], b_c[j], acc[i][j]);
+                for (int j = 0; j < MR; ++j)
+                    acc[i][j] = mfma32(aq_c[i][j4], b_c[j], (FL && st == 0) ? zero16 : acc[i][j]);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int j = 0; j < MR; ++j) b_c[j] = b_n[j];
@@ -903,6 +959,14 @@ __global__ __launch_bounds__(256, 2) void conv1d_mfma_wgrad_dma_kernel(
 #pragma unroll
                 for (int i = 0; i < MC; ++i) aq_c[i] = aq_n[i];
             }
+        }
+        if (FL) {               // second level: the stage's sums join the running totals, in issue order of the MFMAs
+#pragma unroll
+            for (int i = 0; i < MC; ++i)
+#pragma unroll
+                for (int j = 0; j < MR; ++j) acc2[i][j] += acc[i][j];
+#pragma unroll
+            for (int i = 0; i < MC; ++i) bsum2[i] += bsum[i];
         }
         dn = sn; dtt = stt;
         advance();
@@ -918,6 +982,14 @@ __global__ __launch_bounds__(256, 2) void conv1d_mfma_wgrad_dma_kernel(
             ((unsigned long long)(__builtin_amdgcn_s_getreg((31 << 11) | 20) & 0xF) << 48);
 #endif
 
+    if (FL) {
+#pragma unroll
+        for (int i = 0; i < MC; ++i) {
+            bsum[i] = bsum2[i];
+#pragma unroll
+            for (int j = 0; j < MR; ++j) acc[i][j] = acc2[i][j];
+        }
+    }
     if (want_bias) {
 #pragma unroll
         for (int i = 0; i < MC; ++i) bsum[i] += __shfl_xor(bsum[i], 32, 64);
@@ -980,22 +1052,31 @@ __global__ __launch_bounds__(256, 2) void conv1d_mfma_wgrad_dma_kernel(
 int wgrad_reduce(const float *ws, float *dw, float *db, size_t wslab, int Cout, int S,
                  hipStream_t st);
 
+#ifndef ECG_WG_FL
+#define ECG_WG_FL 1          // two-level accumulation; tools build -DECG_WG_FL=0 to A/B its cost and its effect on the error
+#endif
 struct WgCfg { int m_t, r_t, splits; };
 
-static int tune_int(const char *name, int def) {       // development knobs (tools/layer_bench.py A/B runs)
-    const char *v = getenv(name);
-    return v && *v ? atoi(v) : def;
-}
+// Development knobs are COMPILE-TIME (A/B libraries: make VARIANT=x EXTRA="-DECG_WG_SLOTS=768"): the product library reads no
+// environment variable.
+#ifndef ECG_WG_SLOTS
+#define ECG_WG_SLOTS 512
+#endif
+#ifndef ECG_WG_RT
+#define ECG_WG_RT 0
+#endif
 
 static WgCfg wgrad_cfg(int N, int Cin, int Cout, int Lo, bool dma) {
     const int R = Cin * kKM;
-    static const int slots = tune_int("ECG_WG_SLOTS", 512), rt128 = tune_int("ECG_WG_RT", 0);
+    constexpr int slots = ECG_WG_SLOTS, rt128 = ECG_WG_RT;
     WgCfg c;
     // 128 x 192 tiles where 128-wide column tiles would leave a ragged last tile and 192 divide the columns (block 2:
     // R = 960 = 5 x 192 instead of 7.5 x 128: 154.7 -> 150.3 us; block 3, R = 1920 = 15 x 128 = 10 x 192: 264.0 vs 267.5 us,
     // stays at 128).  More, smaller workgroups (ECG_WG_SLOTS 768 / 1024: a second round in the slots the early finishers
     // free) measured 2-8 % SLOWER on every layer — the second prologue / slab costs more than the tail it evens out.
-    const bool wide = dma && R % 192 == 0 && (rt128 == 192 || (rt128 == 0 && R % 128 != 0));
+    // (With the two-level accumulation the 128 x 192 tile needs 96 + 96 accumulator registers and spills: it is only
+    // instantiated in the single-level A/B build; block 2 then takes 128 x 128 tiles, +3 us.)
+    const bool wide = dma && !ECG_WG_FL && R % 192 == 0 && (rt128 == 192 || (rt128 == 0 && R % 128 != 0));
     if (Cout % 128 == 0) c = {128, wide ? 192 : 128, 0};
     else if (Cout % 64 == 0) c = {64, 128, 0};
     else c = {32, 192, 0};
@@ -1039,13 +1120,16 @@ int mfma_wgrad(const float *dy, int ldy, const float *x, float *dw, float *db, f
     dim3 grid((unsigned)(cdiv(R, c.r_t) * (Cout / c.m_t) * c.splits)), block(256);
 #define ECG_WG(KERNEL) \
     hipLaunchKernelGGL(KERNEL, grid, block, 0, st, dy, x, ws, N, Cin, Cout, L, Lo, ldy, pad, c.splits)
-    if (dma && c.m_t == 128 && c.r_t == 192) ECG_WG((conv1d_mfma_wgrad_dma_kernel<128, 192, 2, 2, 1, kKM>));
-    else if (dma && c.m_t == 128) ECG_WG((conv1d_mfma_wgrad_dma_kernel<128, 128, 2, 2, 1, kKM>));
-    else if (dma && c.m_t == 64) ECG_WG((conv1d_mfma_wgrad_dma_kernel<64, 128, 2, 2, 1, kKM>));
-    else if (dma) ECG_WG((conv1d_mfma_wgrad_dma_kernel<32, 192, 1, 2, 2, kKM>));
-    else if (c.m_t == 128) ECG_WG((conv1d_mfma_wgrad_kernel<128, 128, 2, 2, 1, 64, kKM>));
-    else if (c.m_t == 64) ECG_WG((conv1d_mfma_wgrad_kernel<64, 128, 2, 2, 1, 64, kKM>));
-    else ECG_WG((conv1d_mfma_wgrad_kernel<32, 192, 1, 1, 4, 128, kKM>));
+#if !ECG_WG_FL
+    if (dma && c.m_t == 128 && c.r_t == 192) ECG_WG((conv1d_mfma_wgrad_dma_kernel<128, 192, 2, 2, 1, kKM, 0>));
+    else
+#endif
+    if (dma && c.m_t == 128) ECG_WG((conv1d_mfma_wgrad_dma_kernel<128, 128, 2, 2, 1, kKM, ECG_WG_FL>));
+    else if (dma && c.m_t == 64) ECG_WG((conv1d_mfma_wgrad_dma_kernel<64, 128, 2, 2, 1, kKM, ECG_WG_FL>));
+    else if (dma) ECG_WG((conv1d_mfma_wgrad_dma_kernel<32, 192, 1, 2, 2, kKM, ECG_WG_FL>));
+    else if (c.m_t == 128) ECG_WG((conv1d_mfma_wgrad_kernel<128, 128, 2, 2, 1, 64, kKM, ECG_WG_FL>));
+    else if (c.m_t == 64) ECG_WG((conv1d_mfma_wgrad_kernel<64, 128, 2, 2, 1, 64, kKM, ECG_WG_FL>));
+    else ECG_WG((conv1d_mfma_wgrad_kernel<32, 192, 1, 2, 2, 128, kKM, ECG_WG_FL>));
 #undef ECG_WG
     int rc = check_launch("conv1d_mfma_wgrad_kernel");
     if (rc) return rc;

@@ -503,10 +503,10 @@ int wgrad_reduce(const float *ws, float *dw, float *db, size_t wslab, int Cout, 
 
 struct WgBf16Plan { int G, PA, PX, ntt, splits, ring_mt; size_t dyb_elems, xb_elems, slab_floats; };
 
-static int wgb_ring_enabled() {
-    static const int v = [] { const char *e = getenv("ECG_WGB_RING"); return e && *e ? atoi(e) : 1; }();
-    return v;
-}
+#ifndef ECG_WGB_RING
+#define ECG_WGB_RING 1       // compile-time A/B knob (make VARIANT=x EXTRA="-DECG_WGB_RING=0"): no environment is read
+#endif
+static constexpr int wgb_ring_enabled() { return ECG_WGB_RING; }
 
 static WgBf16Plan wgrad_bf16_plan(int N, int Cin, int Cout, int Lo) {
     WgBf16Plan p;

@@ -25,8 +25,9 @@ SIGNATURES = {
     "ecg_check_device": (_i, []),
     "ecg_conv1d_pack_weights": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),
     "ecg_pack_weights_grouped": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
-    "ecg_bn_relu_pool_bwd_launches": (_i, [_i, _i, _i, _i]),
-    "ecg_bn_bwd_one_launch_enable": (_i, [_i]),
+    "ecg_bn_relu_pool_bwd_one_launch_splits": (_i, [_i, _i, _i, _i]),
+    "ecg_bn_relu_pool_bwd_one_launch_counter_uints": (_sz, [_i, _i, _i, _i]),
+    "ecg_bn_relu_pool_bwd_one_launch": (_i, [_vp] * 7 + [_i] + [_vp] * 3 + [_i] * 6 + [_vp]),
     "ecg_pack_weights_grouped_mixed": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
     "ecg_conv1d_fwd_stat_partials": (_i, [_i, _i, _i, _i, _i, _i]),
     "ecg_conv1d_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
@@ -216,20 +217,6 @@ def ptr_table(tensors, any_dtype=False):
 
 def int_table(values):
     return (ctypes.c_int * len(values))(*[int(v) for v in values])
-
-
-_overlap_users = set()
-
-
-def collectives_during_backward(owner, active):
-    """Bookkeeping for the one-launch BatchNorm backward (csrc/bn_relu_pool.hip, bn_bwd_resident_kernel): while ANY owner
-    (an optimizer or DDP wrapper whose gradient hooks issue all-reduces under backward) is active, the kernel's
-    inter-workgroup wait could be stretched by a communication kernel that waits for a late peer — the two-pass form is
-    used instead.  Cheap to call repeatedly."""
-    before = bool(_overlap_users)
-    (_overlap_users.add if active else _overlap_users.discard)(id(owner))
-    if bool(_overlap_users) != before:
-        getattr(load(), "ecg_bn_bwd_one_launch_enable")(0 if _overlap_users else 1)
 
 
 @functools.lru_cache(maxsize=4096)

@@ -103,6 +103,11 @@ class FlatGradDDP(nn.Module):
             broadcast_module_state(module, 0, process_group)
             for p in self._params:
                 p.register_post_accumulate_grad_hook(self._on_grad)
+            # the one all-reduce is issued from the hook of the LAST gradient, i.e. behind every backward kernel on the
+            # stream: nothing communicates while the BatchNorm backward kernels run ("quiet", functional.py)
+            if self._params and self._params[0].is_cuda:
+                from . import functional as F
+                F.declare_backward_collectives(self._params, False)
 
     def _on_grad(self, _param):
         self._pending += 1

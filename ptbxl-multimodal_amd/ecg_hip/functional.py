@@ -67,6 +67,80 @@ def _grad_out(key, ref, *shape):
     return torch.empty(shape, dtype=torch.float32, device=ref.device)
 
 
+# --------------------------------------------------------------------------------------
+# The one-launch BatchNorm backward (csrc/bn_relu_pool.hip, bn_bwd_resident_kernel) and collectives.
+# Its workgroups exchange partial sums through a bounded wait, which is only instant while every workgroup of the grid
+# is resident.  A communication kernel that runs DURING backward and waits for a late peer keeps its CUs; this kernel's
+# workgroups would then run out their wait and take the slow self-service path on every call.  The decision is taken
+# PER CALL, from what is known about the parameters of the block whose backward is running — no process-wide switch:
+#   * the owner of the parameters (FlatAdamW, FlatGradDDP) declares "busy" (its hooks issue all-reduces under backward)
+#     or "quiet" (its exchange starts after the last backward kernel);
+#   * parameters nobody has declared are quiet in a single-rank process and BUSY as soon as torch.distributed runs more
+#     than one rank — so a model wrapped in stock torch.nn.parallel.DistributedDataParallel (bucketed all-reduces under
+#     backward, invisible from here) gets the two-pass form without having to ask for it.
+# ECG_BN_BWD_RESIDENT=0 keeps the two-pass form everywhere; ECG_HIP_REHEARSE_ON_ONE_GPU=1 (several ranks sharing ONE
+# device: workgroups of different processes would wait for each other's CUs) does the same.  Read here, on the host side
+# of the ABI: the library reads no environment.
+# --------------------------------------------------------------------------------------
+import os as _os
+
+_bn_one_launch = (_os.environ.get("ECG_BN_BWD_RESIDENT", "1") != "0"
+                  and _os.environ.get("ECG_HIP_REHEARSE_ON_ONE_GPU") != "1")
+_bn_spin_polls = int(_os.environ.get("ECG_BN_BWD_RESIDENT_SPIN", "-1"))     # tests: 0 = nobody waits (self-service path)
+_backward_collectives = {}      # parameter data_ptr -> True (busy) / False (quiet)
+_bn_counters = {}               # (device index, raw stream) -> zeroed int32 tensor: the kernel's exchange words
+
+
+def set_bn_backward_one_launch(on, spin_polls=None):
+    """Process default for the one-launch BatchNorm backward (True unless the environment says otherwise); returns the
+    previous setting.  `spin_polls` (tests) bounds the inter-workgroup wait: 0 forces the self-service path."""
+    global _bn_one_launch, _bn_spin_polls
+    prev, _bn_one_launch = _bn_one_launch, bool(on)
+    if spin_polls is not None:
+        _bn_spin_polls = int(spin_polls)
+    return prev
+
+
+def declare_backward_collectives(params, busy):
+    """The owner of `params` says whether collectives can run on the device while their backward kernels do (True: the
+    BatchNorm backward of their blocks keeps the two-pass form), that they cannot (False), or withdraws its statement
+    (None).  Cheap; call it whenever the exchange mode changes."""
+    for p in params:
+        k = p if isinstance(p, int) else p.data_ptr()
+        if busy is None:
+            _backward_collectives.pop(k, None)
+        else:
+            _backward_collectives[k] = bool(busy)
+
+
+def _multi_rank():
+    d = torch.distributed
+    return d.is_available() and d.is_initialized() and d.get_world_size() > 1
+
+
+def bn_backward_one_launch_allowed(key):
+    """The per-call decision described above for the block whose conv weight has data_ptr `key`."""
+    if not _bn_one_launch:
+        return False
+    busy = _backward_collectives.get(key)
+    return (not _multi_rank()) if busy is None else (not busy)
+
+
+def _bn_bwd_counters(ref, n_uints):
+    """Caller-owned exchange words of the one-launch BatchNorm backward: zero before the first launch, left zero by every
+    launch.  One buffer per (device, stream) — launches on one stream are ordered, launches on different streams get
+    different buffers.  Inside a stream capture a FRESH zeroed buffer is allocated (a memset node + memory of the
+    graph's private pool): a captured step never shares its words with eager launches or with another graph."""
+    if torch.cuda.is_current_stream_capturing():
+        return torch.zeros(n_uints, dtype=torch.int32, device=ref.device)
+    key = (ref.device.index, _st())
+    t = _bn_counters.get(key)
+    if t is None or t.numel() < n_uints:
+        t = torch.zeros(max(n_uints, 4352), dtype=torch.int32, device=ref.device)
+        _bn_counters[key] = t
+    return t
+
+
 def _numel(shape):
     n = 1
     for d in shape:
@@ -547,9 +621,17 @@ class ConvBlockFn(torch.autograd.Function):
         ldy = Lo if (ctx.bf16 and need_dx) else _query("ecg_conv1d_dy_row_stride", N, Ci, Co, Lin, K, ctx.pad,
                                                        int(bool(need_dx)))
         dy = _empty(y, N, Co, ldy)
-        _call("ecg_bn_relu_pool_gap_bwd_ld" if ctx.gap else "ecg_bn_relu_pool_bwd_ld", _f32(y), _f32(dp),
-              _f32(gamma), _f32(beta), _f32(mean), _f32(invstd), _f32(dy), ldy, _f32(dgamma),
-              _f32(dbeta), _f32(ws), N, Co, Lo, 1 if ctx.batch_stats else 0, _st())
+        if bn_backward_one_launch_allowed(kw) and _query("ecg_bn_relu_pool_bwd_one_launch_splits", N, Co, Lo, ldy):
+            # operands resident in registers: one launch, one read of (dp, y); the exchange words are ours
+            n_u = _query("ecg_bn_relu_pool_bwd_one_launch_counter_uints", N, Co, Lo, ldy)
+            cnt = _bn_bwd_counters(y, n_u) if n_u else None
+            _call("ecg_bn_relu_pool_bwd_one_launch", _f32(y), _f32(dp), _f32(gamma), _f32(beta), _f32(mean),
+                  _f32(invstd), _f32(dy), ldy, _f32(dgamma), _f32(dbeta), L.ptr(cnt), N, Co, Lo,
+                  1 if ctx.batch_stats else 0, 1 if ctx.gap else 0, _bn_spin_polls, _st())
+        else:
+            _call("ecg_bn_relu_pool_gap_bwd_ld" if ctx.gap else "ecg_bn_relu_pool_bwd_ld", _f32(y), _f32(dp),
+                  _f32(gamma), _f32(beta), _f32(mean), _f32(invstd), _f32(dy), ldy, _f32(dgamma),
+                  _f32(dbeta), _f32(ws), N, Co, Lo, 1 if ctx.batch_stats else 0, _st())
         dx, dw, db = conv1d_backward_raw(x, dy, w.shape, ctx.w_bwd, ctx.pad, need_dx,
                                          overlap=True, bf16=ctx.bf16, ldy=ldy, sink_keys=(kw, kb))
         return (dx, dw, db, dgamma, dbeta) + nones

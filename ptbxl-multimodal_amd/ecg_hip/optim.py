@@ -101,7 +101,7 @@ class FlatAdamW(torch.optim.Optimizer):
             # Python to come back from backward() and reach step()
             for p in self._params[:self._n_early]:
                 p.register_post_accumulate_grad_hook(self._on_early_grad)
-            self._note_overlap()
+        self._note_overlap()
 
     def __del__(self):
         try:
@@ -110,9 +110,9 @@ class FlatAdamW(torch.optim.Optimizer):
         except Exception:
             pass
         try:
-            if getattr(self, "_overlap_active", False) and self.flat_param.is_cuda:
-                from . import _lib
-                _lib.collectives_during_backward(self, False)
+            if self.flat_param.is_cuda:
+                from . import functional as F
+                F.declare_backward_collectives(self._sink_keys, None)
         except Exception:
             pass
 
@@ -155,11 +155,13 @@ class FlatAdamW(torch.optim.Optimizer):
         return self._overlap_active
 
     def _note_overlap(self):
-        # all-reduces issued under backward share the device with the backward kernels: tell the library (it then keeps the
-        # BatchNorm backward in its two-pass form, whose progress never depends on a communication kernel leaving a CU)
-        if self.flat_param.is_cuda:
-            from . import _lib
-            _lib.collectives_during_backward(self, self._overlap_active)
+        # Tell the backward kernels, per parameter, whether collectives can run beside them: the hooked exchange issues
+        # all-reduces UNDER backward ("busy": the BatchNorm backward of these blocks keeps its two-pass form, whose progress
+        # never depends on a communication kernel leaving a CU); the single all-reduce in step() starts after the last
+        # backward kernel ("quiet": the one-launch form).  Without an exchange nothing is declared.
+        if self.flat_param.is_cuda and self._exchange:
+            from . import functional as F
+            F.declare_backward_collectives(self._params, bool(self._overlap_active))
 
     def calibrate_overlap(self, run_steps, steps=10, warm=3):
         """Pick the faster exchange form ON THIS NODE: `run_steps(n)` must run n complete train steps (forward,

@@ -74,20 +74,40 @@ def test_missing_library_fails_loudly(monkeypatch, tmp_path):
         _lib.load()
 
 
-def test_one_launch_batchnorm_backward_is_switched_off_while_hooks_issue_collectives(lib):
-    """ecg_bn_bwd_one_launch_enable is a process-wide switch returning the previous setting; the Python bookkeeping turns
-    it off while at least one owner (an optimizer whose gradient hooks issue all-reduces under backward) is active."""
+def test_one_launch_batchnorm_backward_is_decided_per_call_from_the_parameters(monkeypatch):
+    """No process-wide switch in the library any more: ConvBlockFn.backward picks the one-launch or the two-pass entry
+    point per call.  Parameters declared "busy" (hooks issue all-reduces under backward) take two passes, "quiet" ones the
+    one-launch form; undeclared parameters are quiet in a single-rank process and busy as soon as more than one rank
+    exists (stock DistributedDataParallel users get the safe form without asking)."""
+    import torch
+    from ecg_hip import functional as F
+    monkeypatch.setattr(F, "_bn_one_launch", True)
+    monkeypatch.setattr(F, "_backward_collectives", {})
+    a, b = torch.nn.Parameter(torch.zeros(3)), torch.nn.Parameter(torch.zeros(3))
+    ka, kb = a.data_ptr(), b.data_ptr()
+    assert F.bn_backward_one_launch_allowed(ka) and F.bn_backward_one_launch_allowed(kb)
+    F.declare_backward_collectives([a], True)
+    assert not F.bn_backward_one_launch_allowed(ka) and F.bn_backward_one_launch_allowed(kb)      # per parameter, not global
+    F.declare_backward_collectives([a], False)
+    assert F.bn_backward_one_launch_allowed(ka)
+    monkeypatch.setattr(F, "_multi_rank", lambda: True)
+    assert F.bn_backward_one_launch_allowed(ka) and not F.bn_backward_one_launch_allowed(kb)      # undeclared + multi-rank
+    F.declare_backward_collectives([a], None)
+    assert not F.bn_backward_one_launch_allowed(ka)
+    monkeypatch.setattr(F, "_multi_rank", lambda: False)
+    assert F.set_bn_backward_one_launch(False) is True
+    assert not F.bn_backward_one_launch_allowed(ka) and not F.bn_backward_one_launch_allowed(kb)
+    assert F.set_bn_backward_one_launch(True) is False
+
+
+def test_library_reads_no_environment_and_allocates_nothing():
+    """include/ecg_hip.h: "never allocates", "no global mutable state", "reads no environment variable" — checked on the
+    dynamic symbol table of the built library (what it would have to import to break the promise)."""
+    import subprocess
     from ecg_hip import _lib as L
-    f = lib.ecg_bn_bwd_one_launch_enable
-    assert f(1) in (0, 1)
-    assert f(0) == 1 and f(0) == 0 and f(1) == 0 and f(1) == 1
-    a, b = object(), object()
-    L.collectives_during_backward(a, True)
-    assert f(0) == 0                      # already off
-    L.collectives_during_backward(b, True)
-    L.collectives_during_backward(a, False)
-    assert f(0) == 0                      # b still active
-    L.collectives_during_backward(b, False)
-    assert f(1) == 1                      # back on once nobody overlaps
-    L.collectives_during_backward(b, False)            # idempotent
-    assert f(1) == 1
+    if not os.path.exists(L.LIB_PATH):
+        pytest.skip("library not built")
+    syms = subprocess.run(["nm", "-D", "--undefined-only", L.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    for banned in ("getenv", "secure_getenv", "hipMalloc", "hipFree", "hipMemset", "hipMallocAsync", "hipHostMalloc",
+                   "pthread_mutex_lock"):
+        assert not any(line.split()[-1].split("@")[0] == banned for line in syms.splitlines() if line.strip()), banned

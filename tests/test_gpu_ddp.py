@@ -151,3 +151,9 @@ def test_one_rank_rccl_exchange():
     for k in ("flat_adamw_single_allreduce", "flat_grad_ddp_stock_adamw", "no_sync_accumulation"):
         assert d[k]["bit_identical_to_unexchanged_step"], k
     assert d["allreduce_two_buckets_ms"]["floats"] == 719397
+    # the one-launch BatchNorm backward is chosen per call from what the parameters' owner declared: OFF while hooks issue
+    # all-reduces under backward, ON for the single all-reduce / FlatGradDDP (their exchange starts after the last backward
+    # kernel) and for undeclared parameters of a single-rank process; set_overlap() moves an optimizer between the two
+    assert d["bn_backward_one_launch"] == {"undeclared_single_rank": True, "hooked_exchange": False,
+                                           "single_allreduce": True, "hooked_then_set_overlap_false": True,
+                                           "flat_grad_ddp": True}

@@ -243,14 +243,12 @@ def test_trajectory_error_vs_float64_no_worse_than_the_cpu_fp32_path(name, optim
         l32.append(R.train_step(ref32, o32, batch)[1])
         l64.append(R.train_step(ref64, o64, batch64)[1])
     l_hip, l32, l64 = np.array(l_hip), np.array(l32), np.array(l64)
-    # The error of a sequential fp32 accumulation chain grows with the square root of its length.  The MFMA kernels
-    # accumulate each (n, t) reduction as ONE k-ordered fp32 fma chain per slab (exactly what v_mfma_f32_32x32x2_f32 is),
-    # B/32 times longer than at B=32, while oneDNN's blocked / vectorised CPU sums keep their chain length: the bars that
-    # compare the HIP path with the CPU fp32 run are scaled by sqrt(B/32) (1 at B=32, 2.83 at the headline batch).
-    # Measured at B=256 after three steps: mean drift of the first conv weight 0.069 lr vs 0.026 lr on the CPU, both
-    # ~30x inside the hard bound below.
-    chain = (B / 32.0) ** 0.5
-    floor = 2e-6 * chain
+    # Same bars at every batch size.  (Round 3 had scaled them by sqrt(B/32) for the headline batch: the weight-gradient
+    # kernels then accumulated one k-ordered fp32 fma chain of 64 x stages terms per slab, 500 ... 1 900 terms at B=256.
+    # The kernels now sum each 64-term stage from zero and add it to a second accumulator — conv1d_mfma.hip, "TWO-LEVEL
+    # ACCUMULATION" — and the unscaled bars hold; tools/wgrad_error.py prints the per-layer attribution.)
+    chain = 1.0
+    floor = 2e-6
     assert np.abs(l_hip - l64).max() <= max(3.0 * np.abs(l32 - l64).max(), floor), (l_hip - l64, l32 - l64)
     sd, sd32, sd64 = model.state_dict(), ref32.state_dict(), ref64.state_dict()
     tot_hip = tot_ref = n = 0.0
@@ -271,6 +269,21 @@ def test_trajectory_error_vs_float64_no_worse_than_the_cpu_fp32_path(name, optim
     assert tot_hip / n <= 1.5 * chain * tot_ref / n + 1e-7, (tot_hip / n, tot_ref / n)
 
 
+def _assert_grads_match_a_cpu_run(grads, ref32, ref64, tol_of, what=""):
+    """Parameter gradients against the reference model run on the CPU.  An fp32 run of the SAME network can take a ReLU /
+    max-pool decision differently from the exact (float64) forward pass when two candidates are within rounding of each
+    other; one such flip moves a dY element by one position and changes a channel's gradients by ~1/sqrt(terms) — 1e-4 ...
+    1e-2 at small batches, far above any rounding of the sums (tools/wgrad_error.py counts them: at B=7, T=999 the CPU fp32
+    run flips one pooling winner in block 2, the HIP path takes the float64 run's decisions).  Both CPU runs are legitimate
+    outcomes of the reference, so every tensor must match AT LEAST ONE of them within the tolerance — a HIP-only flip
+    still fails."""
+    for k, p32 in ref32.named_parameters():
+        g, g32, g64 = grads[k], p32.grad.numpy(), dict(ref64.named_parameters())[k].grad.numpy()
+        tol = tol_of(k, g32)
+        e32, e64 = np.abs(g - g32).max(), np.abs(g - g64.astype(np.float32)).max()
+        assert min(e32, e64) <= tol, f"{k} {what}: |hip - cpu fp32| = {e32:.3e}, |hip - cpu float64| = {e64:.3e}, tol {tol:.1e}"
+
+
 @pytest.mark.parametrize("B,T", [(1, 1000), (3, 16), (5, 17), (2, 5000), (7, 999)])
 def test_ragged_batches_and_lengths_vs_cpu_oracle(B, T):
     """Last batch is ragged (drop_last unset), Grad-CAM uses B=1, any T >= 16 must work
@@ -282,21 +295,23 @@ def test_ragged_batches_and_lengths_vs_cpu_oracle(B, T):
     model = ctor().to(DEV)
     R.seed_all(1)
     ref = rctor()
+    ref64 = copy.deepcopy(ref).double()
     x, xd, y = R.synthetic_batch(B, T, C, gen_seed=B * 100 + T, demo=True)
     for train in ([True, False] if B > 1 else [False]):
-        model.train(train), ref.train(train)
-        model.zero_grad(), ref.zero_grad()
+        model.train(train), ref.train(train), ref64.train(train)
+        model.zero_grad(), ref.zero_grad(), ref64.zero_grad()
         logits = model(x.to(DEV), xd.to(DEV))
         rlogits = ref(x, xd)
         np.testing.assert_allclose(logits.detach().cpu().numpy(), rlogits.detach().numpy(), atol=1e-4)
         hipF.binary_cross_entropy_with_logits(logits, y.to(DEV)).backward()
         torch.nn.functional.binary_cross_entropy_with_logits(rlogits, y).backward()
-        for (k, a), (_, b) in zip(model.named_parameters(), ref.named_parameters()):
-            ref_g = b.grad.numpy()
-            # absolute 1e-4 at unit scale; eval-mode BN with fresh running stats leaves activations
-            # (hence gradients) un-normalised, so scale the bound with the gradient magnitude
-            tol = 1e-6 if ".net.0.bias" in k and train else 1e-4 * max(1.0, float(np.abs(ref_g).max()))
-            np.testing.assert_allclose(a.grad.cpu().numpy(), ref_g, atol=tol, err_msg=f"{k} train={train}")
+        torch.nn.functional.binary_cross_entropy_with_logits(ref64(x.double(), xd.double()), y.double()).backward()
+        # absolute 1e-4 at unit scale; eval-mode BN with fresh running stats leaves activations
+        # (hence gradients) un-normalised, so scale the bound with the gradient magnitude
+        _assert_grads_match_a_cpu_run(
+            {k: p.grad.cpu().numpy() for k, p in model.named_parameters()}, ref, ref64,
+            lambda k, g: 1e-6 if ".net.0.bias" in k and train else 1e-4 * max(1.0, float(np.abs(g).max())),
+            what=f"train={train}")
 
 
 def test_eval_loop_api_and_device_side_loss():
@@ -394,7 +409,9 @@ def test_gradients_land_in_the_flat_buffer_and_still_accumulate():
     before = opt.flat_param.clone()
     opt.step()
     assert not torch.equal(before, opt.flat_param)
-    # dropping the optimizer unregisters its sinks: gradients become ordinary tensors again
+    # dropping the optimizer unregisters its sinks: gradients become ordinary tensors again.  (The flat buffer itself is
+    # kept alive here: once freed, the caching allocator may hand its address range to one of the new gradients.)
+    keep_flat = opt.flat_grad
     del opt
     import gc
     gc.collect()
@@ -402,6 +419,7 @@ def test_gradients_land_in_the_flat_buffer_and_still_accumulate():
         p.grad = None
     bce_loss_fn(m(x, xd), y).backward()
     assert all(not (lo <= p.grad.data_ptr() < hi) for p in m.parameters())
+    del keep_flat
 
 
 def test_hooked_block_trains_like_the_fused_path_with_flat_optimizer():

@@ -289,16 +289,17 @@ def test_bn_relu_pool_bwd_writes_row_padded_dy(hip, oracle, shape, gap):
                                   (201, 128, 250, False), (256, 32, 1000, False),
                                   (180, 100, 301, False), (97, 200, 222, True), (64, 256, 500, False)])
 def test_bn_backward_in_one_launch_with_resident_operands_vs_oracle(hip, oracle, case):
-    """ecg_bn_relu_pool_bwd_ld / _gap_bwd_ld at the sizes where a block's (dp, y) fits the register file: one launch
-    (bn_bwd_resident_kernel: slice loaded once, per-channel exchange of the partial sums through a device counter, dY
-    from registers).  Same contract as the two-pass form: dY / dgamma / dbeta vs the oracle, the row-padded form writes
-    the same values plus a zero pad, two calls give identical bits (fixed summation order), and the counters are left
-    clean (a third call behaves like the first)."""
+    """ecg_bn_relu_pool_bwd_one_launch at the sizes where a block's (dp, y) fits the register file: one launch
+    (bn_bwd_resident_kernel: slice loaded once, per-channel exchange of the partial sums through CALLER-OWNED tagged words,
+    dY from registers).  Same contract as the two-pass form: dY / dgamma / dbeta vs the oracle, the row-padded form writes
+    the same values plus a zero pad, two calls give identical bits (fixed summation order), the exchange words are left
+    all zero (a third call behaves like the first), and the two-pass entry point agrees with it to rounding."""
     from ecg_hip import _lib as L
     N, C, Lo, gap = case
     ldy = (Lo + 63) // 64 * 64
-    assert L.query("ecg_bn_relu_pool_bwd_launches", N, C, Lo, ldy) == (2 if C == 32 else 1)
-    assert L.query("ecg_bn_relu_pool_bwd_launches", 32, C, Lo, ldy) == 2          # small batches keep the two short passes
+    S = L.query("ecg_bn_relu_pool_bwd_one_launch_splits", N, C, Lo, ldy)
+    assert (S == 0) == (C == 32)                                                      # block 0 (8 per channel) keeps two passes
+    assert L.query("ecg_bn_relu_pool_bwd_one_launch_splits", 32, C, Lo, ldy) == 0     # small batches keep the two short passes
     rng = np.random.default_rng(N + C + Lo)
     y = (rng.standard_normal((N, C, Lo)) * 1.5 + 0.3).astype(np.float32)
     gamma = (1 + 0.2 * rng.standard_normal(C)).astype(np.float32)
@@ -307,44 +308,63 @@ def test_bn_backward_in_one_launch_with_resident_operands_vs_oracle(hip, oracle,
     g = rng.standard_normal((N, C) if gap else (N, C, Lo // 2)).astype(np.float32)
     yd, gd, bd, md, isd, gg = map(dev, (y, gamma, beta, mean, invstd, g))
     ws = torch.empty(L.query("ecg_bn_relu_pool_bwd_ws_floats", N, C, Lo), device="cuda")
-    outs = []
-    for stride in (Lo, ldy, ldy):
+    n_u = L.query("ecg_bn_relu_pool_bwd_one_launch_counter_uints", N, C, Lo, ldy)
+    assert (n_u > 0) == (S > 1)
+    cnt = torch.zeros(max(n_u, 2), dtype=torch.int32, device="cuda")
+
+    def two_pass(stride):
         dy = torch.full((N, C, stride), float("nan"), device="cuda")
         dgam, dbet = torch.full((C,), float("nan"), device="cuda"), torch.full((C,), float("nan"), device="cuda")
         L.call("ecg_bn_relu_pool_gap_bwd_ld" if gap else "ecg_bn_relu_pool_bwd_ld",
                *map(L.f32, (yd, gg, gd, bd, md, isd, dy)), stride, *map(L.f32, (dgam, dbet, ws)), N, C, Lo, 1, L.stream())
-        outs.append((host(dy), host(dgam), host(dbet)))
-    (d0, g0, b0), (d1, g1, b1), (d2, g2, b2) = outs
+        return host(dy), host(dgam), host(dbet)
+
+    def one_launch(stride):
+        dy = torch.full((N, C, stride), float("nan"), device="cuda")
+        dgam, dbet = torch.full((C,), float("nan"), device="cuda"), torch.full((C,), float("nan"), device="cuda")
+        L.call("ecg_bn_relu_pool_bwd_one_launch", *map(L.f32, (yd, gg, gd, bd, md, isd, dy)), stride,
+               L.f32(dgam), L.f32(dbet), L.ptr(cnt), N, C, Lo, 1, 1 if gap else 0, -1, L.stream())
+        torch.cuda.synchronize()
+        assert not bool(cnt.any()), "exchange words not returned to zero"
+        return host(dy), host(dgam), host(dbet)
+
+    dp = np.repeat(g[:, :, None] / (Lo // 2), Lo // 2, axis=2).astype(np.float32) if gap else g
+    rdy, rdg, rdb = oracle.bn_relu_pool_bwd(y, dp, gamma, beta, mean, invstd, True)
+    t0, tg, tb = two_pass(Lo)
+    np.testing.assert_allclose(t0, rdy, atol=2e-5)
+    np.testing.assert_allclose(tg, rdg, rtol=2e-4, atol=2e-3)
+    np.testing.assert_allclose(tb, rdb, rtol=2e-4, atol=2e-3)
+    if S == 0:
+        with pytest.raises(L.EcgHipError, match="one-launch form"):
+            one_launch(Lo)
+        return
+    (d0, g0, b0), (d1, g1, b1), (d2, g2, b2) = [one_launch(st) for st in (Lo, ldy, ldy)]
     np.testing.assert_array_equal(d1[:, :, :Lo], d0)
     assert not d1[:, :, Lo:].any()
     np.testing.assert_array_equal(d2, d1)
     for a, b in ((g0, g1), (b0, b1), (g1, g2), (b1, b2)):
         np.testing.assert_array_equal(a, b)
-    dp = np.repeat(g[:, :, None] / (Lo // 2), Lo // 2, axis=2).astype(np.float32) if gap else g
-    rdy, rdg, rdb = oracle.bn_relu_pool_bwd(y, dp, gamma, beta, mean, invstd, True)
     np.testing.assert_allclose(d0, rdy, atol=2e-5)
     np.testing.assert_allclose(g0, rdg, rtol=2e-4, atol=2e-3)
     np.testing.assert_allclose(b0, rdb, rtol=2e-4, atol=2e-3)
+    np.testing.assert_allclose(d0, t0, atol=2e-5)
+    if S > 1:       # the words are REQUIRED (and checked) when workgroups exchange
+        with pytest.raises(L.EcgHipError, match="counter buffer"):
+            dy = torch.empty(N, C, Lo, device="cuda")
+            L.call("ecg_bn_relu_pool_bwd_one_launch", *map(L.f32, (yd, gg, gd, bd, md, isd, dy)), Lo, None, None, None,
+                   N, C, Lo, 1, 1 if gap else 0, -1, L.stream())
 
 
 def test_bn_backward_one_launch_self_service_gives_the_same_bits(tmp_path):
     """A workgroup of the one-launch BatchNorm backward that does not see its siblings arrive (they are not resident: a
     co-tenant holds their CUs) stops waiting and recomputes their partial sums itself.  Forced here for EVERY workgroup
-    (ECG_BN_BWD_RESIDENT_SPIN=0: nobody waits): dY, dgamma, dbeta must be bit-identical to the run in which the
-    workgroups exchange their partials, on the first call and on the second (counters left clean)."""
+    (spin_polls = 0: nobody waits): dY, dgamma, dbeta must be bit-identical to the run in which the workgroups exchange
+    their partials, on the first call and on the second (exchange words left clean — the worker asserts it)."""
     import subprocess
     import sys
-    worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "bn_resident_worker.py")
-    outs = []
-    for spin in (None, "0"):
-        env = dict(os.environ)
-        env.pop("ECG_BN_BWD_RESIDENT", None), env.pop("ECG_HIP_REHEARSE_ON_ONE_GPU", None)
-        if spin is not None:
-            env["ECG_BN_BWD_RESIDENT_SPIN"] = spin
-        out = tmp_path / f"spin_{spin}.npz"
-        r = subprocess.run([sys.executable, worker, str(out)], env=env, capture_output=True, text=True, timeout=300)
-        assert r.returncode == 0, r.stderr[-2000:]
-        outs.append(dict(np.load(out)))
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import bn_resident_worker as W
+    outs = [W.run(-1), W.run(0)]
     assert outs[0].keys() == outs[1].keys() and len(outs[0]) == 30
     for k in outs[0]:
         assert not np.isnan(outs[0][k]).any(), k
@@ -353,10 +373,8 @@ def test_bn_backward_one_launch_self_service_gives_the_same_bits(tmp_path):
             np.testing.assert_array_equal(outs[0][k], outs[0][k[:-1] + "0"], err_msg=k)
     # two co-tenant processes on the device at once (each kernel wants one workgroup on EVERY CU): whoever does not
     # become fully resident serves itself; both must still produce the solo run's bits
-    env = dict(os.environ)
-    env.pop("ECG_BN_BWD_RESIDENT", None), env.pop("ECG_HIP_REHEARSE_ON_ONE_GPU", None), env.pop("ECG_BN_BWD_RESIDENT_SPIN", None)
-    procs = [subprocess.Popen([sys.executable, worker, str(tmp_path / f"co_{i}.npz")], env=env, stdout=subprocess.PIPE,
-                              stderr=subprocess.PIPE, text=True) for i in range(2)]
+    procs = [subprocess.Popen([sys.executable, W.__file__, str(tmp_path / f"co_{i}.npz")], env=dict(os.environ),
+                              stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for i in range(2)]
     for i, pr in enumerate(procs):
         _, err = pr.communicate(timeout=300)
         assert pr.returncode == 0, err[-2000:]

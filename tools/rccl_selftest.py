@@ -23,11 +23,10 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "ptbxl-multimodal_amd"))
-# The hooked exchange keeps the BatchNorm backward in its two-pass form (csrc/bn_relu_pool.hip: the one-launch form is off
-# while all-reduces are issued under backward); the bit-for-bit comparisons below need the SAME form in the step without an
-# exchange, so the whole self-test runs on the two-pass form.
-os.environ["ECG_BN_BWD_RESIDENT"] = "0"
-
+# The BatchNorm backward takes its one-launch form unless collectives can run under backward (ecg_hip.functional:
+# declare_backward_collectives): the hooked exchange declares its parameters "busy" (two passes), the single all-reduce and
+# FlatGradDDP declare them "quiet" (one launch).  The two forms associate their partial sums differently, so each
+# bit-for-bit comparison below runs its reference step (no exchange) in the form the exchanged step takes.
 
 def main():
     ap = argparse.ArgumentParser()
@@ -84,34 +83,52 @@ def main():
         torch.cuda.synchronize()
         return losses
 
-    # 1. FlatAdamW: hooked two-bucket exchange over RCCL vs no exchange at all
+    import ecg_hip.functional as hipF
+
+    def one_launch(model):            # the form ConvBlockFn.backward will pick for this model's blocks (per call, per parameter)
+        return bool(hipF.bn_backward_one_launch_allowed(model.backbone[1].net[0].weight.data_ptr()))
+
+    # references without an exchange, in both forms of the BatchNorm backward
     ref = fresh()
+    out["bn_backward_one_launch"] = {"undeclared_single_rank": one_launch(ref)}
     ref_losses = run(ref, FlatAdamW(ref.parameters(), lr=1e-3, weight_decay=1e-4))
+    hipF.set_bn_backward_one_launch(False)
+    ref2p = fresh()
+    ref2p_losses = run(ref2p, FlatAdamW(ref2p.parameters(), lr=1e-3, weight_decay=1e-4))
+    hipF.set_bn_backward_one_launch(True)
+
+    # 1. FlatAdamW: hooked two-bucket exchange over RCCL vs no exchange at all (two-pass BatchNorm backward in both)
     m1 = fresh()
     ddp.broadcast_module_state(m1, 0)
     o1 = FlatAdamW(m1.parameters(), lr=1e-3, weight_decay=1e-4, exchange_single_rank=True)
+    out["bn_backward_one_launch"]["hooked_exchange"] = one_launch(m1)
     l1 = run(m1, o1)
     out["flat_adamw_hooked_exchange"] = {
         "overlap_hooks_active": bool(o1._overlap),
-        "bit_identical_to_unexchanged_step": bool(torch.equal(flat_state(ref), flat_state(m1))) and l1 == ref_losses}
+        "bit_identical_to_unexchanged_step": bool(torch.equal(flat_state(ref2p), flat_state(m1))) and l1 == ref2p_losses}
 
-    # 2. the exchange in one piece (overlap off)
+    # 2. the exchange in one piece (overlap off): nothing communicates under backward, the one-launch form stays on
     m2 = fresh()
-    l2 = run(m2, FlatAdamW(m2.parameters(), lr=1e-3, weight_decay=1e-4, exchange_single_rank=True, overlap=False))
+    o2 = FlatAdamW(m2.parameters(), lr=1e-3, weight_decay=1e-4, exchange_single_rank=True, overlap=False)
+    out["bn_backward_one_launch"]["single_allreduce"] = one_launch(m2)
+    l2 = run(m2, o2)
     out["flat_adamw_single_allreduce"] = {
         "bit_identical_to_unexchanged_step": bool(torch.equal(flat_state(ref), flat_state(m2))) and l2 == ref_losses}
+    o1.set_overlap(False)
+    out["bn_backward_one_launch"]["hooked_then_set_overlap_false"] = one_launch(m1)
+    o1.set_overlap(True)
 
     # 3. stock AdamW behind FlatGradDDP (scripts/03's optimizer)
     ref3 = fresh()
     ref3_losses = run(ref3, torch.optim.AdamW(ref3.parameters(), lr=1e-3, weight_decay=1e-4))
     m3 = fresh()
     w3 = ddp.FlatGradDDP(m3, exchange_single_rank=True)
+    out["bn_backward_one_launch"]["flat_grad_ddp"] = one_launch(m3)
     l3 = run(m3, torch.optim.AdamW(m3.parameters(), lr=1e-3, weight_decay=1e-4), wrapped=w3)
     out["flat_grad_ddp_stock_adamw"] = {
         "bit_identical_to_unexchanged_step": bool(torch.equal(flat_state(ref3), flat_state(m3))) and l3 == ref3_losses}
 
-    # 4. accumulation: two backward passes, the first under no_sync()
-    import ecg_hip.functional as hipF
+    # 4. accumulation: two backward passes, the first under no_sync() (a hooked optimizer: two-pass form on both sides)
 
     def two_pass(model, opt, exchanged):
         opt.zero_grad(set_to_none=True)
@@ -124,7 +141,9 @@ def main():
         torch.cuda.synchronize()
 
     ra, ma = fresh(), fresh()
+    hipF.set_bn_backward_one_launch(False)
     two_pass(ra, FlatAdamW(ra.parameters(), lr=1e-3), False)
+    hipF.set_bn_backward_one_launch(True)
     two_pass(ma, FlatAdamW(ma.parameters(), lr=1e-3, exchange_single_rank=True), True)
     out["no_sync_accumulation"] = {"bit_identical_to_unexchanged_step": bool(torch.equal(flat_state(ra), flat_state(ma)))}
 

@@ -11,7 +11,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, "ptbxl-multimodal_amd")):
     sys.path.insert(0, p)
-os.environ.setdefault("ECG_HIP_LIB", os.path.join(ROOT, "ptbxl-multimodal_amd", "lib", "libecg_hip_stamp.so"))
+os.environ.setdefault("ECG_HIP_LIB", os.path.join(ROOT, "tools", "_build", "libecg_hip_stamp.so"))
 
 
 def report(tag, stamps, flops):

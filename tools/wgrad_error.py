@@ -1,0 +1,176 @@
+#!/usr/bin/env python3
+"""Where does the fp32 train step lose accuracy at the headline batch?  (round-3 verdict, item 1)
+
+    python tools/wgrad_error.py [--batch 256] [--length 1000] [--model cnn5|mm] [--out file.json]
+
+Two attributions, both against float64 on the CPU (the stock-torch restatement in double):
+
+  per operator   the (x, dY) pairs of every ConvBlock are taken from the float64 run, rounded to fp32, and the weight
+                 gradient of exactly these operands is computed by the HIP kernel, by stock torch on the CPU in fp32
+                 (oneDNN) and in float64.  rel-RMS error of dW per layer, HIP next to CPU fp32: isolates the kernel's
+                 accumulation chain from everything upstream of it.
+  end to end     first-step gradient of every parameter tensor, HIP model vs float64 and CPU fp32 model vs float64
+                 (the BatchNorm sums, the input-gradient chain and the tail are in these numbers too).
+
+Diagnostic only (tests/ hold the bars).  ECG_HIP_LIB selects another build of the library for A/B runs.
+"""
+import argparse
+import copy
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "ptbxl-multimodal_amd")):
+    sys.path.insert(0, p)
+
+
+def rel_rms(a, ref):
+    import numpy as np
+    a, ref = np.asarray(a, dtype=np.float64), np.asarray(ref, dtype=np.float64)
+    return float(np.sqrt(((a - ref) ** 2).mean()) / max(np.sqrt((ref ** 2).mean()), 1e-300))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batch", type=int, default=256)
+    ap.add_argument("--length", type=int, default=1000)
+    ap.add_argument("--model", choices=["cnn5", "mm"], default="cnn5")
+    ap.add_argument("--out", default="")
+    ap.add_argument("--seed", type=int, default=42, help="model seed (set_seed / seed_all)")
+    ap.add_argument("--gen-seed", type=int, default=1234, help="generator seed of the synthetic batch")
+    a = ap.parse_args()
+    import torch
+    from oracle import ref_models as R
+    from ecg_hip import functional as hipF
+    from ecg_hip import _lib as L
+    from src.models.ecg_cnn import ECGCNN
+    from src.models.ecg_multimodal import ECGMultimodal
+    from src.utils.seed import set_seed
+    dev = torch.device("cuda", 0)
+    demo = a.model == "mm"
+    ctor, rctor = ((ECGMultimodal, R.RefECGMultimodal) if demo else
+                   (lambda: ECGCNN(num_labels=5), lambda: R.RefECGCNN(num_labels=5)))
+    batch = R.synthetic_batch(a.batch, a.length, 5, gen_seed=a.gen_seed, demo=demo)
+    R.seed_all(a.seed)
+    ref32 = rctor().train()
+    ref64 = copy.deepcopy(ref32).double()
+    set_seed(a.seed)
+    model = ctor().to(dev).train()
+
+    # ---- float64 run with hooks on every Conv1d: its input and the gradient of its output ------------------
+    convs64 = [m for m in ref64.modules() if isinstance(m, torch.nn.Conv1d)]
+    cap = {}
+    for i, c in enumerate(convs64):
+        c.register_forward_hook(lambda mod, inp, out, i=i: cap.__setitem__(("x", i), inp[0].detach()))
+        c.register_full_backward_hook(lambda mod, gi, go, i=i: cap.__setitem__(("dy", i), go[0].detach()))
+    b64 = tuple(t.double() for t in batch)
+    ref64.zero_grad()
+    torch.nn.functional.binary_cross_entropy_with_logits(ref64(*b64[:-1]), b64[-1]).backward()
+    ref32.zero_grad()
+    torch.nn.functional.binary_cross_entropy_with_logits(ref32(*batch[:-1]), batch[-1]).backward()
+    model.zero_grad()
+    db = [t.to(dev) for t in batch]
+    hipF.binary_cross_entropy_with_logits(model(*db[:-1]), db[-1]).backward()
+    torch.cuda.synchronize()
+
+    g64 = {k: p.grad.detach().clone().numpy() for k, p in ref64.named_parameters()}
+    g32 = {k: p.grad.detach().clone().numpy() for k, p in ref32.named_parameters()}
+    gh = {k: p.grad.detach().cpu().numpy() for k, p in model.named_parameters()}
+
+    out = {"lib": os.path.basename(L.LIB_PATH), "batch": a.batch, "length": a.length, "model": a.model,
+           "per_operator": [], "end_to_end": []}
+    print(f"library {L.LIB_PATH}\nB={a.batch} 12x{a.length} {a.model}")
+    print("\nper operator: dW of the SAME fp32-rounded (x, dY), rel-RMS error vs float64")
+    print(f"{'layer':<8}{'C_in':>5}{'C_out':>6}{'L':>6}{'terms':>8}{'HIP':>12}{'CPU fp32':>12}{'HIP/CPU':>9}")
+    for i, c in enumerate(convs64):
+        x32, dy32 = cap[("x", i)].float(), cap[("dy", i)].float()
+        K, pad = c.kernel_size[0], c.padding[0]
+        dw64 = torch.nn.grad.conv1d_weight(x32.double(), c.weight.shape, dy32.double(), padding=pad)
+        dw32 = torch.nn.grad.conv1d_weight(x32, c.weight.shape, dy32, padding=pad)
+        xg, dyg = x32.to(dev).contiguous(), dy32.to(dev).contiguous()
+        # the train step hands the weight gradient a ROW-PADDED dY (the LDS-DMA kernel): do the same here
+        N, Ci, Lin = xg.shape
+        Co = c.weight.shape[0]
+        Lo = dyg.shape[2]
+        ldy = L.query("ecg_conv1d_dy_row_stride", N, Ci, Co, Lin, K, pad, 0)
+        dyp = torch.zeros(N, Co, ldy, device=dev)
+        dyp[:, :, :Lo] = dyg
+        _, dwh, _ = hipF.conv1d_backward_raw(xg, dyp, c.weight.shape, None, pad, need_dx=False, ldy=ldy)
+        e_h, e_c = rel_rms(dwh.cpu().numpy(), dw64.numpy()), rel_rms(dw32.numpy(), dw64.numpy())
+        print(f"block {i:<2}{Ci:>5}{Co:>6}{Lo:>6}{N * Lo:>8}{e_h:>12.3e}{e_c:>12.3e}{e_h / e_c:>9.2f}")
+        out["per_operator"].append({"block": i, "terms": N * Lo, "hip": e_h, "cpu_fp32": e_c})
+
+    # ---- the other two conv entry points on the same operands, and the discrete decisions behind the gradients ----
+    print("\nper operator: forward y and input gradient dX of the same fp32-rounded operands, rel-RMS error vs float64")
+    print(f"{'layer':<8}{'chain':>7}{'y HIP':>12}{'y CPU':>12}{'ratio':>7}{'chain':>7}{'dX HIP':>12}{'dX CPU':>12}{'ratio':>7}")
+    for i, c in enumerate(convs64):
+        x32, dy32 = cap[("x", i)].float(), cap[("dy", i)].float()
+        w32, b32 = c.weight.detach().float(), c.bias.detach().float()
+        K, pad = c.kernel_size[0], c.padding[0]
+        Co, Ci = w32.shape[0], w32.shape[1]
+        y64 = torch.nn.functional.conv1d(x32.double(), w32.double(), b32.double(), padding=pad)
+        y32 = torch.nn.functional.conv1d(x32, w32, b32, padding=pad)
+        wf, wb = hipF.conv1d_pack(w32.to(dev), need_bwd=True)
+        yh, _, _ = hipF.conv1d_forward_raw(x32.to(dev), wf, b32.to(dev), Co, K, pad, want_stats=False)
+        e_h, e_c = rel_rms(yh.cpu().numpy(), y64.numpy()), rel_rms(y32.numpy(), y64.numpy())
+        row = f"block {i:<2}{Ci * K:>7}{e_h:>12.3e}{e_c:>12.3e}{e_h / e_c:>7.2f}"
+        rec = {"block": i, "y_hip": e_h, "y_cpu_fp32": e_c}
+        if i > 0:
+            dx64 = torch.nn.grad.conv1d_input(x32.shape, w32.double(), dy32.double(), padding=pad)
+            dx32 = torch.nn.grad.conv1d_input(x32.shape, w32, dy32, padding=pad)
+            dxh, _, _ = hipF.conv1d_backward_raw(x32.to(dev), dy32.to(dev).contiguous(), w32.shape, wb, pad, need_dx=True)
+            d_h, d_c = rel_rms(dxh.cpu().numpy(), dx64.numpy()), rel_rms(dx32.numpy(), dx64.numpy())
+            row += f"{Co * K:>7}{d_h:>12.3e}{d_c:>12.3e}{d_h / d_c:>7.2f}"
+            rec.update(dx_hip=d_h, dx_cpu_fp32=d_c)
+        print(row)
+        out["per_operator"].append(rec)
+
+    # discrete decisions of the float64 run that a fp32 run takes differently: ReLU sign of the pooled maximum, and
+    # which element of a pooling pair wins.  One flipped routing moves one dY element by one position: ~1/sqrt(terms)
+    # of a channel's weight gradient — orders of magnitude above any rounding of the sums.
+    def decisions(m, args, hip):
+        zs, hs = [], []
+        bns = [b for b in m.modules() if isinstance(b, torch.nn.BatchNorm1d)]
+        for b in bns:
+            hs.append(b.register_forward_hook(lambda mod, inp, o: zs.append(o.detach().cpu())))
+        m.zero_grad()
+        m(*args)
+        for h in hs:
+            h.remove()
+        res = []
+        for z in zs:
+            Lp = z.shape[2] // 2
+            pr = z[:, :, :2 * Lp].reshape(z.shape[0], z.shape[1], Lp, 2)
+            res.append(((pr[..., 1] > pr[..., 0]), (pr.max(-1).values > 0)))
+        return res
+    d64 = decisions(ref64, b64[:-1], False)
+    R.seed_all(a.seed)
+    fresh32 = rctor().train()          # (ref32 / model have taken a step's worth of BN statistics already: fresh copies)
+    d32 = decisions(fresh32, batch[:-1], False)
+    set_seed(a.seed)
+    fresh_h = ctor().to(dev).train()
+    dh = decisions(fresh_h, db[:-1], True)
+    print("\ndecisions that differ from the float64 run (block: pooling winner where the maximum is active | ReLU sign of the maximum)")
+    for i in range(len(d64)):
+        a64, m64 = d64[i]
+        def cnt(d):
+            a, m = d[i]
+            return int(((a != a64) & m64 & m).sum()), int((m != m64).sum())
+        rh, rc = cnt(dh), cnt(d32)
+        print(f"block {i}: HIP {rh[0]:>4} | {rh[1]:>4}     CPU fp32 {rc[0]:>4} | {rc[1]:>4}     of {a64.numel()} pairs")
+        out.setdefault("decisions", []).append({"block": i, "hip": rh, "cpu_fp32": rc, "pairs": a64.numel()})
+
+    print("\nend to end: first-step parameter gradients, rel-RMS error vs the float64 model")
+    print(f"{'parameter':<40}{'HIP':>12}{'CPU fp32':>12}{'HIP/CPU':>9}")
+    for k in gh:
+        e_h, e_c = rel_rms(gh[k], g64[k]), rel_rms(g32[k], g64[k])
+        print(f"{k:<40}{e_h:>12.3e}{e_c:>12.3e}{e_h / max(e_c, 1e-300):>9.2f}")
+        out["end_to_end"].append({"param": k, "hip": e_h, "cpu_fp32": e_c})
+    if a.out:
+        with open(a.out, "w") as f:
+            json.dump(out, f, indent=1)
+
+
+if __name__ == "__main__":
+    main()
