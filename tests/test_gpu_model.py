@@ -544,13 +544,22 @@ def _short_run_losses(precision):
         return [train_one_epoch_demo(model, Loader(), opt, DEV) for _ in range(5)]
 
 
-@pytest.mark.parametrize("act_bf16", [True, False])
-@pytest.mark.parametrize("B,T", [(8, 5000), (19, 1000)])
+@pytest.mark.parametrize("B,T,act_bf16", [(8, 5000, True), (8, 5000, False), (19, 1000, True), (19, 1000, False),
+                                          (256, 5000, True)])
 def test_bf16_mixed_precision_train_step_config5(B, T, act_bf16):
-    """BASELINE.json config 5 shape family: ECGCNN(num_labels=1) (AF binary), long windows, bf16
-    conv operands.  No fp32-level parity is claimed: the step must track the fp32 CPU oracle at
-    bf16 accuracy (the reference has no mixed precision to compare with).  B=19: a ragged group of 16 samples in
-    the n16 operand chain (BN forward -> next conv's weight gradient, BN backward -> dY operands)."""
+    """BASELINE.json config 5: ECGCNN(num_labels=1) (AF binary, configs/af_binary.yaml shape), long windows, bf16 conv
+    operands — (256, 5000) is the configuration at its STATED size, end to end.  No fp32-level parity is claimed: the step
+    must track the fp32 CPU oracle at bf16 accuracy (the reference has no mixed precision to compare with).  B=19: a
+    ragged group of 16 samples in the n16 operand chain (BN forward -> next conv's weight gradient, BN backward -> dY).
+
+    Bars = about 1.3x the largest value measured over these five cases (round 4, tools/_bf16_err.py; the measured
+    value of every tensor is in the assertion message):
+      logits 1.2e-3 -> 3e-3, loss 4.2e-5 -> 2e-4;
+      tensors BEHIND the last bf16 conv (block-3 BatchNorm, proj, head): rel <= 3.7e-3, 1-cos <= 6.8e-6 -> 1e-2 / 2e-5;
+      tensors upstream of it: rel 0.064 ... 0.188, 1-cos 0.002 ... 0.0174 -> 0.25 / 0.025.  These are NOT rounding of sums:
+      a bf16 y (eps 2^-8) flips ~0.3 % of the ReLU / pooling decisions, each flip moves one dY element, and the relative
+      error of a gradient grows like sqrt(2 x fraction flipped) ~ 0.08 per block (0.07 / 0.11 / 0.14 / 0.157 from block 3
+      down at the full size) — the price of bf16 activations, the same with fp32 storage of y (0.093 ... 0.14)."""
     from ecg_hip import functional as hipF
     from src.models.ecg_cnn import ECGCNN
     from src.utils.seed import set_seed
@@ -571,17 +580,21 @@ def test_bf16_mixed_precision_train_step_config5(B, T, act_bf16):
     rl = ref(x)
     rloss = torch.nn.functional.binary_cross_entropy_with_logits(rl, y)
     rloss.backward()
-    np.testing.assert_allclose(logits.detach().cpu().numpy(), rl.detach().numpy(), atol=3e-2)
-    assert abs(loss.item() - rloss.item()) < 5e-3
-    assert float((logits.detach().cpu() - rl.detach()).abs().max()) > 1e-6      # it really took the bf16 path
+    dlogit = float((logits.detach().cpu() - rl.detach()).abs().max())
+    assert 1e-6 < dlogit < 3e-3, dlogit                 # bf16 accuracy — and it really took the bf16 path
+    assert abs(loss.item() - rloss.item()) < 2e-4, (loss.item(), rloss.item())
+    measured = {}
     for (k, a), (_, b) in zip(model.named_parameters(), ref.named_parameters()):
         if ".net.0.bias" in k:
             continue
-        g, r = a.grad.cpu().numpy().ravel(), b.grad.numpy().ravel()
+        g, r = a.grad.cpu().numpy().ravel().astype(np.float64), b.grad.numpy().ravel().astype(np.float64)
         rel = np.linalg.norm(g - r) / (np.linalg.norm(r) + 1e-12)
-        cos = float(g @ r) / (np.linalg.norm(g) * np.linalg.norm(r) + 1e-20)
-        # bf16 rounding noise accumulates towards the first block (3 bf16 input-grad convs deep)
-        assert rel < 0.2 and cos > 0.98, (k, rel, cos)
+        omc = 1.0 - float(g @ r) / (np.linalg.norm(g) * np.linalg.norm(r) + 1e-20)
+        measured[k] = (round(float(rel), 5), float(f"{omc:.3g}"))
+    for k, (rel, omc) in measured.items():
+        behind = k.startswith(("backbone.3.net.1", "proj", "head"))
+        rel_bar, omc_bar = (1e-2, 2e-5) if behind else (0.25, 0.025)
+        assert rel <= rel_bar and omc <= omc_bar, f"{k}: rel {rel} (bar {rel_bar}), 1-cos {omc} (bar {omc_bar}); all: {measured}"
 
 
 @pytest.mark.parametrize("frozen", [None, 1, 2, 3])
