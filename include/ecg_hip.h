@@ -206,8 +206,37 @@ int ecg_bn_relu_pool_bwd_n16_yh(const void *y_bf16, int ldyy, const void *dp, in
                                 const float *beta, const float *mean, const float *invstd, float *dy, int ldy,
                                 void *dy_n16, int PA, float *dgamma, float *dbeta, float *ws, int N, int C, int L,
                                 int train, int gap, void *dy_bf16, ecg_stream_t stream);
+/* The same passes on bf16 [N][C][ld] tensors ONLY (round 4, csrc/bn_relu_pool_h.hip; 16 bytes per lane, no n16 copies — the
+ * producers of the time-on-K weight gradient ecg_conv1d_bwd_weight_bias_bf16_ncl):
+ *   ecg_bn_stats_relu_pool_fwd_h: statistics combine + BN + ReLU + MaxPool(2): y_bf16 [N][C][ldy] -> p_bf16 [N][C][ldp], rows
+ *     zero-filled from L/2 to ldp (ldy, ldp multiples of 8); mean / invstd are outputs, running statistics and the counter
+ *     are updated as by ecg_bn_stats_relu_pool_fwd.
+ *   ecg_bn_relu_pool_bwd_h: reduction pass + dx pass: dp bf16 [N][C][ldp] (dp_kind 0), fp32 dg [N][C] of the fused global
+ *     average pool (1) or fp32 dp [N][C][ldp] (2) -> dy_bf16 [N][C][ldy]
+ *     with rows zero-filled from L to ldy (give ldy = ecg_conv1d_bf16_tk_dy_stride(L)), dgamma, dbeta; ws from
+ *     ecg_bn_relu_pool_bwd_ws_floats.  Same reference call site: autograd of ConvBlock.net[1..3], src/models/ecg_cnn.py:14-16. */
+int ecg_bn_stats_relu_pool_fwd_h(const float *stat_partials, int P, long long count, float *running_mean,
+                                 float *running_var, long long *num_batches_tracked, float momentum, float eps,
+                                 const void *y_bf16, int ldy, const float *gamma, const float *beta, float *mean,
+                                 float *invstd, void *p_bf16, int ldp, int N, int C, int L, ecg_stream_t stream);
+int ecg_bn_relu_pool_bwd_h(const void *y_bf16, int ldyy, const void *dp, int dp_kind, int ldp, const float *gamma,
+                           const float *beta, const float *mean, const float *invstd, void *dy_bf16, int ldy,
+                           float *dgamma, float *dbeta, float *ws, int N, int C, int L, int train,
+                           ecg_stream_t stream);
 int ecg_conv1d_bwd_data_bf16hh(const void *dy_bf16, int ldy, const void *wb_bwd, void *dx_bf16, int ldx, int N,
                                int C_in, int C_out, int L, int K, int pad, ecg_stream_t stream);
+/* Weight + bias gradient on the bf16 tensors the other two convs read — TIME on the MFMA's K axis, no n16 copies (round 4,
+ * csrc/conv1d_wgrad_bf16_tk.hip): dy_bf16 [N][C_out][ldy] with ldy = ecg_conv1d_bf16_tk_dy_stride(Lo) (rows zero-filled to a
+ * multiple of 128), x either bf16 [N][C_in][ldx] (x_is_bf16 != 0: ldx % 8 == 0, rows zero-filled past L — the previous
+ * block's pooled activation as ecg_bn_stats_relu_pool_fwd_yh writes it) or the fp32 network input [N][C_in][ldx] (L % 8 == 0),
+ * rounded to bf16 while it is staged.  K == 15, pad == 7, C_out % 64 == 0 (ecg_conv1d_bf16_tk_supported).  Exact on the
+ * bf16-rounded operands up to fp32 accumulation order.  Same reference call site as ecg_conv1d_bwd_weight_bias. */
+int ecg_conv1d_bf16_tk_supported(int C_in, int C_out, int K, int pad);
+int ecg_conv1d_bf16_tk_dy_stride(int Lo);
+size_t ecg_conv1d_bwd_weight_bf16_ncl_ws_floats(int N, int C_in, int C_out, int L, int K, int pad);
+int ecg_conv1d_bwd_weight_bias_bf16_ncl(const void *dy_bf16, int ldy, const void *x, int x_is_bf16, int ldx,
+                                        float *dw, float *db, float *ws, int N, int C_in, int C_out, int L,
+                                        int K, int pad, ecg_stream_t stream);
 size_t ecg_conv1d_bwd_weight_bf16_packed_ws_floats(int N, int C_in, int C_out, int L, int K, int pad);
 int ecg_conv1d_bwd_weight_bias_bf16_packed(const void *dy_n16, const void *x_n16, float *dw, float *db,
                                            float *ws, int N, int C_in, int C_out, int L, int K, int pad,

@@ -1,0 +1,426 @@
+// conv1d_wgrad_bf16_tk.hip — mixed-precision weight gradient with TIME on the MFMA's K axis (round 4).
+//
+//   dW[co][ci][k] = sum_n sum_t dY[n][co][t] * X[n][ci][t + k - pad]
+//
+// conv1d_wgrad_bf16.hip puts a group of 16 SAMPLES on the K axis of v_mfma_f32_32x32x16_bf16 because a tap shift along t
+// moves the x operand by 2 bytes — an unaligned 16-byte fragment.  The price was a second copy of every activation and
+// of every dY in the "n16" layout, written by the BatchNorm passes: 0.49 GB of the 2.3 GB those passes move per step of
+// BASELINE config 5, plus a packing pass over the network input.  This kernel reads the tensors the OTHER two convs read —
+// bf16 [N][C][ld] rows — and takes the 16 reduction indices of an MFMA along t:
+//   A[co][j] = dY[n][co][t0 + j]            one aligned ds_read_b128 per lane (8 consecutive t)
+//   B[j][(ci,k)] = X[n][ci][t0 + j + k - 7] the x tile is kept FOUR times in LDS, shifted by 0 / 1 / 2 / 3 elements (built
+//                                           with v_alignbit when the tile is committed): a fragment that starts at element e
+//                                           reads copy e % 4 at an 8-byte aligned address — two ds_read_b64, the same LDS
+//                                           cycles as one aligned ds_read_b128.  (Measured on the way: gfx950 serves a 2-byte
+//                                           aligned ds_read_b128, but at 1/11 of the aligned rate — tools/lds_unaligned_bench.hip;
+//                                           two copies read with ds_read2_b32 pairs run at a quarter of the b64 rate on 32
+//                                           banks: 3x the LDS cycles of the n16 kernel, 190 vs 147 us on block 3.)
+// A stage is (sample n, 128 time steps) = 8 MFMA k-steps; workgroup tile M_T (co) x 512 columns r = ci*15 + k, eight waves,
+// one workgroup per CU, two dY images and two x images in LDS:
+//   dY tile [M_T][128] bf16 (32 KB at M_T = 128) streams global -> LDS by DMA (asm, see conv1d_bf16_ring.hip), rows of 16
+//     16-byte slots with slot s of row co stored at s ^ (co & 15) (conflict-free A reads) — needs dY rows zero-filled to a
+//     multiple of 128 (ecg_conv1d_bf16_tk_dy_stride), which is what makes a ragged last tile harmless;
+//   x tile [NCI][152] bf16 is register-staged one stage ahead (zero padding by mask, the four copies written with four
+//     ds_write_b128 per 16-byte chunk); x is the previous block's bf16 activation [N][C_in][ldx] (rows zero-filled past L),
+//     or the fp32 network input, rounded to bf16 here (block 0: no packing pass at all).
+// Split over stages into <= 256 slabs summed in fixed order by wgrad_reduce_kernel, bias gradient on the dY fragments.
+// Exact on bf16-rounded operands up to fp32 accumulation order (tests/test_gpu_ops.py::test_bf16_tk_*).
+// Replaces autograd's conv weight-gradient (reference src/models/ecg_cnn.py:13 via loss.backward()).
+#include "common.h"
+
+namespace ecg {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned short u16;
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4t __attribute__((ext_vector_type(4)));
+
+namespace tk {
+
+constexpr int KK = 15, PAD = 7;
+constexpr int TT = 128;          // time steps per stage
+constexpr int KS = TT / 16;      // MFMA k-steps per stage
+constexpr int XC = 19;           // 16-byte chunks of an x row image: elements t0 - 8 ... t0 + 143
+constexpr int XRS = 320;         // x row stride in bytes: 80 dwords = 16 banks (mod 64) between input channels
+constexpr int XCOPY_PAD[4] = {0, 32, 128, 160};   // the four shifted copies start 0 / 8 / 32 / 40 banks into a bank row: the
+                                                  // (channel, copy) windows of 8 banks that the 32 lanes of a half-wave
+                                                  // read then overlap only between channel c and c + 2
+constexpr int R_T = 512;
+
+__device__ __forceinline__ int acc_row(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }
+
+__device__ __forceinline__ unsigned pack2(float lo, float hi) {
+    const u16 a = __builtin_bit_cast(u16, (__bf16)lo), b = __builtin_bit_cast(u16, (__bf16)hi);
+    return (unsigned)a | ((unsigned)b << 16);
+}
+
+template <int M_T, int WM, int WR, bool XF32>
+__global__ __launch_bounds__(512) void conv1d_wgrad_bf16_tk_kernel(
+    const u16 *__restrict__ dy, const void *__restrict__ xin, float *__restrict__ slab, int N, int Cin, int Cout,
+    int L, int ldy, int ldx, int ntt, int S) {
+    static_assert(WM * WR == 8, "8 waves per workgroup");
+    constexpr int MC = M_T / WM / 32, MR = R_T / WR / 32;
+    static_assert(MC == 2 && (MR == 4 || MR == 2), "wave tile 64 x 128 or 64 x 64");
+    constexpr int NCI = (R_T + KK - 2) / KK + 1;
+    constexpr int AIMG = M_T * 16 * 16;                    // dY image: M_T rows of 16 slots of 16 bytes
+    constexpr int ADMA = AIMG / 1024, APW = ADMA / 8;      // 1 KB DMA pieces, per wave
+    static_assert(ADMA % 8 == 0, "dY image must split evenly over the eight waves");
+    constexpr int XCSZ = NCI * XRS;                        // bytes of one copy (a multiple of 256: 64 banks)
+    constexpr int XIMG = ((4 * XCSZ + XCOPY_PAD[3] + 255) / 256) * 256;
+    constexpr int XITEMS = NCI * XC, XI = (XITEMS + 511) / 512;
+    static_assert(2 * (AIMG + XIMG) <= 160 * 1024, "LDS");
+    static_assert(APW <= KS, "one DMA piece per k-step");
+
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[2 * (AIMG + XIMG)];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int half = lane >> 5, l31 = lane & 31;
+    const int R = Cin * KK;
+    const int RT = (R + R_T - 1) / R_T, CT = Cout / M_T;
+    int tile;
+    {       // XCD-aware order (conv1d_mfma.hip): the R tiles of one (C_out tile, split) share a dY slice
+        const int nwg = gridDim.x, bid = blockIdx.x;
+        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+        tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    }
+    const int tile_r = tile % RT, tile_cs = tile / RT;
+    const int r0 = tile_r * R_T, co0 = (tile_cs % CT) * M_T, s = tile_cs / CT;
+    const int wr = wave % WR, wm = wave / WR;
+    const int wm0 = wm * (M_T / WM), wr0 = wr * (R_T / WR);
+    const int ci_base = r0 / KK;
+    const int total = N * ntt;
+    const int st_begin = (int)((long long)total * s / S), st_end = (int)((long long)total * (s + 1) / S);
+
+    // ---- fragment addressing: byte offsets inside an image ---------------------------------------------
+    const int aoffl = (wm0 + l31) * 256;                    // + ((2 ks + half) ^ (co & 15)) * 16, + i * 32 rows
+    const int asw = l31 & 15;                               // (wm0 + 32 i) is a multiple of 16: co & 15 = l31 & 15
+    int boffl[MR];
+#pragma unroll
+    for (int j = 0; j < MR; ++j) {
+        int r = r0 + wr0 + 32 * j + l31;
+        if (r >= R) r = R - 1;                              // clamped columns compute garbage that is never stored
+        const int ci = r / KK, tap = r - ci * KK;
+        // first element of the fragment at k-step 0, half 0: e = tap + 1 -> copy e % 4 at byte 2 (e - e % 4): a multiple of 8
+        const int e = tap + 1, sft = e & 3;
+        boffl[j] = (ci - ci_base) * XRS + sft * XCSZ + (sft == 0 ? XCOPY_PAD[0] : sft == 1 ? XCOPY_PAD[1] : sft == 2 ? XCOPY_PAD[2] : XCOPY_PAD[3])
+                   + 2 * (e - sft) + 16 * half;
+    }
+
+    f32x16 acc[MC][MR];
+#pragma unroll
+    for (int a = 0; a < MC; ++a)
+#pragma unroll
+        for (int b = 0; b < MR; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+    float bsum[MC];
+#pragma unroll
+    for (int a = 0; a < MC; ++a) bsum[a] = 0.f;
+    const bool want_bias = (tile_r == 0);
+
+    // ---- dY DMA geometry (loop-invariant per lane) ---------------------------------------------------------
+    int aoff[APW];
+#pragma unroll
+    for (int j = 0; j < APW; ++j) {
+        const int sl = (j * 8 + wave) * 64 + lane;
+        const int co = sl >> 4, ls = sl & 15;
+        const int gs = ls ^ (co & 15);                      // LDS slot ls of row co holds the row's 16-byte chunk gs
+        aoff[j] = (co * ldy + 8 * gs) * 2;                  // bytes
+    }
+    const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)lds;
+    auto glds = [&](const u16 *base, unsigned voff, unsigned dst_off) __attribute__((always_inline)) {
+        const unsigned dst = (unsigned)__builtin_amdgcn_readfirstlane((int)(lds_base + dst_off));
+        unsigned keep;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(voff), "s"(base), "s"(dst) : "memory");
+    };
+
+    // ---- x staging geometry ------------------------------------------------------------------------------
+    int xrow[XI], xe[XI], xdst[XI];
+#pragma unroll
+    for (int j = 0; j < XI; ++j) {
+        const int idx = min(tid + 512 * j, XITEMS - 1);
+        const int row = idx / XC, c = idx - row * XC;
+        xrow[j] = min(ci_base + row, Cin - 1) * ldx;       // clamped rows feed columns that are never stored
+        xe[j] = 8 * c - 8;
+        xdst[j] = row * XRS + 16 * c;
+    }
+    u32x4 xE[XI];
+    unsigned xN[XI][2];                                     // the first two dwords of the next chunk (shifted copies)
+
+    // stage coordinates of the stage that is STAGED next (dY DMA + x loads)
+    int dn = st_begin / ntt, dt0 = (st_begin - dn * ntt) * TT;
+    auto advance = [&]() __attribute__((always_inline)) {
+        dt0 += TT;
+        if (dt0 >= ntt * TT) { dt0 = 0; ++dn; }
+        if (dn >= N) { dn = N - 1; dt0 = (ntt - 1) * TT; }  // past the end: restage a valid tile nobody reads
+    };
+    auto dma_a = [&](int j, int aimg) __attribute__((always_inline)) {
+        const u16 *abase = dy + ((size_t)dn * Cout + co0) * ldy + dt0;                    // uniform
+        glds(abase, (unsigned)aoff[j], (unsigned)(aimg * AIMG + (j * 8 + wave) * 1024));
+    };
+    auto load_x = [&](int j) __attribute__((always_inline)) {
+        const int g0 = dt0 + xe[j];
+        if (XF32) {
+            const float *xr = static_cast<const float *>(xin) + (size_t)dn * Cin * ldx + xrow[j];
+            // (host: L % 8 == 0, so a chunk is inside the row or outside it as a whole; the clamp only keeps the load in bounds)
+            const int gc = min(max(g0, 0), L - 8);
+            const f32x4t a = *reinterpret_cast<const f32x4t *>(xr + gc), b = *reinterpret_cast<const f32x4t *>(xr + gc + 4);
+            const int gn = min(max(g0 + 8, 0), L - 4);
+            const f32x4t nx = *reinterpret_cast<const f32x4t *>(xr + gn);
+            const bool ok = g0 >= 0 && g0 < L;
+            float v[8];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { v[i] = ok ? a[i] : 0.f; v[4 + i] = ok ? b[i] : 0.f; }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) xE[j][i] = pack2(v[2 * i], v[2 * i + 1]);
+            const bool okn = g0 + 8 >= 0 && g0 + 8 < L;
+            xN[j][0] = okn ? pack2(nx[0], nx[1]) : 0u;
+            xN[j][1] = okn ? pack2(nx[2], nx[3]) : 0u;
+        } else {
+            const u16 *xr = static_cast<const u16 *>(xin) + (size_t)dn * Cin * ldx + xrow[j];
+            const int gc = min(max(g0, 0), ldx - 8);
+            xE[j] = *reinterpret_cast<const u32x4 *>(xr + gc);
+            typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+            const u32x2 nx = *reinterpret_cast<const u32x2 *>(xr + min(max(g0 + 8, 0), ldx - 4));
+            const bool ok = g0 >= 0 && g0 < ldx;           // rows are zero-filled from L to ldx by their producer
+#pragma unroll
+            for (int i = 0; i < 4; ++i) xE[j][i] = ok ? xE[j][i] : 0u;
+            const bool okn = g0 + 8 >= 0 && g0 + 8 < ldx;
+            xN[j][0] = okn ? nx[0] : 0u;
+            xN[j][1] = okn ? nx[1] : 0u;
+        }
+    };
+    auto commit_x = [&](int j, int ximg) __attribute__((always_inline)) {
+        if (512 * (j + 1) <= XITEMS || tid + 512 * j < XITEMS) {
+            // copy s holds the row shifted by s elements: copy_s[e] = E[e + s]
+            const unsigned e0 = xE[j][0], e1 = xE[j][1], e2 = xE[j][2], e3 = xE[j][3], n0 = xN[j][0], n1 = xN[j][1];
+            u32x4 c1, c2, c3;
+            c1[0] = __builtin_amdgcn_alignbit(e1, e0, 16); c1[1] = __builtin_amdgcn_alignbit(e2, e1, 16);
+            c1[2] = __builtin_amdgcn_alignbit(e3, e2, 16); c1[3] = __builtin_amdgcn_alignbit(n0, e3, 16);
+            c2[0] = e1; c2[1] = e2; c2[2] = e3; c2[3] = n0;
+            c3[0] = c1[1]; c3[1] = c1[2]; c3[2] = c1[3]; c3[3] = __builtin_amdgcn_alignbit(n1, n0, 16);
+            unsigned char *dst = lds + 2 * AIMG + ximg * XIMG + xdst[j];
+            *reinterpret_cast<u32x4 *>(dst + XCOPY_PAD[0]) = xE[j];
+            *reinterpret_cast<u32x4 *>(dst + XCSZ + XCOPY_PAD[1]) = c1;
+            *reinterpret_cast<u32x4 *>(dst + 2 * XCSZ + XCOPY_PAD[2]) = c2;
+            *reinterpret_cast<u32x4 *>(dst + 3 * XCSZ + XCOPY_PAD[3]) = c3;
+        }
+    };
+
+    if (st_begin < st_end) {
+#pragma unroll
+        for (int j = 0; j < APW; ++j) dma_a(j, 0);
+#pragma unroll
+        for (int j = 0; j < XI; ++j) load_x(j);
+#pragma unroll
+        for (int j = 0; j < XI; ++j) commit_x(j, 0);
+        advance();
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    for (int st = st_begin; st < st_end; ++st) {
+        const int img = (st - st_begin) & 1;
+        const int abase_l = img * AIMG, xbase_l = 2 * AIMG + img * XIMG;
+        // (per-lane terms are made opaque where they are used: left alone, hipcc precomputes one address register per
+        // (k-step, fragment) and spills — conv1d_wgrad_bf16.hip)
+        auto ld_a = [&](int ks, int i) __attribute__((always_inline)) {
+            int sw = asw;
+            asm volatile("" : "+v"(sw));
+            return *reinterpret_cast<const bf16x8 *>(&lds[abase_l + aoffl + (((2 * ks + half) ^ sw) << 4) + i * (32 * 256)]);
+        };
+        // two base registers per fragment, 8 bytes apart and opaque to the compiler: with one base it fuses the two 8-byte
+        // reads into ds_read2_b64, which runs at a quarter of the ds_read_b64 rate (MI355X_MICROARCH.md, LDS table)
+        int bl[MR], bh[MR];
+#pragma unroll
+        for (int j = 0; j < MR; ++j) {
+            bl[j] = xbase_l + boffl[j];
+            bh[j] = bl[j] + 8;
+            asm volatile("" : "+v"(bl[j]), "+v"(bh[j]));
+        }
+        auto ld_b = [&](int ks, int j) __attribute__((always_inline)) {
+            typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+            const u32x2 lo = *reinterpret_cast<const u32x2 *>(&lds[bl[j] + 32 * ks]);          // 8-byte aligned
+            const u32x2 hi = *reinterpret_cast<const u32x2 *>(&lds[bh[j] + 32 * ks]);
+            u32x4 v;
+            v[0] = lo[0]; v[1] = lo[1]; v[2] = hi[0]; v[3] = hi[1];
+            return __builtin_bit_cast(bf16x8, v);
+        };
+        bf16x8 a_c[MC], a_n[MC], b_c[MR];
+#pragma unroll
+        for (int i = 0; i < MC; ++i) a_c[i] = ld_a(0, i);
+#pragma unroll
+        for (int j = 0; j < MR; ++j) b_c[j] = ld_b(0, j);
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            // the NEXT stage's operands: x loads at the first k-step, one dY DMA piece per k-step behind them, the x commit
+            // (into the other image, free since the last barrier) two k-steps before the stage ends
+            if (ks == 0) {
+#pragma unroll
+                for (int j = 0; j < XI; ++j) load_x(j);
+            }
+            if (ks < APW) dma_a(ks, img ^ 1);
+            if (ks == KS - 2) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (x loads and DMA pieces issued >= 4 k-steps ago)
+#pragma unroll
+                for (int j = 0; j < XI; ++j) commit_x(j, img ^ 1);
+            }
+            const int kn = ks + 1 < KS ? ks + 1 : KS - 1;             // (the last step re-reads its own fragments: unused)
+#pragma unroll
+            for (int i = 0; i < MC; ++i) a_n[i] = ld_a(kn, i);
+            if (want_bias && (ks % WR) == wr) {                        // (bf16-rounded dY, fp32 sum)
+#pragma unroll
+                for (int i = 0; i < MC; ++i)
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) bsum[i] += (float)a_c[i][e];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < MR; ++j) {
+#pragma unroll
+                for (int i = 0; i < MC; ++i)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_c[i], b_c[j], acc[i][j], 0, 0, 0);
+                b_c[j] = ld_b(kn, j);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int i = 0; i < MC; ++i) a_c[i] = a_n[i];
+        }
+        advance();
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");     // this wave's pieces / commits of the next stage have landed
+        __syncthreads();                                                 // ... everybody's; and this image is free again
+    }
+
+    if (want_bias) {                                        // uniform per workgroup; the images are dead (last barrier of the loop)
+        float *bred = reinterpret_cast<float *>(lds);
+#pragma unroll
+        for (int i = 0; i < MC; ++i) {
+            bsum[i] += __shfl_xor(bsum[i], 32, 64);
+            if (half == 0) bred[wave * (MC * 32) + 32 * i + l31] = bsum[i];
+        }
+        __syncthreads();
+        if (wr == 0) {
+#pragma unroll
+            for (int i = 0; i < MC; ++i) {
+                float t = 0.f;
+                for (int w = 0; w < WR; ++w) t += bred[(wm * WR + w) * (MC * 32) + 32 * i + l31];     // fixed order
+                bsum[i] = t;
+            }
+        }
+    }
+    const size_t wslab = (size_t)Cout * R;
+    float *out = slab + (size_t)s * wslab;
+#pragma unroll
+    for (int i = 0; i < MC; ++i)
+#pragma unroll
+        for (int j = 0; j < MR; ++j) {
+            const int r = r0 + wr0 + 32 * j + l31;
+            if (r < R) {
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    const int co = co0 + wm0 + 32 * i + acc_row(q, half);
+                    out[(size_t)co * R + r] = acc[i][j][q];
+                }
+            }
+        }
+    if (want_bias && wr == 0 && half == 0) {
+#pragma unroll
+        for (int i = 0; i < MC; ++i)
+            slab[(size_t)S * wslab + (size_t)s * Cout + co0 + wm0 + 32 * i + l31] = bsum[i];
+    }
+}
+
+}  // namespace tk
+
+// conv1d_direct.hip: dw[i] = sum_s slab[s][i] in fixed order
+int wgrad_reduce(const float *ws, float *dw, float *db, size_t wslab, int Cout, int S, hipStream_t st);
+
+struct TkPlan { int m_t, ntt, splits; size_t slab_floats; };
+
+static TkPlan tk_plan(int N, int Cin, int Cout, int Lo) {
+    TkPlan p{0, cdiv(Lo, tk::TT), 1, 0};
+    if (Cout % 64 != 0) return p;
+    p.m_t = Cout % 128 == 0 ? 128 : 64;
+    const int tiles = cdiv(Cin * tk::KK, tk::R_T) * (Cout / p.m_t);
+    int s = 256 / tiles;                                    // one eight-wave workgroup per CU
+    const int total = N * p.ntt;
+    if (s > total / 4) s = total / 4;                       // a slab is written and re-read per split: >= 4 stages each
+    if (s < 1) s = 1;
+    p.splits = s;
+    p.slab_floats = (size_t)s * ((size_t)Cout * Cin * tk::KK + Cout);
+    return p;
+}
+
+// 1 when the time-on-K kernel takes the layer (bit 0) — K = 15, pad = 7, C_out a multiple of 64
+bool wgrad_bf16_tk_supported(int Cin, int Cout, int K, int pad) {
+    (void)Cin;
+    return K == tk::KK && pad == tk::PAD && Cout % 64 == 0;
+}
+
+int wgrad_bf16_tk_dy_stride(int Lo) { return cdiv(Lo, tk::TT) * tk::TT; }
+
+size_t wgrad_bf16_tk_ws_floats(int N, int Cin, int Cout, int L, int K, int pad) {
+    return tk_plan(N, Cin, Cout, L + 2 * pad - K + 1).slab_floats + 16;
+}
+
+int wgrad_bf16_tk(const void *dy_bf16, int ldy, const void *x, int x_is_bf16, int ldx, float *dw, float *db,
+                  float *ws, int N, int Cin, int Cout, int L, int K, int pad, hipStream_t st) {
+    const int Lo = L + 2 * pad - K + 1;
+    const TkPlan p = tk_plan(N, Cin, Cout, Lo);
+    if (!p.m_t) return fail(ECG_EINVAL, "conv1d_bwd_weight_bias_bf16_ncl: C_out=%d is not a multiple of 64", Cout);
+    const int R = Cin * K;
+    const u16 *dy = static_cast<const u16 *>(dy_bf16);
+    dim3 grid((unsigned)(cdiv(R, tk::R_T) * (Cout / p.m_t) * p.splits)), block(512);
+#define ECG_TK(MT, WM, WR, XF) \
+    hipLaunchKernelGGL((tk::conv1d_wgrad_bf16_tk_kernel<MT, WM, WR, XF>), grid, block, 0, st, dy, x, ws, N, Cin, Cout, L, ldy, \
+                       ldx, p.ntt, p.splits)
+    if (p.m_t == 128) { if (x_is_bf16) ECG_TK(128, 2, 4, false); else ECG_TK(128, 2, 4, true); }
+    else { if (x_is_bf16) ECG_TK(64, 1, 8, false); else ECG_TK(64, 1, 8, true); }
+#undef ECG_TK
+    int rc = check_launch("conv1d_wgrad_bf16_tk_kernel");
+    if (rc) return rc;
+    return wgrad_reduce(ws, dw, db, (size_t)Cout * R, Cout, p.splits, st);
+}
+
+}  // namespace ecg
+
+using namespace ecg;
+
+ECG_API int ecg_conv1d_bf16_tk_supported(int C_in, int C_out, int K, int pad) {
+    return wgrad_bf16_tk_supported(C_in, C_out, K, pad) ? 1 : 0;
+}
+
+ECG_API int ecg_conv1d_bf16_tk_dy_stride(int Lo) { return Lo > 0 ? wgrad_bf16_tk_dy_stride(Lo) : 0; }
+
+ECG_API size_t ecg_conv1d_bwd_weight_bf16_ncl_ws_floats(int N, int C_in, int C_out, int L, int K, int pad) {
+    if (!wgrad_bf16_tk_supported(C_in, C_out, K, pad) || N <= 0 || L + 2 * pad - K + 1 <= 0) return 0;
+    return wgrad_bf16_tk_ws_floats(N, C_in, C_out, L, K, pad);
+}
+
+ECG_API int ecg_conv1d_bwd_weight_bias_bf16_ncl(const void *dy_bf16, int ldy, const void *x, int x_is_bf16, int ldx,
+                                                float *dw, float *db, float *ws, int N, int C_in, int C_out, int L,
+                                                int K, int pad, ecg_stream_t stream) {
+    ECG_REQUIRE(N > 0 && C_in > 0 && C_out > 0 && L >= 16, "conv1d_bwd_weight_bias_bf16_ncl: N=%d C_in=%d C_out=%d L=%d", N,
+                C_in, C_out, L);
+    ECG_REQUIRE(wgrad_bf16_tk_supported(C_in, C_out, K, pad),
+                "conv1d_bwd_weight_bias_bf16_ncl: needs K == 15, pad == 7, C_out %% 64 == 0");
+    ECG_REQUIRE(dy_bf16 && x && dw && ws, "conv1d_bwd_weight_bias_bf16_ncl: null pointer");
+    const int Lo = L + 2 * pad - K + 1;
+    ECG_REQUIRE(ldy % 128 == 0 && ldy >= wgrad_bf16_tk_dy_stride(Lo),
+                "conv1d_bwd_weight_bias_bf16_ncl: dY rows must be zero-filled to a stride of %d (got %d)",
+                wgrad_bf16_tk_dy_stride(Lo), ldy);
+    if (x_is_bf16)
+        ECG_REQUIRE(ldx % 8 == 0 && ldx >= L, "conv1d_bwd_weight_bias_bf16_ncl: bf16 x needs a row stride >= L that is a "
+                    "multiple of 8 (rows zero-filled past L); got %d", ldx);
+    else
+        ECG_REQUIRE(L % 8 == 0 && ldx % 4 == 0 && ldx >= L, "conv1d_bwd_weight_bias_bf16_ncl: fp32 x needs L %% 8 == 0 and "
+                    "a row stride that is a multiple of 4 (L=%d, ldx=%d)", L, ldx);
+    ECG_REQUIRE(((reinterpret_cast<uintptr_t>(dy_bf16) | reinterpret_cast<uintptr_t>(x)) & 15) == 0,
+                "conv1d_bwd_weight_bias_bf16_ncl: operands must be 16-byte aligned");
+    ECG_REQUIRE((long long)C_out * ldy * 2 < (1LL << 31) && (long long)N * C_in * ldx < (1LL << 31) &&
+                (long long)N * C_out * ldy < (1LL << 31), "conv1d_bwd_weight_bias_bf16_ncl: tensor too large for 32-bit offsets");
+    return wgrad_bf16_tk(dy_bf16, ldy, x, x_is_bf16, ldx, dw, db, ws, N, C_in, C_out, L, K, pad, as_stream(stream));
+}

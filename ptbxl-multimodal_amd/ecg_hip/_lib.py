@@ -56,7 +56,13 @@ SIGNATURES = {
     "ecg_bn_stats_relu_pool_fwd_yh": (_i, [_vp, _i, _ll, _vp, _vp, _vp, _f, _f, _vp, _i] + [_vp] * 7 + [_i] * 7 + [_vp]),
     "ecg_bn_relu_pool_bwd_n16_yh": (_i, [_vp, _i, _vp, _i, _i] + [_vp] * 5 +
                                     [_i, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
+    "ecg_bn_stats_relu_pool_fwd_h": (_i, [_vp, _i, _ll, _vp, _vp, _vp, _f, _f, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "ecg_bn_relu_pool_bwd_h": (_i, [_vp, _i, _vp, _i, _i] + [_vp] * 5 + [_i] + [_vp] * 3 + [_i] * 4 + [_vp]),
     "ecg_conv1d_bwd_data_bf16hh": (_i, [_vp, _i, _vp, _vp, _i] + [_i] * 6 + [_vp]),
+    "ecg_conv1d_bf16_tk_supported": (_i, [_i] * 4),
+    "ecg_conv1d_bf16_tk_dy_stride": (_i, [_i]),
+    "ecg_conv1d_bwd_weight_bf16_ncl_ws_floats": (_sz, [_i] * 6),
+    "ecg_conv1d_bwd_weight_bias_bf16_ncl": (_i, [_vp, _i, _vp, _i, _i, _vp, _vp, _vp] + [_i] * 6 + [_vp]),
     "ecg_conv1d_bwd_weight_bf16_packed_ws_floats": (_sz, [_i] * 6),
     "ecg_conv1d_bwd_weight_bias_bf16_packed": (_i, [_vp] * 5 + [_i] * 6 + [_vp]),
     "ecg_bn_stat_partials_count": (_i, [_i, _i, _i]),

@@ -482,20 +482,26 @@ class ConvBlockFn(torch.autograd.Function):
                 raise L.EcgHipError("ConvBlock: a bf16 activation arrived at a block that cannot consume it")
         Lo = Lin + 2 * pad - K + 1
         p_n16, PX, shift = None, 0, 0
-        if not gap and bf16 and need_grad and next_geom is not None and Lo >= 2:
+        # Round 4: when the NEXT block's weight gradient is the time-on-K kernel (csrc/conv1d_wgrad_bf16_tk.hip) every
+        # consumer of p reads plain bf16 rows: no n16 copy, and the statistics + pool pass is the row-streaming "h" kernel.
+        rows_next = bool(not gap and bf16 and _bf16_activation_storage and use_batch and need_grad and Lo >= 2
+                         and next_geom is not None and len(next_geom) >= 4 and next_geom[3]
+                         and _bf16_chain_ok(Co, next_geom[2], next_geom[0], next_geom[1], Lo // 2)
+                         and _query("ecg_conv1d_bf16_tk_supported", Co, next_geom[2], next_geom[0], next_geom[1]))
+        if not gap and bf16 and need_grad and next_geom is not None and Lo >= 2 and not rows_next:
             # mixed precision: p also as the next conv's weight-gradient operand (bf16, n16 layout)
             PX, shift = _query("ecg_conv1d_n16_positions", Lo // 2, next_geom[0], next_geom[1], 1), next_geom[1]
         # bf16 activation storage: only when both consumers of y are the kernels that read it (the fused
         # statistics + pool pass in its n16 / gap form now, the n16 BatchNorm backward later)
         ldyh = 0
-        if (bf16 and _bf16_activation_storage and use_batch and need_grad and Lo >= 2 and (gap or PX) and (sup & 4)
+        if (bf16 and _bf16_activation_storage and use_batch and need_grad and Lo >= 2 and (gap or PX or rows_next) and (sup & 4)
                 and _query("ecg_conv1d_n16_positions", Lin, K, pad, 0)):
             ldyh = (Lo + 7) & ~7
         # ... and p itself as bf16 [N][Co][ldp] (instead of fp32) when the next block is one that reads it: its forward
         # conv then reads half the bytes, and its input gradient comes back as bf16 of the same shape
         ldp = 0
-        if (ldyh and PX and len(next_geom) >= 4 and next_geom[3]
-                and _bf16_chain_ok(Co, next_geom[2], next_geom[0], next_geom[1], Lo // 2)):
+        if ldyh and (rows_next or (PX and len(next_geom) >= 4 and next_geom[3]
+                                   and _bf16_chain_ok(Co, next_geom[2], next_geom[0], next_geom[1], Lo // 2))):
             ldp = (Lo // 2 + 7) & ~7
         if x_h and not ldyh:
             # the producer wrote p as bf16 because THIS block looked able to read it (_bf16_chain_ok), but the bf16-y
@@ -529,7 +535,11 @@ class ConvBlockFn(torch.autograd.Function):
             if cnt is not None and cnt.dtype != torch.int64:
                 raise L.EcgHipError("num_batches_tracked must be int64")
             mean, invstd = _empty(x, Co), _empty(x, Co)
-            if ldyh:
+            if ldyh and rows_next:
+                _call("ecg_bn_stats_relu_pool_fwd_h", _f32(partials), P, N * Lo, _f32(rm), _f32(rv), L.ptr(cnt),
+                      _bn_momentum(momentum, nbt), float(eps), L.ptr(y), ldyh, _f32(gamma), _f32(beta), _f32(mean),
+                      _f32(invstd), L.ptr(p), ldp, N, Co, Lo, _st())
+            elif ldyh:
                 _call("ecg_bn_stats_relu_pool_fwd_yh", _f32(partials), P, N * Lo, _f32(rm), _f32(rv), L.ptr(cnt),
                       _bn_momentum(momentum, nbt), float(eps), L.ptr(y), ldyh, _f32(gamma), _f32(beta), _f32(mean),
                       _f32(invstd), _f32(p_f32), L.ptr(p_n16), L.ptr(p) if ldp else None, ldp, N, Co, Lo, PX, shift, mode,
@@ -574,6 +584,29 @@ class ConvBlockFn(torch.autograd.Function):
         ws = _empty(y, _query("ecg_bn_relu_pool_bwd_ws_floats", N, Co, Lo))
         nones = (None,) * 12
         PA = _query("ecg_conv1d_n16_positions", Lin, K, ctx.pad, 0) if ctx.bf16 else 0
+        rows = bool(PA and ctx.ldyh and Lo >= 2 and ctx.batch_stats
+                    and _query("ecg_conv1d_bf16_tk_supported", Ci, Co, K, ctx.pad)
+                    and (x_h or (Lin % 8 == 0 and not need_dx)))
+        if rows:
+            # Round 4: plain bf16 rows end to end.  BatchNorm backward (reduction + dx, 16 bytes per lane) writes dY ONCE, as
+            # bf16 [N][Co][ldt] with rows zero-filled to a multiple of 128; the time-on-K weight gradient and the input
+            # gradient both read it; x is the previous block's bf16 activation (or the fp32 network input)
+            ldt = _query("ecg_conv1d_bf16_tk_dy_stride", Lo)
+            dyh = torch.empty(N, Co, ldt, dtype=torch.bfloat16, device=y.device)
+            # dp: the fp32 gradient of the fused global average pool [N][Co], bf16 rows [N][Co][ldp], or fp32 rows [N][Co][Lo/2]
+            dp_kind, dp_ld = (1, 0) if ctx.gap else ((0, ctx.ldp) if ctx.ldp else (2, Lo // 2))
+            _call("ecg_bn_relu_pool_bwd_h", L.ptr(y), ctx.ldyh, L.ptr(dp), dp_kind, dp_ld, _f32(gamma), _f32(beta), _f32(mean),
+                  _f32(invstd), L.ptr(dyh), ldt, _f32(dgamma), _f32(dbeta), _f32(ws), N, Co, Lo, 1, _st())
+            dw, db = _grad_out(kw, x, Co, Ci, K), _grad_out(kb, x, Co)
+            ws2 = _empty(y, max(1, _query("ecg_conv1d_bwd_weight_bf16_ncl_ws_floats", N, Ci, Co, Lin, K, ctx.pad)))
+            _call("ecg_conv1d_bwd_weight_bias_bf16_ncl", L.ptr(dyh), ldt, L.ptr(x), 1 if x_h else 0, x.shape[2], _f32(dw),
+                  _f32(db), _f32(ws2), N, Ci, Co, Lin, K, ctx.pad, _st())
+            dx = None
+            if need_dx:         # (rows implies x_h here: the previous block's dp comes back as bf16 of x's shape)
+                dx = torch.empty_like(x)
+                _call("ecg_conv1d_bwd_data_bf16hh", L.ptr(dyh), ldt, L.ptr(ctx.w_bwd), L.ptr(dx), x.shape[2], N, Ci, Co,
+                      Lin, K, ctx.pad, _st())
+            return (dx, dw, db, dgamma, dbeta) + nones
         if PA and Lo >= 2 and (_query("ecg_conv1d_bf16_supported", Ci, Co, K, ctx.pad) & 4):
             # mixed precision: the BatchNorm backward writes dY straight in the weight gradient's operand layout
             # (bf16 n16) — and in fp32 only when an input gradient follows; x is already there from the forward

@@ -785,6 +785,49 @@ def test_bf16_weight_grad_is_exact_on_bf16_rounded_operands(hip, oracle, case, p
                N, Ci, 48, Lin, 15, 7, L.stream())
 
 
+@pytest.mark.parametrize("case", [(3, 32, 64, 300, True), (2, 64, 128, 131, True), (5, 128, 256, 125, True),
+                                  (2, 12, 64, 256, False), (1, 128, 128, 640, True), (17, 64, 64, 16, True),
+                                  (2, 16, 128, 1000, False)])
+def test_bf16_tk_weight_grad_is_exact_on_bf16_rounded_operands(hip, oracle, case):
+    """The time-on-K weight gradient (csrc/conv1d_wgrad_bf16_tk.hip) reads the bf16 tensors the other two convs read —
+    dY [N][C_out][ldy] with rows zero-filled to 128, x [N][C_in][ldx] bf16 with rows zero-filled past L (or the fp32 network
+    input, rounded while it is staged) — and must equal the oracle on the bf16-rounded operands up to fp32 accumulation
+    order: pins the plain / shifted x images (odd taps read the copy shifted by one element), the zero padding on both
+    sides of a row, ragged last tiles, the swizzled dY image and the split / reduce.  The row pads are filled with NaN-free
+    garbage where the contract allows garbage (x rows past ldx do not exist; dY pads must be zero)."""
+    from ecg_hip import _lib as L
+    N, Ci, Co, Lin, xbf = case
+    rng = np.random.default_rng(sum(case[:4]))
+    x = rng.standard_normal((N, Ci, Lin)).astype(np.float32)
+    dy = rng.standard_normal((N, Co, Lin)).astype(np.float32)
+    assert L.query("ecg_conv1d_bf16_tk_supported", Ci, Co, 15, 7) == 1
+    ldy = L.query("ecg_conv1d_bf16_tk_dy_stride", Lin)
+    assert ldy % 128 == 0 and 0 <= ldy - Lin < 128
+    dyh = torch.zeros(N, Co, ldy, dtype=torch.bfloat16, device="cuda")
+    dyh[:, :, :Lin] = dev(dy).to(torch.bfloat16)
+    if xbf:
+        ldx = (Lin + 7) & ~7
+        xd = torch.zeros(N, Ci, ldx, dtype=torch.bfloat16, device="cuda")
+        xd[:, :, :Lin] = dev(x).to(torch.bfloat16)
+    else:
+        ldx, xd = Lin, dev(x)
+    dw, db = torch.full((Co, Ci, 15), float("nan"), device="cuda"), torch.full((Co,), float("nan"), device="cuda")
+    ws = torch.empty(L.query("ecg_conv1d_bwd_weight_bf16_ncl_ws_floats", N, Ci, Co, Lin, 15, 7), device="cuda")
+    L.call("ecg_conv1d_bwd_weight_bias_bf16_ncl", L.ptr(dyh), ldy, L.ptr(xd), 1 if xbf else 0, ldx, L.f32(dw), L.f32(db),
+           L.f32(ws), N, Ci, Co, Lin, 15, 7, L.stream())
+    rdw, rdb = oracle.conv1d_bwd_weight(_bf16_round(dy), _bf16_round(x), 15, 7)
+    scale = np.sqrt(N * Lin)
+    np.testing.assert_allclose(host(dw), rdw, atol=3e-6 * float(np.abs(rdw).max()) + 2e-5)
+    np.testing.assert_allclose(host(db), rdb, atol=3e-6 * float(np.abs(rdb).max()) + 2e-6 * scale + 2e-5)
+    dw2, db2 = torch.empty_like(dw), torch.empty_like(db)          # fixed summation order: identical bits on a second call
+    L.call("ecg_conv1d_bwd_weight_bias_bf16_ncl", L.ptr(dyh), ldy, L.ptr(xd), 1 if xbf else 0, ldx, L.f32(dw2), L.f32(db2),
+           L.f32(ws), N, Ci, Co, Lin, 15, 7, L.stream())
+    assert torch.equal(dw, dw2) and torch.equal(db, db2)
+    with pytest.raises(L.EcgHipError, match="zero-filled to a stride"):
+        L.call("ecg_conv1d_bwd_weight_bias_bf16_ncl", L.ptr(dyh), ldy - 8, L.ptr(xd), 1 if xbf else 0, ldx, L.f32(dw),
+               L.f32(db), L.f32(ws), N, Ci, Co, Lin, 15, 7, L.stream())
+
+
 def _unpack_n16(buf, G, C, P):
     """bf16 [G][C][P][16] (a flat torch.bfloat16 tensor) -> float32 numpy [16*G][C][P]."""
     a = buf.view(G, C, P, 16).to(torch.float32).cpu().numpy()

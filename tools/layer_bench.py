@@ -119,6 +119,18 @@ def main():
                  f32(dy), ldy, f32(x), f32(dw), f32(db), f32(ws), N, ci, co, Lc, K, pad, st())
 
         ops = [("fwd", fwd)] + ([("dgrad", dgrad)] if need_dx else []) + [("wgrad", wgrad)]
+        if H and q("ecg_conv1d_bf16_tk_supported", ci, co, K, pad):
+            # the time-on-K weight gradient on the bf16 NCL tensors themselves (no n16 operands)
+            ldt = q("ecg_conv1d_bf16_tk_dy_stride", Lo)
+            dyt = torch.zeros(N, co, ldt, dtype=torch.bfloat16, device=dev)
+            dyt[:, :, :Lo] = dy[:, :, :Lo].to(torch.bfloat16)
+            wst = torch.empty(max(1, q("ecg_conv1d_bwd_weight_bf16_ncl_ws_floats", N, ci, co, Lc, K, pad)), device=dev)
+            dw_tk, db_tk = torch.empty_like(w), torch.empty_like(bias)
+
+            def wgrad_tk():
+                call("ecg_conv1d_bwd_weight_bias_bf16_ncl", L.ptr(dyt), ldt, L.ptr(xh) if xin_h else f32(x), 1 if xin_h else 0,
+                     ldh if xin_h else Lc, f32(dw_tk), f32(db_tk), f32(wst), N, ci, co, Lc, K, pad, st())
+            ops.append(("wgrad_tk", wgrad_tk))
         for name, fn in ops:
             for _ in range(3):
                 fn()
@@ -134,6 +146,12 @@ def main():
             total += med
             rows.append({"block": b, "op": name, "us": round(med, 1), "min_us": round(ts[0], 1),
                          "tflops": round(flops / med / 1e6, 1), "frac": round(flops / med / 1e6 / peak, 3)})
+        if a.check and H and any(n == "wgrad_tk" for n, _ in ops):
+            xr = (xh[:, :, :Lc] if xin_h else x.to(torch.bfloat16)).float().requires_grad_(True)
+            wr = w.clone().requires_grad_(True)
+            torch.nn.functional.conv1d(xr, wr, bias, padding=pad).backward(dyt[:, :, :Lo].float())
+            e = (dw_tk - wr.grad).abs().max().item() / max(1.0, wr.grad.abs().max().item())
+            rows.append({"block": b, "check_tk_dw_rel": float(f"{e:.2e}"), "ok": e < 1e-4})
         if a.check and not H:
             xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
             br = bias.clone().requires_grad_(True)
