@@ -48,11 +48,12 @@ CONV_ENTRY = {"ecg_conv1d_fwd": (FWD, "f32"), "ecg_conv1d_fwd_bf16": (FWD, "bf16
               "ecg_conv1d_bwd_data_bf16": (DGRAD, "bf16"), "ecg_conv1d_bwd_data_bf16h": (DGRAD, "bf16"),
               "ecg_conv1d_bwd_weight_bias": (WGRAD, "f32"), "ecg_conv1d_bwd_weight_bias_ld": (WGRAD, "f32"),
               "ecg_conv1d_bwd_weight_bias_bf16": (WGRAD, "bf16"), "ecg_conv1d_bwd_weight_bias_bf16_packed": (WGRAD, "bf16"),
-              "ecg_conv1d_fwd_bf16_yh": (FWD, "bf16"), "ecg_conv1d_bwd_data_bf16hh": (DGRAD, "bf16")}
+              "ecg_conv1d_fwd_bf16_yh": (FWD, "bf16"), "ecg_conv1d_bwd_data_bf16hh": (DGRAD, "bf16"),
+              "ecg_conv1d_bwd_weight_bias_bf16_ncl": (WGRAD, "bf16")}
 # bytes per element of the two activation operands an entry point streams (reduction-side tensor, result-side tensor);
 # everything not listed reads and writes fp32.  ecg_conv1d_fwd_bf16_yh reads fp32 only for the network input (x_bf16 = 0).
 IO_BYTES = {"ecg_conv1d_bwd_data_bf16h": (4, 2), "ecg_conv1d_bwd_weight_bias_bf16_packed": (2, 2),
-            "ecg_conv1d_bwd_data_bf16hh": (2, 2)}
+            "ecg_conv1d_bwd_data_bf16hh": (2, 2), "ecg_conv1d_bwd_weight_bias_bf16_ncl": (2, 2)}
 
 
 # ------------------------------------------------------------------------------------------------
@@ -240,6 +241,8 @@ def layer_table(timings):
         bx, by = IO_BYTES.get(name, (4, 4))
         if name == "ecg_conv1d_fwd_bf16_yh":
             bx, by = (2 if sig[0] else 4), 2
+        if name == "ecg_conv1d_bwd_weight_bias_bf16_ncl":        # ints: ldy, x_is_bf16, ldx, N, ... (block 0 reads the fp32 input)
+            bx, by = (2 if sig[1] else 4), 2
         abytes = float(N) * (bx * Lc * ci + by * Lo * co) + 4.0 * co * ci * K
         avg = sum(ms) / len(ms)
         peak = PEAK_BF16_TFLOPS if dt == "bf16" else PEAK_F32_TFLOPS

@@ -229,7 +229,7 @@ int ecg_conv1d_bwd_data_bf16hh(const void *dy_bf16, int ldy, const void *wb_bwd,
  * csrc/conv1d_wgrad_bf16_tk.hip): dy_bf16 [N][C_out][ldy] with ldy = ecg_conv1d_bf16_tk_dy_stride(Lo) (rows zero-filled to a
  * multiple of 128), x either bf16 [N][C_in][ldx] (x_is_bf16 != 0: ldx % 8 == 0, rows zero-filled past L — the previous
  * block's pooled activation as ecg_bn_stats_relu_pool_fwd_yh writes it) or the fp32 network input [N][C_in][ldx] (L % 8 == 0),
- * rounded to bf16 while it is staged.  K == 15, pad == 7, C_out % 64 == 0 (ecg_conv1d_bf16_tk_supported).  Exact on the
+ * rounded to bf16 while it is staged.  K == 15, pad == 7, C_out % 32 == 0 (ecg_conv1d_bf16_tk_supported).  Exact on the
  * bf16-rounded operands up to fp32 accumulation order.  Same reference call site as ecg_conv1d_bwd_weight_bias. */
 int ecg_conv1d_bf16_tk_supported(int C_in, int C_out, int K, int pad);
 int ecg_conv1d_bf16_tk_dy_stride(int Lo);

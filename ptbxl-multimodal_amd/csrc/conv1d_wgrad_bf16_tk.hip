@@ -46,7 +46,6 @@ constexpr int XRS = 320;         // x row stride in bytes: 80 dwords = 16 banks 
 constexpr int XCOPY_PAD[4] = {0, 32, 128, 160};   // the four shifted copies start 0 / 8 / 32 / 40 banks into a bank row: the
                                                   // (channel, copy) windows of 8 banks that the 32 lanes of a half-wave
                                                   // read then overlap only between channel c and c + 2
-constexpr int R_T = 512;
 
 __device__ __forceinline__ int acc_row(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }
 
@@ -55,22 +54,27 @@ __device__ __forceinline__ unsigned pack2(float lo, float hi) {
     return (unsigned)a | ((unsigned)b << 16);
 }
 
-template <int M_T, int WM, int WR, bool XF32>
+// WK > 1: the WK waves of a wave-tile group take every WK-th k-step of a stage and are summed through LDS at the end (the
+// 32-channel first layer: one 32 x 192 tile, MFMA work for two waves — the kernel is a stream of dY rows there).
+template <int M_T, int R_T, int WM, int WR, int WK, bool XF32>
 __global__ __launch_bounds__(512) void conv1d_wgrad_bf16_tk_kernel(
     const u16 *__restrict__ dy, const void *__restrict__ xin, float *__restrict__ slab, int N, int Cin, int Cout,
     int L, int ldy, int ldx, int ntt, int S) {
-    static_assert(WM * WR == 8, "8 waves per workgroup");
+    static_assert(WM * WR * WK == 8, "8 waves per workgroup");
     constexpr int MC = M_T / WM / 32, MR = R_T / WR / 32;
-    static_assert(MC == 2 && (MR == 4 || MR == 2), "wave tile 64 x 128 or 64 x 64");
+    static_assert((MC == 2 && (MR == 4 || MR == 2)) || (MC == 1 && MR == 3), "wave tile 64 x 128, 64 x 64 or 32 x 96");
+    constexpr int KPW = KS / WK;                            // k-steps per wave and stage
+    static_assert(KS % WK == 0 && KPW % (WK > 1 ? WR : 1) == 0, "k-steps split evenly; bias rows rotate over the WR waves");
     constexpr int NCI = (R_T + KK - 2) / KK + 1;
     constexpr int AIMG = M_T * 16 * 16;                    // dY image: M_T rows of 16 slots of 16 bytes
-    constexpr int ADMA = AIMG / 1024, APW = ADMA / 8;      // 1 KB DMA pieces, per wave
+    constexpr int ADMA = AIMG / 1024, APW = (ADMA + 7) / 8; // 1 KB DMA pieces, per wave
     static_assert(ADMA % 8 == 0, "dY image must split evenly over the eight waves");
-    constexpr int XCSZ = NCI * XRS;                        // bytes of one copy (a multiple of 256: 64 banks)
+    constexpr int XCSZ = NCI * XRS;                        // bytes of one copy
     constexpr int XIMG = ((4 * XCSZ + XCOPY_PAD[3] + 255) / 256) * 256;
     constexpr int XITEMS = NCI * XC, XI = (XITEMS + 511) / 512;
+    constexpr int ACCF = MC * MR * 16 * 64;                // floats of one wave's accumulators (WK > 1 exchange)
     static_assert(2 * (AIMG + XIMG) <= 160 * 1024, "LDS");
-    static_assert(APW <= KS, "one DMA piece per k-step");
+    static_assert(WK == 1 || WM * WR * ACCF * 4 + 8 * MC * 32 * 4 <= 2 * (AIMG + XIMG), "accumulator exchange must fit the dead images");
 
     __shared__ __attribute__((aligned(1024))) unsigned char lds[2 * (AIMG + XIMG)];
 
@@ -87,7 +91,7 @@ __global__ __launch_bounds__(512) void conv1d_wgrad_bf16_tk_kernel(
     }
     const int tile_r = tile % RT, tile_cs = tile / RT;
     const int r0 = tile_r * R_T, co0 = (tile_cs % CT) * M_T, s = tile_cs / CT;
-    const int wr = wave % WR, wm = wave / WR;
+    const int wk = wave % WK, wr = (wave / WK) % WR, wm = wave / (WK * WR);
     const int wm0 = wm * (M_T / WM), wr0 = wr * (R_T / WR);
     const int ci_base = r0 / KK;
     const int total = N * ntt;
@@ -105,7 +109,7 @@ __global__ __launch_bounds__(512) void conv1d_wgrad_bf16_tk_kernel(
         // first element of the fragment at k-step 0, half 0: e = tap + 1 -> copy e % 4 at byte 2 (e - e % 4): a multiple of 8
         const int e = tap + 1, sft = e & 3;
         boffl[j] = (ci - ci_base) * XRS + sft * XCSZ + (sft == 0 ? XCOPY_PAD[0] : sft == 1 ? XCOPY_PAD[1] : sft == 2 ? XCOPY_PAD[2] : XCOPY_PAD[3])
-                   + 2 * (e - sft) + 16 * half;
+                   + 2 * (e - sft) + 16 * half + 32 * wk;   // (this wave's first k-step of a stage is wk)
     }
 
     f32x16 acc[MC][MR];
@@ -124,7 +128,7 @@ __global__ __launch_bounds__(512) void conv1d_wgrad_bf16_tk_kernel(
     int aoff[APW];
 #pragma unroll
     for (int j = 0; j < APW; ++j) {
-        const int sl = (j * 8 + wave) * 64 + lane;
+        const int sl = min((j * 8 + wave) * 64 + lane, M_T * 16 - 1);
         const int co = sl >> 4, ls = sl & 15;
         const int gs = ls ^ (co & 15);                      // LDS slot ls of row co holds the row's 16-byte chunk gs
         aoff[j] = (co * ldy + 8 * gs) * 2;                  // bytes
@@ -150,21 +154,26 @@ __global__ __launch_bounds__(512) void conv1d_wgrad_bf16_tk_kernel(
     u32x4 xE[XI];
     unsigned xN[XI][2];                                     // the first two dwords of the next chunk (shifted copies)
 
-    // stage coordinates of the stage that is STAGED next (dY DMA + x loads)
+    // Two cursors over the stages of this workgroup: `d*` = the stage whose dY tile is DMA'd next (one stage ahead of the
+    // MFMAs), `x*` = the stage whose x tile is LOADED next (two ahead: a tile is loaded during stage s, committed to LDS at
+    // the start of stage s + 1 and multiplied in stage s + 2 — a whole stage for the loads to land, whatever its length)
     int dn = st_begin / ntt, dt0 = (st_begin - dn * ntt) * TT;
-    auto advance = [&]() __attribute__((always_inline)) {
-        dt0 += TT;
-        if (dt0 >= ntt * TT) { dt0 = 0; ++dn; }
-        if (dn >= N) { dn = N - 1; dt0 = (ntt - 1) * TT; }  // past the end: restage a valid tile nobody reads
+    int xn = dn, xt0 = dt0;
+    auto advance = [&](int &n_, int &t_) __attribute__((always_inline)) {
+        t_ += TT;
+        if (t_ >= ntt * TT) { t_ = 0; ++n_; }
+        if (n_ >= N) { n_ = N - 1; t_ = (ntt - 1) * TT; }   // past the end: restage a valid tile nobody reads
     };
     auto dma_a = [&](int j, int aimg) __attribute__((always_inline)) {
-        const u16 *abase = dy + ((size_t)dn * Cout + co0) * ldy + dt0;                    // uniform
-        glds(abase, (unsigned)aoff[j], (unsigned)(aimg * AIMG + (j * 8 + wave) * 1024));
+        if (ADMA % 8 == 0 || j * 8 + wave < ADMA) {
+            const u16 *abase = dy + ((size_t)dn * Cout + co0) * ldy + dt0;                    // uniform
+            glds(abase, (unsigned)aoff[j], (unsigned)(aimg * AIMG + (j * 8 + wave) * 1024));
+        }
     };
     auto load_x = [&](int j) __attribute__((always_inline)) {
-        const int g0 = dt0 + xe[j];
+        const int g0 = xt0 + xe[j];
         if (XF32) {
-            const float *xr = static_cast<const float *>(xin) + (size_t)dn * Cin * ldx + xrow[j];
+            const float *xr = static_cast<const float *>(xin) + (size_t)xn * Cin * ldx + xrow[j];
             // (host: L % 8 == 0, so a chunk is inside the row or outside it as a whole; the clamp only keeps the load in bounds)
             const int gc = min(max(g0, 0), L - 8);
             const f32x4t a = *reinterpret_cast<const f32x4t *>(xr + gc), b = *reinterpret_cast<const f32x4t *>(xr + gc + 4);
@@ -180,7 +189,7 @@ __global__ __launch_bounds__(512) void conv1d_wgrad_bf16_tk_kernel(
             xN[j][0] = okn ? pack2(nx[0], nx[1]) : 0u;
             xN[j][1] = okn ? pack2(nx[2], nx[3]) : 0u;
         } else {
-            const u16 *xr = static_cast<const u16 *>(xin) + (size_t)dn * Cin * ldx + xrow[j];
+            const u16 *xr = static_cast<const u16 *>(xin) + (size_t)xn * Cin * ldx + xrow[j];
             const int gc = min(max(g0, 0), ldx - 8);
             xE[j] = *reinterpret_cast<const u32x4 *>(xr + gc);
             typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
@@ -217,7 +226,11 @@ __global__ __launch_bounds__(512) void conv1d_wgrad_bf16_tk_kernel(
         for (int j = 0; j < XI; ++j) load_x(j);
 #pragma unroll
         for (int j = 0; j < XI; ++j) commit_x(j, 0);
-        advance();
+        advance(dn, dt0);
+        advance(xn, xt0);
+#pragma unroll
+        for (int j = 0; j < XI; ++j) load_x(j);             // the second stage's tile: committed at the start of the first
+        advance(xn, xt0);
     }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __syncthreads();
@@ -227,10 +240,10 @@ __global__ __launch_bounds__(512) void conv1d_wgrad_bf16_tk_kernel(
         const int abase_l = img * AIMG, xbase_l = 2 * AIMG + img * XIMG;
         // (per-lane terms are made opaque where they are used: left alone, hipcc precomputes one address register per
         // (k-step, fragment) and spills — conv1d_wgrad_bf16.hip)
-        auto ld_a = [&](int ks, int i) __attribute__((always_inline)) {
+        auto ld_a = [&](int i_, int i) __attribute__((always_inline)) {      // k-step wk + WK * i_
             int sw = asw;
             asm volatile("" : "+v"(sw));
-            return *reinterpret_cast<const bf16x8 *>(&lds[abase_l + aoffl + (((2 * ks + half) ^ sw) << 4) + i * (32 * 256)]);
+            return *reinterpret_cast<const bf16x8 *>(&lds[abase_l + aoffl + (((2 * WK * i_ + 2 * wk + half) ^ sw) << 4) + i * (32 * 256)]);
         };
         // two base registers per fragment, 8 bytes apart and opaque to the compiler: with one base it fuses the two 8-byte
         // reads into ds_read2_b64, which runs at a quarter of the ds_read_b64 rate (MI355X_MICROARCH.md, LDS table)
@@ -241,10 +254,10 @@ __global__ __launch_bounds__(512) void conv1d_wgrad_bf16_tk_kernel(
             bh[j] = bl[j] + 8;
             asm volatile("" : "+v"(bl[j]), "+v"(bh[j]));
         }
-        auto ld_b = [&](int ks, int j) __attribute__((always_inline)) {
+        auto ld_b = [&](int i_, int j) __attribute__((always_inline)) {
             typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-            const u32x2 lo = *reinterpret_cast<const u32x2 *>(&lds[bl[j] + 32 * ks]);          // 8-byte aligned
-            const u32x2 hi = *reinterpret_cast<const u32x2 *>(&lds[bh[j] + 32 * ks]);
+            const u32x2 lo = *reinterpret_cast<const u32x2 *>(&lds[bl[j] + 32 * WK * i_]);          // 8-byte aligned
+            const u32x2 hi = *reinterpret_cast<const u32x2 *>(&lds[bh[j] + 32 * WK * i_]);
             u32x4 v;
             v[0] = lo[0]; v[1] = lo[1]; v[2] = hi[0]; v[3] = hi[1];
             return __builtin_bit_cast(bf16x8, v);
@@ -254,24 +267,23 @@ __global__ __launch_bounds__(512) void conv1d_wgrad_bf16_tk_kernel(
         for (int i = 0; i < MC; ++i) a_c[i] = ld_a(0, i);
 #pragma unroll
         for (int j = 0; j < MR; ++j) b_c[j] = ld_b(0, j);
+        // staging, all at the top of the stage: the x tile loaded during the LAST stage goes into the other image (free since
+        // the last barrier; its loads have had a whole stage), then the dY DMA pieces of the next stage, then the loads of
+        // the x tile after it — in THIS order: vmcnt retires in order, so the wait at the end of the stage can let exactly
+        // the x loads (the youngest) stay in flight while the DMA pieces must have landed
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-            // the NEXT stage's operands: x loads at the first k-step, one dY DMA piece per k-step behind them, the x commit
-            // (into the other image, free since the last barrier) two k-steps before the stage ends
-            if (ks == 0) {
+        for (int j = 0; j < XI; ++j) commit_x(j, img ^ 1);
 #pragma unroll
-                for (int j = 0; j < XI; ++j) load_x(j);
-            }
-            if (ks < APW) dma_a(ks, img ^ 1);
-            if (ks == KS - 2) {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (x loads and DMA pieces issued >= 4 k-steps ago)
+        for (int j = 0; j < APW; ++j) dma_a(j, img ^ 1);
 #pragma unroll
-                for (int j = 0; j < XI; ++j) commit_x(j, img ^ 1);
-            }
-            const int kn = ks + 1 < KS ? ks + 1 : KS - 1;             // (the last step re-reads its own fragments: unused)
+        for (int j = 0; j < XI; ++j) load_x(j);
+#pragma unroll
+        for (int i_ = 0; i_ < KPW; ++i_) {
+            const int kn = i_ + 1 < KPW ? i_ + 1 : KPW - 1;           // (the last step re-reads its own fragments: unused)
 #pragma unroll
             for (int i = 0; i < MC; ++i) a_n[i] = ld_a(kn, i);
-            if (want_bias && (ks % WR) == wr) {                        // (bf16-rounded dY, fp32 sum)
+            if (want_bias && (i_ % WR) == wr) {                        // (bf16-rounded dY, fp32 sum; every k-step exactly once)
 #pragma unroll
                 for (int i = 0; i < MC; ++i)
 #pragma unroll
@@ -289,27 +301,56 @@ __global__ __launch_bounds__(512) void conv1d_wgrad_bf16_tk_kernel(
 #pragma unroll
             for (int i = 0; i < MC; ++i) a_c[i] = a_n[i];
         }
-        advance();
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");     // this wave's pieces / commits of the next stage have landed
-        __syncthreads();                                                 // ... everybody's; and this image is free again
+        advance(dn, dt0);
+        advance(xn, xt0);
+        // this wave's x commits (LDS) and DMA pieces must have landed before the barrier publishes image img ^ 1; the x loads
+        // issued BEHIND the pieces (at least one vector-memory instruction per item) may stay in flight
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt vmcnt(%0)" :: "n"(XI) : "memory");
+        __syncthreads();                                                 // image img is free again; image img ^ 1 is complete
     }
 
+    // ---- combine: bias partials of the waves that hold the same channel rows; accumulators of the WK k-split waves ----
     if (want_bias) {                                        // uniform per workgroup; the images are dead (last barrier of the loop)
-        float *bred = reinterpret_cast<float *>(lds);
+        float *bred = reinterpret_cast<float *>(lds) + (WK > 1 ? WM * WR * ACCF : 0);
 #pragma unroll
         for (int i = 0; i < MC; ++i) {
             bsum[i] += __shfl_xor(bsum[i], 32, 64);
             if (half == 0) bred[wave * (MC * 32) + 32 * i + l31] = bsum[i];
         }
         __syncthreads();
-        if (wr == 0) {
+        if (wr == 0 && wk == 0) {
 #pragma unroll
             for (int i = 0; i < MC; ++i) {
                 float t = 0.f;
-                for (int w = 0; w < WR; ++w) t += bred[(wm * WR + w) * (MC * 32) + 32 * i + l31];     // fixed order
+                for (int w = 0; w < WR * WK; ++w) t += bred[(wm * WR * WK + w) * (MC * 32) + 32 * i + l31];     // fixed order
                 bsum[i] = t;
             }
         }
+    }
+    if (WK > 1) {
+        float *ex = reinterpret_cast<float *>(lds) + (wr + WR * wm) * ACCF;
+        for (int w = 1; w < WK; ++w) {
+            __syncthreads();
+            if (wk == w) {
+#pragma unroll
+                for (int i = 0; i < MC; ++i)
+#pragma unroll
+                    for (int j = 0; j < MR; ++j)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) ex[((i * MR + j) * 16 + r) * 64 + lane] = acc[i][j][r];
+            }
+            __syncthreads();
+            if (wk == 0) {
+#pragma unroll
+                for (int i = 0; i < MC; ++i)
+#pragma unroll
+                    for (int j = 0; j < MR; ++j)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) acc[i][j][r] += ex[((i * MR + j) * 16 + r) * 64 + lane];
+            }
+        }
+        if (wk != 0) return;
     }
     const size_t wslab = (size_t)Cout * R;
     float *out = slab + (size_t)s * wslab;
@@ -338,14 +379,15 @@ __global__ __launch_bounds__(512) void conv1d_wgrad_bf16_tk_kernel(
 // conv1d_direct.hip: dw[i] = sum_s slab[s][i] in fixed order
 int wgrad_reduce(const float *ws, float *dw, float *db, size_t wslab, int Cout, int S, hipStream_t st);
 
-struct TkPlan { int m_t, ntt, splits; size_t slab_floats; };
+struct TkPlan { int m_t, r_t, ntt, splits; size_t slab_floats; };
 
 static TkPlan tk_plan(int N, int Cin, int Cout, int Lo) {
-    TkPlan p{0, cdiv(Lo, tk::TT), 1, 0};
-    if (Cout % 64 != 0) return p;
-    p.m_t = Cout % 128 == 0 ? 128 : 64;
-    const int tiles = cdiv(Cin * tk::KK, tk::R_T) * (Cout / p.m_t);
-    int s = 256 / tiles;                                    // one eight-wave workgroup per CU
+    TkPlan p{0, 512, cdiv(Lo, tk::TT), 1, 0};
+    if (Cout % 32 != 0) return p;
+    p.m_t = Cout % 128 == 0 ? 128 : Cout % 64 == 0 ? 64 : 32;
+    if (p.m_t == 32) p.r_t = 192;                           // the 32-channel first layer: 32 x 192 tiles, k-steps split over waves
+    const int tiles = cdiv(Cin * tk::KK, p.r_t) * (Cout / p.m_t);
+    int s = (p.m_t == 32 ? 512 : 256) / tiles;             // one eight-wave workgroup per CU (two of the small ones)
     const int total = N * p.ntt;
     if (s > total / 4) s = total / 4;                       // a slab is written and re-read per split: >= 4 stages each
     if (s < 1) s = 1;
@@ -354,10 +396,10 @@ static TkPlan tk_plan(int N, int Cin, int Cout, int Lo) {
     return p;
 }
 
-// 1 when the time-on-K kernel takes the layer (bit 0) — K = 15, pad = 7, C_out a multiple of 64
+// K = 15, pad = 7, C_out a multiple of 32
 bool wgrad_bf16_tk_supported(int Cin, int Cout, int K, int pad) {
     (void)Cin;
-    return K == tk::KK && pad == tk::PAD && Cout % 64 == 0;
+    return K == tk::KK && pad == tk::PAD && Cout % 32 == 0;
 }
 
 int wgrad_bf16_tk_dy_stride(int Lo) { return cdiv(Lo, tk::TT) * tk::TT; }
@@ -370,15 +412,16 @@ int wgrad_bf16_tk(const void *dy_bf16, int ldy, const void *x, int x_is_bf16, in
                   float *ws, int N, int Cin, int Cout, int L, int K, int pad, hipStream_t st) {
     const int Lo = L + 2 * pad - K + 1;
     const TkPlan p = tk_plan(N, Cin, Cout, Lo);
-    if (!p.m_t) return fail(ECG_EINVAL, "conv1d_bwd_weight_bias_bf16_ncl: C_out=%d is not a multiple of 64", Cout);
+    if (!p.m_t) return fail(ECG_EINVAL, "conv1d_bwd_weight_bias_bf16_ncl: C_out=%d is not a multiple of 32", Cout);
     const int R = Cin * K;
     const u16 *dy = static_cast<const u16 *>(dy_bf16);
-    dim3 grid((unsigned)(cdiv(R, tk::R_T) * (Cout / p.m_t) * p.splits)), block(512);
-#define ECG_TK(MT, WM, WR, XF) \
-    hipLaunchKernelGGL((tk::conv1d_wgrad_bf16_tk_kernel<MT, WM, WR, XF>), grid, block, 0, st, dy, x, ws, N, Cin, Cout, L, ldy, \
-                       ldx, p.ntt, p.splits)
-    if (p.m_t == 128) { if (x_is_bf16) ECG_TK(128, 2, 4, false); else ECG_TK(128, 2, 4, true); }
-    else { if (x_is_bf16) ECG_TK(64, 1, 8, false); else ECG_TK(64, 1, 8, true); }
+    dim3 grid((unsigned)(cdiv(R, p.r_t) * (Cout / p.m_t) * p.splits)), block(512);
+#define ECG_TK(MT, RT, WM, WR, WK, XF) \
+    hipLaunchKernelGGL((tk::conv1d_wgrad_bf16_tk_kernel<MT, RT, WM, WR, WK, XF>), grid, block, 0, st, dy, x, ws, N, Cin, Cout, L, \
+                       ldy, ldx, p.ntt, p.splits)
+    if (p.m_t == 128) { if (x_is_bf16) ECG_TK(128, 512, 2, 4, 1, false); else ECG_TK(128, 512, 2, 4, 1, true); }
+    else if (p.m_t == 64) { if (x_is_bf16) ECG_TK(64, 512, 1, 8, 1, false); else ECG_TK(64, 512, 1, 8, 1, true); }
+    else { if (x_is_bf16) ECG_TK(32, 192, 1, 2, 4, false); else ECG_TK(32, 192, 1, 2, 4, true); }
 #undef ECG_TK
     int rc = check_launch("conv1d_wgrad_bf16_tk_kernel");
     if (rc) return rc;
@@ -406,7 +449,7 @@ ECG_API int ecg_conv1d_bwd_weight_bias_bf16_ncl(const void *dy_bf16, int ldy, co
     ECG_REQUIRE(N > 0 && C_in > 0 && C_out > 0 && L >= 16, "conv1d_bwd_weight_bias_bf16_ncl: N=%d C_in=%d C_out=%d L=%d", N,
                 C_in, C_out, L);
     ECG_REQUIRE(wgrad_bf16_tk_supported(C_in, C_out, K, pad),
-                "conv1d_bwd_weight_bias_bf16_ncl: needs K == 15, pad == 7, C_out %% 64 == 0");
+                "conv1d_bwd_weight_bias_bf16_ncl: needs K == 15, pad == 7, C_out %% 32 == 0");
     ECG_REQUIRE(dy_bf16 && x && dw && ws, "conv1d_bwd_weight_bias_bf16_ncl: null pointer");
     const int Lo = L + 2 * pad - K + 1;
     ECG_REQUIRE(ldy % 128 == 0 && ldy >= wgrad_bf16_tk_dy_stride(Lo),

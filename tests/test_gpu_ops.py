@@ -787,7 +787,8 @@ def test_bf16_weight_grad_is_exact_on_bf16_rounded_operands(hip, oracle, case, p
 
 @pytest.mark.parametrize("case", [(3, 32, 64, 300, True), (2, 64, 128, 131, True), (5, 128, 256, 125, True),
                                   (2, 12, 64, 256, False), (1, 128, 128, 640, True), (17, 64, 64, 16, True),
-                                  (2, 16, 128, 1000, False)])
+                                  (2, 16, 128, 1000, False), (3, 12, 32, 1000, False), (2, 12, 32, 136, False),
+                                  (5, 20, 32, 77, True), (1, 12, 96, 264, False)])
 def test_bf16_tk_weight_grad_is_exact_on_bf16_rounded_operands(hip, oracle, case):
     """The time-on-K weight gradient (csrc/conv1d_wgrad_bf16_tk.hip) reads the bf16 tensors the other two convs read —
     dY [N][C_out][ldy] with rows zero-filled to 128, x [N][C_in][ldx] bf16 with rows zero-filled past L (or the fp32 network
