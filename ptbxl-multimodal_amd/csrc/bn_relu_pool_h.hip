@@ -86,6 +86,7 @@ __device__ __forceinline__ bool pool_route_h(float y0, float y1, float mu, float
 // forward: grid = (C, S2); a workgroup owns channel c and the samples of split s2 and walks (row, chunk of 8 pooled
 // outputs) flat, U chunks in flight per thread: 32 bytes of y in, 16 bytes of p out per chunk
 // ---------------------------------------------------------------------------------------
+template <int U>
 __global__ __launch_bounds__(kBlockH) void bn_relu_pool_fwd_h_kernel(
     const u16h *__restrict__ y, const float *__restrict__ gamma, const float *__restrict__ beta, u16h *__restrict__ p,
     int N, int C, int Lp, int ldy, int ldp, int S2, BnFinH fin) {
@@ -95,7 +96,6 @@ __global__ __launch_bounds__(kBlockH) void bn_relu_pool_fwd_h_kernel(
     const float sc = is * gamma[c], be = beta[c];
     const int n0 = (int)((long long)N * s2 / S2), n1 = (int)((long long)N * (s2 + 1) / S2);
     const int CH = ldp >> 3, total = (n1 - n0) * CH;
-    constexpr int U = 4;
     for (int base = tl; base < total; base += U * kBlockH) {
         u32x4h lo[U], hi[U];
         size_t out[U];
@@ -143,7 +143,7 @@ __global__ __launch_bounds__(kBlockH) void bn_relu_pool_fwd_h_kernel(
 // ---------------------------------------------------------------------------------------
 // DK: 0 = dp bf16 [N][C][ldp]; 1 = fp32 dg [N][C] of the fused global average pool (dp = dg * bcast everywhere);
 //     2 = dp fp32 [N][C][ldp] (a consumer that hands back an fp32 gradient: frozen statistics downstream, unfused leaves)
-template <int DK>
+template <int DK, int U>
 __global__ __launch_bounds__(kBlockH) void bn_bwd_reduce_h_kernel(
     const u16h *__restrict__ y, const void *__restrict__ g, const float *__restrict__ gamma,
     const float *__restrict__ beta, const float *__restrict__ mean, const float *__restrict__ invstd,
@@ -154,7 +154,6 @@ __global__ __launch_bounds__(kBlockH) void bn_bwd_reduce_h_kernel(
     const float mu = mean[c], is = invstd[c], sc = is * gamma[c], be = beta[c];
     const int Lp = L >> 1, CH = (Lp + 3) >> 2, total = (n1 - n0) * CH;     // chunks that hold at least one pooling pair
     float a = 0.f, q = 0.f;
-    constexpr int U = 4;
     for (int base = tl; base < total; base += U * kBlockH) {
         u32x4h yv[U];
         float d[U][4];
@@ -208,7 +207,7 @@ __global__ __launch_bounds__(kBlockH) void bn_bwd_reduce_h_kernel(
 // S reduction partials (double, fixed order) is folded in; workgroup (c, 0) also stores dgamma / dbeta.
 // thread <-> chunk of 8 outputs: 16 bytes of y + 8 of dp in, 16 out
 // ---------------------------------------------------------------------------------------
-template <int DK>
+template <int DK, int U>
 __global__ __launch_bounds__(kBlockH) void bn_bwd_dx_h_kernel(
     const u16h *__restrict__ y, const void *__restrict__ g, const float *__restrict__ gamma,
     const float *__restrict__ beta, const float *__restrict__ mean, const float *__restrict__ invstd,
@@ -243,7 +242,6 @@ __global__ __launch_bounds__(kBlockH) void bn_bwd_dx_h_kernel(
     const int n0 = (int)((long long)N * s2 / S2), n1 = (int)((long long)N * (s2 + 1) / S2);
     const int Lp = L >> 1, CH = ldy >> 3, total = (n1 - n0) * CH;
     const int lastq = (L - 1) >> 3;                          // last chunk that holds a sample of the row
-    constexpr int U = 4;
     for (int base = tl; base < total; base += U * kBlockH) {
         u32x4h yv[U];
         float d[U][4];
@@ -304,6 +302,22 @@ __global__ __launch_bounds__(kBlockH) void bn_bwd_dx_h_kernel(
 
 using namespace ecg;
 
+// Chunks in flight per thread.  A workgroup walks its `items` chunks in trips of U x 256; with one round of workgroups running
+// in lock-step a half-empty last trip is idle bandwidth (12x5000, 2048 workgroups: 1252-2560 chunks per workgroup — U = 4
+// left 17-39 % of the slots of the last trip empty).  Take the U in 3..6 that wastes the fewest slots (ties: the larger).
+static int pick_u(long long items) {
+    int best = 4;
+    long long best_slots = -1;
+    for (int u = 3; u <= 6; ++u) {
+        const long long trips = (items + 256LL * u - 1) / (256LL * u), slots = trips * u;
+        if (best_slots < 0 || slots <= best_slots) { best = u; best_slots = slots; }
+    }
+    return best;
+}
+#define ECG_PICK_U(U_, ...) \
+    do { switch (U_) { case 3: { constexpr int UU = 3; __VA_ARGS__; } break; case 5: { constexpr int UU = 5; __VA_ARGS__; } break; \
+                       case 6: { constexpr int UU = 6; __VA_ARGS__; } break; default: { constexpr int UU = 4; __VA_ARGS__; } } } while (0)
+
 static int splits_h(int N, int C) {
     int s = cdiv(2048, C);
     if (s > N) s = N;
@@ -328,8 +342,10 @@ ECG_API int ecg_bn_stats_relu_pool_fwd_h(const float *stat_partials, int P, long
                    momentum, eps};
     int S2 = cdiv(kStreamBlocksH, C);
     if (S2 > N) S2 = N;
-    hipLaunchKernelGGL(bn_relu_pool_fwd_h_kernel, dim3(C, S2), dim3(kBlockH), 0, as_stream(stream),
-                       static_cast<const u16h *>(y_bf16), gamma, beta, static_cast<u16h *>(p_bf16), N, C, L / 2, ldy, ldp, S2, f);
+    const int u = pick_u((long long)cdiv(N, S2) * (ldp / 8));
+    ECG_PICK_U(u, hipLaunchKernelGGL(bn_relu_pool_fwd_h_kernel<UU>, dim3(C, S2), dim3(kBlockH), 0, as_stream(stream),
+                                     static_cast<const u16h *>(y_bf16), gamma, beta, static_cast<u16h *>(p_bf16), N, C, L / 2,
+                                     ldy, ldp, S2, f));
     return check_launch("bn_relu_pool_fwd_h_kernel");
 }
 
@@ -351,17 +367,19 @@ ECG_API int ecg_bn_relu_pool_bwd_h(const void *y_bf16, int ldyy, const void *dp,
     const int S = splits_h(N, C);
     const float bcast = dp_kind == 1 ? 1.0f / (float)(L / 2) : 0.f;
     const u16h *y = static_cast<const u16h *>(y_bf16);
-#define ECG_RED(DK) hipLaunchKernelGGL(bn_bwd_reduce_h_kernel<DK>, dim3(C, S), dim3(kBlockH), 0, st, y, dp, gamma, beta, mean, invstd, \
-                                       ws, N, C, L, S, bcast, ldyy, ldp)
+    const int ur = pick_u((long long)cdiv(N, S) * ((L / 2 + 3) / 4));
+#define ECG_RED(DK) ECG_PICK_U(ur, hipLaunchKernelGGL((bn_bwd_reduce_h_kernel<DK, UU>), dim3(C, S), dim3(kBlockH), 0, st, y, dp, gamma, \
+                                                      beta, mean, invstd, ws, N, C, L, S, bcast, ldyy, ldp))
     if (dp_kind == 1) ECG_RED(1); else if (dp_kind == 2) ECG_RED(2); else ECG_RED(0);
 #undef ECG_RED
     int rc = check_launch("bn_bwd_reduce_h_kernel");
     if (rc) return rc;
     int S2 = cdiv(kStreamBlocksH, C);
     if (S2 > N) S2 = N;
-#define ECG_DX(DK) hipLaunchKernelGGL(bn_bwd_dx_h_kernel<DK>, dim3(C, S2), dim3(kBlockH), 0, st, y, dp, gamma, beta, mean, invstd, ws, \
-                                      S, (double)N * L, dgamma, dbeta, static_cast<u16h *>(dy_bf16), ldy, N, C, L, S2, bcast, train, \
-                                      ldyy, ldp)
+    const int ud = pick_u((long long)cdiv(N, S2) * (ldy / 8));
+#define ECG_DX(DK) ECG_PICK_U(ud, hipLaunchKernelGGL((bn_bwd_dx_h_kernel<DK, UU>), dim3(C, S2), dim3(kBlockH), 0, st, y, dp, gamma, beta, \
+                                                     mean, invstd, ws, S, (double)N * L, dgamma, dbeta, static_cast<u16h *>(dy_bf16), \
+                                                     ldy, N, C, L, S2, bcast, train, ldyy, ldp))
     if (dp_kind == 1) ECG_DX(1); else if (dp_kind == 2) ECG_DX(2); else ECG_DX(0);
 #undef ECG_DX
     return check_launch("bn_bwd_dx_h_kernel");
