@@ -894,6 +894,93 @@ def test_bn_relu_pool_n16_producers_match_the_plain_passes(hip, oracle, shape):
         assert np.array_equal(_unpack_n16(dyb, G, C, PA), want)
 
 
+@pytest.mark.parametrize("shape", [(19, 32, 300), (5, 64, 257), (18, 128, 125), (3, 256, 78), (33, 32, 16), (256, 64, 250)])
+@pytest.mark.parametrize("gap", [False, True])
+def test_bf16_row_passes_equal_the_n16_producers(hip, shape, gap):
+    """Round 4: the BatchNorm + ReLU + pool passes on bf16 ROWS only (csrc/bn_relu_pool_h.hip: 16 bytes per lane, no n16
+    copies — the producers of the time-on-K weight gradient).  Forward: bit-identical to ecg_bn_stats_relu_pool_fwd_yh's
+    bf16 output (pooled values, zero fill to the row stride, mean / invstd, running statistics, counter).  Backward: the
+    per-element formulas are the n16 producers'; the reduction partials associate differently, so dY agrees to one bf16
+    rounding of k1 / k2-level differences, the zero fill up to the 128-multiple stride is exact, dgamma / dbeta agree to
+    fp32 summation order — for bf16 dp rows, fp32 dp rows and the fp32 gradient of the fused global average pool."""
+    from ecg_hip import _lib as L
+    N, C, Lo = shape
+    Lp, G = Lo // 2, (N + 15) // 16
+    rng = np.random.default_rng(sum(shape) + gap)
+    ldy, ldp = (Lo + 7) & ~7, (Lp + 7) & ~7
+    yh = torch.full((N, C, ldy), float("nan"), dtype=torch.bfloat16, device="cuda")          # row padding must be ignored
+    yh[:, :, :Lo] = dev((rng.standard_normal((N, C, Lo)) * 1.5 + 0.3).astype(np.float32)).to(torch.bfloat16)
+    y32 = yh[:, :, :Lo].float().contiguous()
+    gamma, beta = dev((rng.random(C) + 0.5).astype(np.float32)), dev(rng.standard_normal(C).astype(np.float32) * 0.3)
+    P = L.query("ecg_bn_stat_partials_count", N, C, Lo)
+    part = torch.empty(C * P * 2, device="cuda")
+    L.call("ecg_bn_stat_partials", L.f32(y32), L.f32(part), N, C, Lo, L.stream())
+    PX = L.query("ecg_conv1d_n16_positions", Lp, 15, 7, 1)
+
+    def fwd(rows):
+        rm, rv = torch.zeros(C, device="cuda"), torch.ones(C, device="cuda")
+        nbt = torch.zeros((), dtype=torch.int64, device="cuda")
+        mean, invstd = torch.empty(C, device="cuda"), torch.empty(C, device="cuda")
+        ph = torch.full((N, C, ldp), float("nan"), dtype=torch.bfloat16, device="cuda")
+        head = [L.f32(part), P, N * Lo, L.f32(rm), L.f32(rv), L.ptr(nbt), 0.1, 1e-5, L.ptr(yh), ldy, L.f32(gamma), L.f32(beta),
+                L.f32(mean), L.f32(invstd)]
+        if rows:
+            L.call("ecg_bn_stats_relu_pool_fwd_h", *head, L.ptr(ph), ldp, N, C, Lo, L.stream())
+        else:
+            pb = torch.empty(G * C * PX * 16, dtype=torch.bfloat16, device="cuda")
+            L.call("ecg_bn_stats_relu_pool_fwd_yh", *head, None, L.ptr(pb), L.ptr(ph), ldp, N, C, Lo, PX, 7, 2, L.stream())
+        return ph, mean, invstd, rm, rv, nbt
+
+    if not gap:
+        for a, c in zip(fwd(False), fwd(True)):
+            assert torch.equal(a, c)
+    mean, invstd = fwd(True)[1:3]
+    PA = L.query("ecg_conv1d_n16_positions", Lo, 15, 7, 0)
+    ldt = L.query("ecg_conv1d_bf16_tk_dy_stride", Lo)
+    ws = torch.empty(L.query("ecg_bn_relu_pool_bwd_ws_floats", N, C, Lo), device="cuda")
+    dp = dev(rng.standard_normal((N, C) if gap else (N, C, Lp)).astype(np.float32))
+    dph = None
+    if not gap:
+        dph = torch.full((N, C, ldp), float("nan"), dtype=torch.bfloat16, device="cuda")
+        dph[:, :, :Lp] = dp.to(torch.bfloat16)
+
+    def n16(dp_t, dp_bf16, ld):
+        dg, db = torch.empty(C, device="cuda"), torch.empty(C, device="cuda")
+        dyb = torch.empty(G * C * PA * 16, dtype=torch.bfloat16, device="cuda")
+        dyh = torch.full((N, C, PA), 7.0, dtype=torch.bfloat16, device="cuda")
+        L.call("ecg_bn_relu_pool_bwd_n16_yh", L.ptr(yh), ldy, L.ptr(dp_t), dp_bf16, ld, L.f32(gamma), L.f32(beta), L.f32(mean),
+               L.f32(invstd), None, Lo, L.ptr(dyb), PA, L.f32(dg), L.f32(db), L.f32(ws), N, C, Lo, 1, 1 if gap else 0,
+               L.ptr(dyh), L.stream())
+        return dyh, dg, db
+
+    def rows(dp_t, kind, ld):
+        dg, db = torch.empty(C, device="cuda"), torch.empty(C, device="cuda")
+        dyh = torch.full((N, C, ldt), 7.0, dtype=torch.bfloat16, device="cuda")
+        L.call("ecg_bn_relu_pool_bwd_h", L.ptr(yh), ldy, L.ptr(dp_t), kind, ld, L.f32(gamma), L.f32(beta), L.f32(mean),
+               L.f32(invstd), L.ptr(dyh), ldt, L.f32(dg), L.f32(db), L.f32(ws), N, C, Lo, 1, L.stream())
+        return dyh, dg, db
+
+    cases = [((dp, 0, 0), (dp, 1, 0))] if gap else [((dph, 1, ldp), (dph, 0, ldp)), ((dp, 0, 0), (dp, 2, Lp))]
+    scale = float(np.sqrt(N * Lo))
+    for a_args, r_args in cases:
+        (dy_a, dg_a, db_a), (dy_r, dg_r, db_r) = n16(*a_args), rows(*r_args)
+        assert float(dy_r[:, :, Lo:].float().abs().sum()) == 0.0                     # zero fill to the 128-multiple stride
+        a, r = dy_a[:, :, :Lo].float(), dy_r[:, :, :Lo].float()
+        assert not bool(torch.isnan(r).any())
+        # identical per-element arithmetic; k1 / k2 come from differently associated fp32 partials: the bf16 results differ by
+        # at most one rounding step on a few elements
+        assert float((a - r).abs().max()) <= 2.0 ** -7 * float(a.abs().max()) + 1e-6
+        assert float((a != r).float().mean()) < 0.05
+        np.testing.assert_allclose(host(dg_r), host(dg_a), rtol=2e-4, atol=2e-5 * scale)
+        np.testing.assert_allclose(host(db_r), host(db_a), rtol=2e-4, atol=2e-5 * scale)
+        dy_r2 = rows(*r_args)[0]
+        assert torch.equal(dy_r, dy_r2)                                                   # fixed summation order
+    with pytest.raises(L.EcgHipError, match="multiples of 8"):
+        L.call("ecg_bn_relu_pool_bwd_h", L.ptr(yh), ldy, L.ptr(dp), 1 if gap else 2, Lp, L.f32(gamma), L.f32(beta), L.f32(mean),
+               L.f32(invstd), L.ptr(torch.empty(N, C, ldt, dtype=torch.bfloat16, device="cuda")), ldt + 4, None, None, L.f32(ws),
+               N, C, Lo, 1, L.stream())
+
+
 # (N, Ci, Co, L): every forward tile plan (32x256, 64x256, 64x128, 128x256), resident and streamed weights, odd rows
 # (row stride > L, last dword half padding), ragged sample groups
 @pytest.mark.parametrize("case", [(19, 12, 32, 300), (5, 32, 64, 257), (18, 64, 128, 125), (3, 128, 256, 77),
