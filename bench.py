@@ -201,6 +201,12 @@ def csrc_digest():
 _PMC = None
 
 
+def leg_tag(model, labels, dtype, length):
+    """Name of a measured configuration in profiles/pmc_traffic.json: the same entry-point signature occurs in several legs
+    (ECGCNN(5) and ECGMultimodal share every conv shape), so the counter traffic is keyed by leg AND entry."""
+    return f"{'mm' if model == 'multimodal' else 'cnn' + str(labels)}_{dtype}_{length}"
+
+
 def pmc_traffic(key):
     """(HBM bytes per launch, provenance) from the committed rocprofv3 --pmc passes (profiles/pmc_traffic.json:
     2*FETCH_SIZE + WRITE_SIZE per the guide's gfx950 correction), or (None, reason) when the file is missing, has
@@ -213,7 +219,7 @@ def pmc_traffic(key):
             _PMC = {}
     meta = _PMC.get("_meta", {})
     if key not in _PMC.get("entries", {}):
-        return None, "not collected"
+        return None, "not collected"          # (key = "<leg>|<entry>[signature]")
     if meta.get("csrc_digest") != csrc_digest():
         return None, f"stale: collected for csrc {meta.get('csrc_digest')} at {meta.get('commit')}"
     return _PMC["entries"][key], f"profiles/pmc_traffic.json ({meta.get('source')}, commit {meta.get('commit')})"
@@ -222,7 +228,7 @@ def pmc_traffic(key):
 OTHER_ROWS = []          # the non-conv entry points of the last layer_table() call (BatchNorm / pool passes, tail, loss, optimizer, packs)
 
 
-def layer_table(timings):
+def layer_table(timings, leg=""):
     """Instrumented pass -> one row per (conv entry point, layer): live µs per call (all launches of the entry
     point, e.g. weight-gradient MFMA kernel + slab reduce), TFLOP/s, fraction of the MFMA peak for its operand
     type, algorithmic bytes and, when a matching counter collection is committed, HBM traffic / algorithmic."""
@@ -248,7 +254,7 @@ def layer_table(timings):
         peak = PEAK_BF16_TFLOPS if dt == "bf16" else PEAK_F32_TFLOPS
         ach = flops / (avg * 1e-3) / 1e12
         key = f"{name}{list(sig)}"
-        tr, prov = pmc_traffic(key)
+        tr, prov = pmc_traffic(f"{leg}|{key}")
         prov_short = (f"pmc@{_PMC.get('_meta', {}).get('commit')}" if tr else prov.split(":")[0])
         rows.append({"entry": key, "op": op, "operands": dt, "c_in": ci, "c_out": co, "L": Lc, "calls": len(ms),
                      "avg_us": round(avg * 1e3, 2), "tflops": round(ach, 2), "peak": peak, "frac": round(ach / peak, 4),
@@ -681,7 +687,7 @@ def main():
             run_eager(wrapped, ListLoader(batch, n_instr), opt, dev)
         if exch:
             opt.reduce_gradients = inner
-        rows, other_ms = layer_table(kt.result)
+        rows, other_ms = layer_table(kt.result, leg_tag(spec["model"], labels, "bf16" if bf16 else "f32", T))
         # did the loop API replay a captured step (ecg_hip.graph.LoopStepper: FlatAdamW, one rank, no hooks)?
         loop_replays = (not graph) and any(st.graphs for st in getattr(opt, "_ecg_loop_steppers", {}).values())
         conv_ms = sum(r["avg_us"] * r["calls"] for r in rows) / 1e3

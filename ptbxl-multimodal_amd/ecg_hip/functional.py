@@ -241,6 +241,18 @@ class conv_precision:
 _bf16_activation_storage = True
 
 
+_bf16_row_operands = True      # round 4: the weight gradient reads plain bf16 rows (time on the MFMA's K axis), no n16 copies
+
+
+def set_bf16_row_operands(on):
+    """A/B switch for the mixed-precision train step: True (default) = BatchNorm passes on bf16 rows only + the time-on-K
+    weight gradient (csrc/conv1d_wgrad_bf16_tk.hip, bn_relu_pool_h.hip); False = the rounds-2/3 form, in which the BatchNorm
+    passes also write every p and dY in the "n16" layout of the sample-on-K weight gradient.  Returns the previous setting."""
+    global _bf16_row_operands
+    prev, _bf16_row_operands = _bf16_row_operands, bool(on)
+    return prev
+
+
 def set_bf16_activation_storage(on):
     """bf16 mode only: store the conv output y of a training ConvBlock as bf16 (what torch.autocast does) — the
     BatchNorm passes are HBM-bound and y is their largest operand.  On by default; off keeps y in fp32."""
@@ -484,7 +496,7 @@ class ConvBlockFn(torch.autograd.Function):
         p_n16, PX, shift = None, 0, 0
         # Round 4: when the NEXT block's weight gradient is the time-on-K kernel (csrc/conv1d_wgrad_bf16_tk.hip) every
         # consumer of p reads plain bf16 rows: no n16 copy, and the statistics + pool pass is the row-streaming "h" kernel.
-        rows_next = bool(not gap and bf16 and _bf16_activation_storage and use_batch and need_grad and Lo >= 2
+        rows_next = bool(_bf16_row_operands and not gap and bf16 and _bf16_activation_storage and use_batch and need_grad and Lo >= 2
                          and next_geom is not None and len(next_geom) >= 4 and next_geom[3]
                          and _bf16_chain_ok(Co, next_geom[2], next_geom[0], next_geom[1], Lo // 2)
                          and _query("ecg_conv1d_bf16_tk_supported", Co, next_geom[2], next_geom[0], next_geom[1]))
@@ -584,7 +596,7 @@ class ConvBlockFn(torch.autograd.Function):
         ws = _empty(y, _query("ecg_bn_relu_pool_bwd_ws_floats", N, Co, Lo))
         nones = (None,) * 12
         PA = _query("ecg_conv1d_n16_positions", Lin, K, ctx.pad, 0) if ctx.bf16 else 0
-        rows = bool(PA and ctx.ldyh and Lo >= 2 and ctx.batch_stats
+        rows = bool(_bf16_row_operands and PA and ctx.ldyh and Lo >= 2 and ctx.batch_stats
                     and _query("ecg_conv1d_bf16_tk_supported", Ci, Co, K, ctx.pad)
                     and (x_h or (Lin % 8 == 0 and not need_dx)))
         if rows:

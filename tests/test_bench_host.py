@@ -13,7 +13,9 @@ import bench  # noqa: E402
 
 def test_layer_table_prices_entry_points_against_their_roofs(monkeypatch):
     monkeypatch.setattr(bench, "_PMC", {"_meta": {"csrc_digest": bench.csrc_digest(), "commit": "abc", "source": "x"},
-                                        "entries": {"ecg_conv1d_fwd[256, 128, 256, 125, 15, 7]": 65_000_000}})
+                                        "entries": {"cnn5_f32_1000|ecg_conv1d_fwd[256, 128, 256, 125, 15, 7]": 65_000_000,
+                                                    # the same signature in another leg: must not be picked up
+                                                    "mm_f32_1000|ecg_conv1d_fwd[256, 128, 256, 125, 15, 7]": 1}})
     timings = {
         ("ecg_conv1d_fwd", (256, 128, 256, 125, 15, 7)): [0.25, 0.25],                       # ms per call
         ("ecg_conv1d_bwd_weight_bias_ld", (128, 256, 128, 256, 125, 15, 7)): [0.27],         # heaviest: dominant
@@ -21,7 +23,8 @@ def test_layer_table_prices_entry_points_against_their_roofs(monkeypatch):
         ("ecg_conv1d_bwd_data_bf16hh", (640, 632, 256, 128, 256, 625, 15, 7)): [0.16],
         ("ecg_bn_stats_relu_pool_fwd", (1024, 256000, 256, 32, 1000, 0, 0, 0)): [0.014],
     }
-    rows, other_ms = bench.layer_table(timings)
+    rows, other_ms = bench.layer_table(timings, bench.leg_tag("cnn", 5, "f32", 1000))
+    assert bench.leg_tag("multimodal", 5, "f32", 1000) == "mm_f32_1000" and bench.leg_tag("cnn", 1, "bf16", 5000) == "cnn1_bf16_5000"
     assert abs(other_ms - 0.014) < 1e-12 and len(rows) == 4
     by = {r["entry"].split("[")[0]: r for r in rows}
     f = by["ecg_conv1d_fwd"]
@@ -46,7 +49,7 @@ def test_layer_table_prices_entry_points_against_their_roofs(monkeypatch):
 
 
 def test_counter_traffic_is_refused_for_other_kernel_sources(monkeypatch):
-    key = "ecg_conv1d_fwd[256, 12, 32, 1000, 15, 7]"
+    key = "cnn5_f32_1000|ecg_conv1d_fwd[256, 12, 32, 1000, 15, 7]"
     monkeypatch.setattr(bench, "_PMC", {"_meta": {"csrc_digest": "0" * 16, "commit": "old", "source": "s"}, "entries": {key: 1}})
     tr, why = bench.pmc_traffic(key)
     assert tr is None and why.startswith("stale: collected for csrc 0000000000000000 at old")
@@ -61,7 +64,8 @@ def test_committed_counter_traffic_matches_the_committed_kernels():
     assert meta["_meta"]["csrc_digest"] == bench.csrc_digest()
     keys = set(meta["entries"])
     for ci, co, L in ((12, 32, 1000), (32, 64, 500), (64, 128, 250), (128, 256, 125)):
-        assert f"ecg_conv1d_fwd[256, {ci}, {co}, {L}, 15, 7]" in keys
+        assert f"cnn5_f32_1000|ecg_conv1d_fwd[256, {ci}, {co}, {L}, 15, 7]" in keys
+        assert f"mm_f32_1000|ecg_conv1d_fwd[256, {ci}, {co}, {L}, 15, 7]" in keys        # keyed by leg: no collisions
 
 
 def test_percentiles_and_flop_counts():

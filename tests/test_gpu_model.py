@@ -597,6 +597,43 @@ def test_bf16_mixed_precision_train_step_config5(B, T, act_bf16):
         assert rel <= rel_bar and omc <= omc_bar, f"{k}: rel {rel} (bar {rel_bar}), 1-cos {omc} (bar {omc_bar}); all: {measured}"
 
 
+@pytest.mark.parametrize("B,T", [(19, 1000), (8, 5000)])
+def test_bf16_row_operands_train_step_matches_the_n16_form(B, T):
+    """Round 4: the mixed-precision step with the BatchNorm passes on bf16 rows and the time-on-K weight gradient against the
+    rounds-2/3 form (n16 operands) on the same batch: the forward is the same arithmetic (logits and loss bit-identical);
+    every gradient agrees to the accumulation order of the two weight-gradient kernels and the reduction partials of the two
+    BatchNorm backward forms."""
+    from ecg_hip import functional as hipF
+    from src.models.ecg_cnn import ECGCNN
+    from src.utils.seed import set_seed
+    x, y = R.synthetic_batch(B, T, 1)
+    res = []
+    for rows in (True, False):
+        set_seed(42)
+        model = ECGCNN(num_labels=1).to(DEV).train()
+        prev = hipF.set_bf16_row_operands(rows)
+        try:
+            with hipF.conv_precision("bf16"):
+                logits = model(x.to(DEV))
+                loss = hipF.binary_cross_entropy_with_logits(logits, y.to(DEV))
+                loss.backward()
+        finally:
+            hipF.set_bf16_row_operands(prev)
+        res.append((logits.detach().clone(), loss.item(), {k: p.grad.clone() for k, p in model.named_parameters()},
+                    {k: b.clone() for k, b in model.named_buffers()}))
+    (l0, s0, g0, b0), (l1, s1, g1, b1) = res
+    assert torch.equal(l0, l1) and s0 == s1
+    for k in b0:
+        assert torch.equal(b0[k], b1[k]), k                   # running statistics and counters: same forward
+    for k in g0:
+        if ".net.0.bias" in k:
+            continue                                           # (true gradient 0 under train-mode BatchNorm: rounding noise)
+        a, c = g0[k].double().reshape(-1), g1[k].double().reshape(-1)
+        rel = float((a - c).norm() / (c.norm() + 1e-30))
+        # bf16 dY differs by one rounding step on a few elements (k1 / k2 from differently associated partials): 1e-3 level
+        assert rel < 5e-3, (k, rel)
+
+
 @pytest.mark.parametrize("frozen", [None, 1, 2, 3])
 def test_bf16_chain_with_a_frozen_batchnorm_or_an_input_gradient(frozen):
     """bf16 activation storage hands bf16 tensors from block to block only when the consumer is a training block that

@@ -111,10 +111,12 @@ def main():
              "# a derived clock above 2.4 GHz means GUI_ACTIVE spans more than the (short) dispatch: the row is flagged and priced",
              "# with duration x the stamped 2.1 GHz instead; mfma_busy_floor = busy / (1024 * duration * 2.4 GHz) always holds"]
     entries = {}
-    variants = [("", "ECGCNN(5), 12x1000, fp32 (the headline)"), ("_mm", "ECGMultimodal, 12x1000, fp32"),
-                ("_c5f32", "ECGCNN(1), 12x5000, fp32 (BASELINE configs[4])"),
-                ("_c5bf16", "ECGCNN(1), 12x5000, bf16 mode (BASELINE configs[4])")]
-    for suffix, title in variants:
+    # (suffix of the counter-pass directories, title, leg tag = bench.leg_tag(model, labels, dtype, length): the traffic table
+    # is keyed by leg AND entry point — ECGCNN(5) and ECGMultimodal share every conv signature)
+    variants = [("", "ECGCNN(5), 12x1000, fp32 (the headline)", "cnn5_f32_1000"), ("_mm", "ECGMultimodal, 12x1000, fp32", "mm_f32_1000"),
+                ("_c5f32", "ECGCNN(1), 12x5000, fp32 (BASELINE configs[4])", "cnn1_f32_5000"),
+                ("_c5bf16", "ECGCNN(1), 12x5000, bf16 mode (BASELINE configs[4])", "cnn1_bf16_5000")]
+    for suffix, title, leg in variants:
       if not os.path.exists(os.path.join(OUT, f"pmc_fetch_{TAG}{suffix}.order.json")):
           continue
       lines.append(f"## {title}")
@@ -125,7 +127,7 @@ def main():
           f = mean([s.get("FETCH_SIZE", 0.0) for s in fetch[key]])
           w = mean([s.get("WRITE_SIZE", 0.0) for s in write[key]]) if key in write else float("nan")
           hb = (2 * f + w) * 1024
-          entries[key] = int(hb)
+          entries[f"{leg}|{key}"] = int(hb)
           us = mean([s["_ns"] for s in fetch[key]]) / 1e3
           extra = ""
           if key in sq and "mfma" in "".join(k for k in [key]) or ("conv1d" in key and key in sq):
