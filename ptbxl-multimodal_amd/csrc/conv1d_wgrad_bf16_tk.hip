@@ -379,6 +379,9 @@ __global__ __launch_bounds__(512) void conv1d_wgrad_bf16_tk_kernel(
 // conv1d_direct.hip: dw[i] = sum_s slab[s][i] in fixed order
 int wgrad_reduce(const float *ws, float *dw, float *db, size_t wslab, int Cout, int S, hipStream_t st);
 
+#ifndef ECG_TK_SLOTS32
+#define ECG_TK_SLOTS32 512       // workgroups of the 32-channel tile plan (compile-time A/B knob: make VARIANT=.. EXTRA=-DECG_TK_SLOTS32=256)
+#endif
 struct TkPlan { int m_t, r_t, ntt, splits; size_t slab_floats; };
 
 static TkPlan tk_plan(int N, int Cin, int Cout, int Lo) {
@@ -387,7 +390,7 @@ static TkPlan tk_plan(int N, int Cin, int Cout, int Lo) {
     p.m_t = Cout % 128 == 0 ? 128 : Cout % 64 == 0 ? 64 : 32;
     if (p.m_t == 32) p.r_t = 192;                           // the 32-channel first layer: 32 x 192 tiles, k-steps split over waves
     const int tiles = cdiv(Cin * tk::KK, p.r_t) * (Cout / p.m_t);
-    int s = (p.m_t == 32 ? 512 : 256) / tiles;             // one eight-wave workgroup per CU (two of the small ones)
+    int s = (p.m_t == 32 ? ECG_TK_SLOTS32 : 256) / tiles;   // one eight-wave workgroup per CU (two of the small ones)
     const int total = N * p.ntt;
     if (s > total / 4) s = total / 4;                       // a slab is written and re-read per split: >= 4 stages each
     if (s < 1) s = 1;

@@ -94,6 +94,9 @@ def mfma_busy_columns(busy_cycles, gui_active_per_xcd, d_us):
 
 def main():
     os.makedirs(PROF, exist_ok=True)
+    traffic_only = "--traffic-only" in sys.argv       # on the GPU box, between the counter passes and the bench runs
+    if traffic_only:
+        return traffic_tables()
     for f in glob.glob(os.path.join(OUT, f"{TAG}_bench*.json")) + glob.glob(os.path.join(OUT, f"{TAG}_input_pipeline.json")) + glob.glob(os.path.join(OUT, f"{TAG}_inference.json")):
         shutil.copy(f, os.path.join(PROF, os.path.basename(f)))
     stats = newest(os.path.join(OUT, f"prof_{TAG}", "**", "*_kernel_stats.csv"))
@@ -104,6 +107,22 @@ def main():
     open(os.path.join(PROF, f"{TAG}_kernel_stats_summary.txt"), "w").write(
         f"# rocprofv3 --kernel-trace --stats -- python3 bench.py --no-cpu-baseline --no-also --steps 20 --warmup 5 --priming 0  ({steps} steps incl. warm-up, the per-step-event repeat and the instrumented pass)\n" + summ)
 
+    c5 = glob.glob(os.path.join(OUT, f"prof_{TAG}_c5bf16", "**", "*_kernel_stats.csv"), recursive=True)
+    if c5:
+        c5s = newest(os.path.join(OUT, f"prof_{TAG}_c5bf16", "**", "*_kernel_stats.csv"))
+        shutil.copy(c5s, os.path.join(PROF, f"{TAG}_kernel_stats_bf16_config5.csv"))
+        summ5 = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "prof_summary.py"), c5s, str(steps), "40"],
+                               capture_output=True, text=True).stdout
+        open(os.path.join(PROF, f"{TAG}_kernel_stats_bf16_config5_summary.txt"), "w").write(
+            "# rocprofv3 --kernel-trace --stats -- python3 bench.py --no-cpu-baseline --no-also --priming-seconds 0 --dtype bf16 "
+            f"--length 5000 --labels 1 --steps 20 --warmup 5 --priming 0  ({steps} steps incl. warm-up, the per-step-event repeat "
+            "and the instrumented pass)\n" + summ5)
+    lines = traffic_tables()
+    print(summ[:1500])
+    print("\n".join(lines[:40]))
+
+
+def traffic_tables():
     lines = ["# per entry point of one B=256 train step (tools/pmc_step.py; same keys as bench.py `layers`):",
              "# launches per call, µs per call (under the counter pass), FETCH_SIZE / WRITE_SIZE in KiB as rocprofv3 reports them",
              "# (separate passes), hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024 (gfx950 FETCH_SIZE correction),",
@@ -146,8 +165,7 @@ def main():
             "formula": "hbm bytes per call = (2 * FETCH_SIZE + WRITE_SIZE) KiB summed over the entry point's launches, separate "
                        "rocprofv3 --pmc passes of tools/pmc_step.py; gfx950 FETCH_SIZE correction per MI355X_MICROARCH.md"}
     json.dump({"_meta": meta, "entries": entries}, open(os.path.join(PROF, "pmc_traffic.json"), "w"), indent=1)
-    print(summ[:1500])
-    print("\n".join(lines[:40]))
+    return lines
 
 
 if __name__ == "__main__":
