@@ -431,7 +431,10 @@ __global__ __launch_bounds__(kBlock) void bn_bwd_dx_kernel(
 //   * S == 1 (C >= #CUs: the last block) needs no exchange at all and never touches `counters`.
 // Arithmetic: the per-element formulas of the two kernels above; the partial sums associate differently (1024 threads,
 // 16 waves), which the parity tests' tolerances cover like any other split count.
-constexpr int kResThreads = 1024, kResPairs = 16, kResMaxC = 1024, kResMaxS = 4, kResSpin = 512;
+#ifndef ECG_BN_RES_MAX_S
+#define ECG_BN_RES_MAX_S 8       // workgroups per channel the one-launch form accepts (compile-time A/B knob)
+#endif
+constexpr int kResThreads = 1024, kResPairs = 16, kResMaxC = 1024, kResMaxS = ECG_BN_RES_MAX_S, kResSpin = 512;
 
 __device__ __forceinline__ unsigned long long res_word(float v) {      // {value bits, tag = 1}
     return (1ull << 32) | (unsigned long long)__float_as_uint(v);
@@ -1008,9 +1011,11 @@ static int resident_splits(int N, int C, int L, int ldy) {
     int S = ncu / C;
     if (S > N) S = N;
     if (S < 1) return 0;
-    // measured per call at B=256 12x1000 (two-pass -> resident): S = 1 32.1 -> 25.5 us, S = 2 30.2 -> 26.0, S = 4 29.1 -> 26.6,
-    // S = 8 27.6 -> 27.2: the wait costs what the second read saved; and at B=32 (an eighth of the bytes) the two short
-    // passes win (12-15 us against 14-19): the one-launch form is for slices that fill at least half of its registers
+    // measured per call at B=256 12x1000 (two-pass -> one launch; tools/bn_bwd_bench.py, round 4): S = 1 31.6 -> 24.9 us, S = 2
+    // 30.1 -> 24.4, S = 4 29.3 -> 24.7, S = 8 (block 0) 28.6 -> 25.0.  (With round 3's counter protocol — one thread spinning, then
+    // everybody loading the partials: two serial round trips — S = 8 gained nothing, 27.6 -> 27.2; with every word polled by its
+    // own thread it is one round trip.)  At B=32 (an eighth of the bytes) the two short passes win (12-15 us against 14-19):
+    // the one-launch form is for slices that fill at least half of its registers
     if (S > kResMaxS) return 0;
     const int Lr = (L + 1) / 2;
     const long long pairs = (long long)cdiv(N, S) * Lr;

@@ -283,7 +283,7 @@ def test_bn_relu_pool_bwd_writes_row_padded_dy(hip, oracle, shape, gap):
 
 
 # (N, C, L, gap): blocks 1-3 of the headline configuration (S = 4, 2, 1 workgroups per channel; L = 125 is odd: scalar
-# loads, an unpooled tail sample per row), an uneven sample split, block 0 (S = 8), which keeps the two passes, and
+# loads, an unpooled tail sample per row), an uneven sample split, block 0 (S = 8 since round 4), and
 # shapes off the model's grid (channel counts that do not divide the CU count, odd rows, ragged splits)
 @pytest.mark.parametrize("case", [(256, 64, 500, False), (256, 128, 250, False), (256, 256, 125, True), (256, 256, 125, False),
                                   (201, 128, 250, False), (256, 32, 1000, False),
@@ -298,7 +298,8 @@ def test_bn_backward_in_one_launch_with_resident_operands_vs_oracle(hip, oracle,
     N, C, Lo, gap = case
     ldy = (Lo + 63) // 64 * 64
     S = L.query("ecg_bn_relu_pool_bwd_one_launch_splits", N, C, Lo, ldy)
-    assert (S == 0) == (C == 32)                                                      # block 0 (8 per channel) keeps two passes
+    if N >= 128:
+        assert S == max(1, 256 // C)                                                  # C x S <= 256 CUs: 8 / 4 / 2 / 1 workgroups per channel
     assert L.query("ecg_bn_relu_pool_bwd_one_launch_splits", 32, C, Lo, ldy) == 0     # small batches keep the two short passes
     rng = np.random.default_rng(N + C + Lo)
     y = (rng.standard_normal((N, C, Lo)) * 1.5 + 0.3).astype(np.float32)
