@@ -194,7 +194,10 @@ __global__ __launch_bounds__(kBlock) void bn_relu_pool_gap_fwd_kernel(
     // flight together and their four lane reductions interleave.  (One row per trip left this pass latency-bound: 32.8 MB
     // in 21 us on the 62-pair rows of 12x1000, 82 MB in 25 us on the 312-pair rows of 12x5000.)  Per row the additions
     // and their order are unchanged.
-    constexpr int RB = 4;
+#ifndef ECG_GAP_RB
+#define ECG_GAP_RB 4
+#endif
+    constexpr int RB = ECG_GAP_RB;
     for (int nb = n0 + (threadIdx.x >> 6); nb < n1; nb += 4 * RB) {
         float a[RB];
         size_t rows[RB];

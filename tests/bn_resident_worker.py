@@ -11,7 +11,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, "ptbxl-multimodal_amd")):
     sys.path.insert(0, p)
 
-CASES = ((256, 64, 500, False), (201, 128, 250, False), (256, 256, 125, True), (256, 128, 250, False), (180, 100, 301, True))
+CASES = ((256, 64, 500, False), (201, 128, 250, False), (256, 256, 125, True), (256, 128, 250, False), (180, 100, 301, True),
+         (256, 32, 1000, False))          # 4, 2, 1, 2, 2 and 8 workgroups per channel
 
 
 def run(spin_polls=-1):

@@ -366,7 +366,7 @@ def test_bn_backward_one_launch_self_service_gives_the_same_bits(tmp_path):
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
     import bn_resident_worker as W
     outs = [W.run(-1), W.run(0)]
-    assert outs[0].keys() == outs[1].keys() and len(outs[0]) == 30
+    assert outs[0].keys() == outs[1].keys() and len(outs[0]) == 36
     for k in outs[0]:
         assert not np.isnan(outs[0][k]).any(), k
         np.testing.assert_array_equal(outs[0][k], outs[1][k], err_msg=k)
