@@ -411,6 +411,9 @@ __global__ __launch_bounds__(512) void conv1d_wgrad_bf16_tk_kernel(
 // conv1d_direct.hip: dw[i] = sum_s slab[s][i] in fixed order
 int wgrad_reduce(const float *ws, float *dw, float *db, size_t wslab, int Cout, int S, hipStream_t st);
 
+#ifndef ECG_TK_RT128
+#define ECG_TK_RT128 512         // column-tile width of the 128-channel plan (A/B knob: 256 halves the slab bytes per layer)
+#endif
 #ifndef ECG_TK_SLOTS32
 #define ECG_TK_SLOTS32 512       // workgroups of the 32-channel tile plan (compile-time A/B knob: make VARIANT=.. EXTRA=-DECG_TK_SLOTS32=256)
 #endif
@@ -421,6 +424,7 @@ static TkPlan tk_plan(int N, int Cin, int Cout, int Lo) {
     if (Cout % 32 != 0) return p;
     p.m_t = Cout % 128 == 0 ? 128 : Cout % 64 == 0 ? 64 : 32;
     if (p.m_t == 32) p.r_t = 192;                           // the 32-channel first layer: 32 x 192 tiles, k-steps split over waves
+    if (p.m_t == 128) p.r_t = ECG_TK_RT128;
     const int tiles = cdiv(Cin * tk::KK, p.r_t) * (Cout / p.m_t);
     int s = (p.m_t == 32 ? ECG_TK_SLOTS32 : 256) / tiles;   // one eight-wave workgroup per CU (two of the small ones)
     const int total = N * p.ntt;
@@ -454,7 +458,7 @@ int wgrad_bf16_tk(const void *dy_bf16, int ldy, const void *x, int x_is_bf16, in
 #define ECG_TK(MT, RT, WM, WR, WK, XF) \
     hipLaunchKernelGGL((tk::conv1d_wgrad_bf16_tk_kernel<MT, RT, WM, WR, WK, XF>), grid, block, 0, st, dy, x, ws, N, Cin, Cout, L, \
                        ldy, ldx, p.ntt, p.splits)
-    if (p.m_t == 128) { if (x_is_bf16) ECG_TK(128, 512, 2, 4, 1, false); else ECG_TK(128, 512, 2, 4, 1, true); }
+    if (p.m_t == 128) { if (x_is_bf16) ECG_TK(128, ECG_TK_RT128, 2, 4, 1, false); else ECG_TK(128, ECG_TK_RT128, 2, 4, 1, true); }
     else if (p.m_t == 64) { if (x_is_bf16) ECG_TK(64, 512, 1, 8, 1, false); else ECG_TK(64, 512, 1, 8, 1, true); }
     else { if (x_is_bf16) ECG_TK(32, 192, 1, 2, 4, false); else ECG_TK(32, 192, 1, 2, 4, true); }
 #undef ECG_TK

@@ -552,7 +552,7 @@ def test_bf16_mixed_precision_train_step_config5(B, T, act_bf16):
     must track the fp32 CPU oracle at bf16 accuracy (the reference has no mixed precision to compare with).  B=19: a
     ragged group of 16 samples in the n16 operand chain (BN forward -> next conv's weight gradient, BN backward -> dY).
 
-    Bars = about 1.3x the largest value measured over these five cases (round 4, tools/_bf16_err.py; the measured
+    Bars = about 1.3x the largest value measured over these five cases (round 4, tools/bf16_grad_error.py; the measured
     value of every tensor is in the assertion message):
       logits 1.2e-3 -> 3e-3, loss 4.2e-5 -> 2e-4;
       tensors BEHIND the last bf16 conv (block-3 BatchNorm, proj, head): rel <= 3.7e-3, 1-cos <= 6.8e-6 -> 1e-2 / 2e-5;
