@@ -106,8 +106,12 @@ class FlatGradDDP(nn.Module):
             # the one all-reduce is issued from the hook of the LAST gradient, i.e. behind every backward kernel on the
             # stream: nothing communicates while the BatchNorm backward kernels run ("quiet", functional.py)
             if self._params and self._params[0].is_cuda:
+                import weakref
                 from . import functional as F
                 F.declare_backward_collectives(self._params, False)
+                # withdraw the statement when the wrapper goes away: the table is keyed by parameter address, and a later
+                # model whose parameters land on the same addresses must start undeclared
+                weakref.finalize(self, F.declare_backward_collectives, [p.data_ptr() for p in self._params], None)
 
     def _on_grad(self, _param):
         self._pending += 1
