@@ -47,7 +47,7 @@ constexpr int kStreamBlocks = 2048;
 // bf16 operands (the bf16-storage backward, `wide`): 2048 — that pass is bound by the latency of its dependent load rounds
 // (6 bytes per position: the number of loads in flight per thread, the per-position instruction count and the walk order
 // were all varied without effect), and twice the workgroups took 4-11 us off every backward call of 12x5000 (config-5 step
-// 1.449 -> 1.415 ms); 4096 adds nothing.  ECG_BN_SPLITS overrides both (tuning).
+// 1.449 -> 1.415 ms); 4096 adds nothing.
 static int stat_splits(int N, int C, bool wide = false) {
     int s = cdiv(wide ? 2048 : 1024, C);
     if (s > N) s = N;
