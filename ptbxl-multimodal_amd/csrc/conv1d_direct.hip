@@ -304,6 +304,17 @@ __global__ __launch_bounds__(64 * G) void wgrad_reduce4_kernel(const float *__re
         const float *src = i < wslab ? slab + i : slab + (size_t)S * wslab + (i - wslab);
         const size_t stride = i < wslab ? wslab : (size_t)Cout;
         int s = w;
+        // eight slabs in flight per lane (8 KB per wave; with four a CU held ~30 KB in flight — short of what HBM latency
+        // needs — and the pass ran at 3.4-4.6 TB/s); the additions stay in slab order: bit-identical sums
+        for (; s + 7 * G < S; s += 8 * G) {
+            float4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const float4 *>(src + (size_t)(s + u * G) * stride);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                a[0] += (double)v[u].x; a[1] += (double)v[u].y; a[2] += (double)v[u].z; a[3] += (double)v[u].w;
+            }
+        }
         for (; s + 3 * G < S; s += 4 * G) {
             const float4 v0 = *reinterpret_cast<const float4 *>(src + (size_t)s * stride);
             const float4 v1 = *reinterpret_cast<const float4 *>(src + (size_t)(s + G) * stride);
