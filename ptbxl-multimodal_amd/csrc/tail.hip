@@ -111,25 +111,37 @@ __global__ void film_bwd_kernel(const float *__restrict__ z, const float *__rest
 }
 
 // ---- BCE with logits (mean) -------------------------------------------------------------------
-__global__ __launch_bounds__(256) void bce_kernel(const float *__restrict__ x,
-                                                  const float *__restrict__ t,
-                                                  float *__restrict__ loss, float *__restrict__ dx,
-                                                  int numel, double *__restrict__ running,
-                                                  double weight) {
-    __shared__ double red[4];
+// One workgroup of 1024 threads: at the model's sizes (B x C = 1280 logits) every element is loaded in the first trip — the
+// kernel is one dependent chain load -> exp / log1p -> reduce -> store, so its time is that chain's latency (5.8 us with 256
+// threads walking five trips; the sums are fixed-order per thread, then lanes by butterfly, then waves in order).
+constexpr int kBceThreads = 1024;
+__global__ __launch_bounds__(kBceThreads) void bce_kernel(const float *__restrict__ x,
+                                                          const float *__restrict__ t,
+                                                          float *__restrict__ loss, float *__restrict__ dx,
+                                                          int numel, double *__restrict__ running,
+                                                          double weight) {
+    __shared__ double red[kBceThreads / 64];
     double a = 0.0;
     const float inv = 1.0f / (float)numel;
-    for (int i = threadIdx.x; i < numel; i += 256) {
-        float xi = x[i], ti = t[i];
-        float l = fmaxf(xi, 0.f) - xi * ti + log1pf(expf(-fabsf(xi)));
-        a += (double)l;
-        if (dx) dx[i] = (1.0f / (1.0f + expf(-xi)) - ti) * inv;
+    for (int i0 = threadIdx.x; i0 < numel; i0 += 2 * kBceThreads) {
+        const int i1 = i0 + kBceThreads;
+        const bool two = i1 < numel;
+        const float x0 = x[i0], t0 = t[i0], x1 = two ? x[i1] : 0.f, t1 = two ? t[i1] : 0.f;      // both trips' loads in flight
+        a += (double)(fmaxf(x0, 0.f) - x0 * t0 + log1pf(expf(-fabsf(x0))));
+        if (dx) dx[i0] = (1.0f / (1.0f + expf(-x0)) - t0) * inv;
+        if (two) {
+            a += (double)(fmaxf(x1, 0.f) - x1 * t1 + log1pf(expf(-fabsf(x1))));
+            if (dx) dx[i1] = (1.0f / (1.0f + expf(-x1)) - t1) * inv;
+        }
     }
     a = wave_sum(a);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = a;
     __syncthreads();
     if (threadIdx.x == 0) {
-        const float l = (float)((red[0] + red[1] + red[2] + red[3]) / (double)numel);
+        double tot = 0.0;
+#pragma unroll
+        for (int w = 0; w < kBceThreads / 64; ++w) tot += red[w];
+        const float l = (float)(tot / (double)numel);
         loss[0] = l;
         if (running) running[0] += (double)l * weight;    // epoch bookkeeping without extra launches
     }
@@ -219,7 +231,7 @@ ECG_API int ecg_bce_logits_fwd(const float *x, const float *target, float *loss,
                                int numel, double *running_sum, double weight,
                                ecg_stream_t stream) {
     ECG_REQUIRE(x && target && loss && numel > 0, "bce_logits_fwd: bad argument");
-    hipLaunchKernelGGL(bce_kernel, dim3(1), dim3(256), 0, as_stream(stream), x, target, loss, dx,
+    hipLaunchKernelGGL(bce_kernel, dim3(1), dim3(kBceThreads), 0, as_stream(stream), x, target, loss, dx,
                        numel, running_sum, weight);
     return check_launch("bce_kernel");
 }
