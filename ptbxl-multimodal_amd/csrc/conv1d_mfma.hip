@@ -118,15 +118,11 @@ __device__ __forceinline__ int xcd_chunked(int bid, int nwg) {
 }
 struct EvalEpi { const float *gamma, *beta, *mean, *var; float eps; int gap; };
 
-// XBN (A/B builds only, `make VARIANT=xbn EXTRA=-DECG_XBN=1`; never instantiated in the product library): x is the PREVIOUS
-// block's conv output y_prev [N][C_in][ldx] and the kernel applies that block's BatchNorm + ReLU + MaxPool(2) while it stages
-// the tile — x[s] = max(0, max(bn(y[2s]), bn(y[2s+1]))), xbn = [C_in][3] (mean, invstd*gamma, beta) — i.e. the pooled
-// activation is never written.  Measured and priced in profiles/EXPERIMENTS.md (E5).
-template <int CO_T, int T_T, int WCO, int WT, int EPI, bool XBN = false>
+template <int CO_T, int T_T, int WCO, int WT, int EPI>
 __global__ __launch_bounds__(256, 2) void conv1d_mfma_fwd_kernel(
     const float *__restrict__ x, const float *__restrict__ wp, const float *__restrict__ bias,
     float *__restrict__ y, float *__restrict__ partials, int Cin, int Cout, int L, int ldx, int Lo,
-    int pad, int P, int tiles_t, EvalEpi ev, const float *__restrict__ xbn = nullptr) {
+    int pad, int P, int tiles_t, EvalEpi ev) {
     constexpr bool STATS = (EPI == EPI_STATS), GAP = (EPI == EPI_EVAL_GAP);
     static_assert(WCO * WT == 4, "4 waves per workgroup");
     constexpr int KK = kKM, CI_C = 4, NST = KK * CI_C / 2;
@@ -146,15 +142,11 @@ __global__ __launch_bounds__(256, 2) void conv1d_mfma_fwd_kernel(
 
     // ONE shared array: a second __shared__ object beside an LDS-DMA target makes hipcc wait
     // vmcnt(0) in front of every LDS read.
-    constexpr int XBNF = XBN ? 3 * 512 : 0;      // the previous block's (mean, scale, beta) per input channel
-    __shared__ __attribute__((aligned(1024))) float lds[2 * IMG + XBNF];
+    __shared__ __attribute__((aligned(1024))) float lds[2 * IMG];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int half = lane >> 5, l31 = lane & 31;
     ECG_STAMP_AT(0);
-    if (XBN) {
-        for (int i = tid; i < 3 * Cin; i += 256) lds[2 * IMG + i] = xbn[i];     // (published by the prologue's barrier)
-    }
     // logical tile order: the C_out tiles of one (n, t tile) are adjacent — they read the same x panel
     const int CT = Cout / CO_T;
     const int tile = xcd_chunked(blockIdx.x, gridDim.x);
@@ -206,18 +198,17 @@ __global__ __launch_bounds__(256, 2) void conv1d_mfma_fwd_kernel(
         const int k = row / CI_C, ci = row - k * CI_C;
         woff[j] = (k * Cin + ci) * Cout + col;
     }
-    int xoff[XLOADS], xcil[XLOADS];
+    int xoff[XLOADS];
     unsigned xmask = 0;
 #pragma unroll
     for (int j = 0; j < XLOADS; ++j) {
         const int e = min(tid + 256 * j, XEL - 1);
         const int ci = e / XS, pos = e - ci * XS;
         const int s = t0 - pad + pos;
-        xoff[j] = ci * ldx + (XBN ? 2 : 1) * min(max(s, 0), L - 1);     // XBN: the pooling pair (2s, 2s+1) of y_prev
-        xcil[j] = 3 * ci;
+        xoff[j] = ci * ldx + min(max(s, 0), L - 1);
         xmask |= ((s >= 0) && (s < L)) ? (1u << j) : 0u;
     }
-    float xreg[XLOADS], xreg1[XBN ? XLOADS : 1];
+    float xreg[XLOADS];
 
     const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) float *)lds;
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
@@ -226,24 +217,12 @@ __global__ __launch_bounds__(256, 2) void conv1d_mfma_fwd_kernel(
             glds16(wp + (size_t)ci0 * Cout + co0, (unsigned)woff[j] * 4u,
                    (unsigned)__builtin_amdgcn_readfirstlane((int)(lds_base + (unsigned)((img - lds) + (j * 4 + wave_u) * 256) * 4u)));
     };
-    auto load_x = [&](int j, int ci0) {
-        if (XBN) {
-            const float2 v = *reinterpret_cast<const float2 *>(xn + (size_t)ci0 * ldx + xoff[j]);   // (ldx even: 8-byte aligned)
-            xreg[j] = v.x; xreg1[j] = v.y;
-        } else xreg[j] = xn[(size_t)ci0 * ldx + xoff[j]];
-    };
-    auto commit_x = [&](int j, float *img, int cic) {       // cic: first input channel of the chunk being committed
+    auto load_x = [&](int j, int ci0) { xreg[j] = xn[(size_t)ci0 * ldx + xoff[j]]; };
+    auto commit_x = [&](int j, float *img) {
         const int e = tid + 256 * j;
         const unsigned keep = 0u - ((xmask >> j) & 1u);
-        float v = xreg[j];
-        if (XBN) {
-            const float *tb = lds + 2 * IMG + 3 * cic + xcil[j];
-            const float mu = tb[0], sc = tb[1], be = tb[2];
-            const float a0 = bn_apply1(xreg[j], mu, sc, be), a1 = bn_apply1(xreg1[j], mu, sc, be);
-            v = fmaxf(a1 > a0 ? a1 : a0, 0.f);
-        }
         if (256 * (j + 1) <= XEL || e < XEL)
-            img[WPAD + e] = __uint_as_float(__float_as_uint(v) & keep);
+            img[WPAD + e] = __uint_as_float(__float_as_uint(xreg[j]) & keep);
     };
 
     const int nchunks = Cin / CI_C;
@@ -252,9 +231,8 @@ __global__ __launch_bounds__(256, 2) void conv1d_mfma_fwd_kernel(
     for (int j = 0; j < DPW; ++j) dma_w(j, 0, lds);
 #pragma unroll
     for (int j = 0; j < XLOADS; ++j) load_x(j, 0);
-    if (XBN) __syncthreads();                             // (the table, before the first commit reads it)
 #pragma unroll
-    for (int j = 0; j < XLOADS; ++j) commit_x(j, lds, 0);
+    for (int j = 0; j < XLOADS; ++j) commit_x(j, lds);
     if (nchunks > 1) {
 #pragma unroll
         for (int j = 0; j < XLOADS; ++j) load_x(j, CI_C);
@@ -288,7 +266,7 @@ __global__ __launch_bounds__(256, 2) void conv1d_mfma_fwd_kernel(
             wait_lgkm_f((MC + 1) / 2 + (MT + 1) / 2);      // the reads just issued (pairs merge into ds_read2_b32) may fly
             // staging, one operation per step: x commits, then weight DMA pieces, then x loads
             if (st < XLOADS) {
-                if (do_next) commit_x(st, nxt, ci_next);
+                if (do_next) commit_x(st, nxt);
             } else if (st < XLOADS + DPW) {
                 if (do_next) dma_w(st - XLOADS, ci_next, nxt);
             } else if (st < 2 * XLOADS + DPW) {
@@ -803,12 +781,10 @@ __global__ __launch_bounds__(256, 2) void conv1d_mfma_wgrad_kernel(
 // inline constant 0 and the stage's 64-term sum is added to a second register set at the end of the stage: chains of
 // 64 + total terms, fixed order (bitwise reproducible), no extra memory traffic; cost = one v_pk_add_f32 per two
 // accumulator registers per stage (32 MFMAs of 64 cycles per register pair).
-// XBN: as in the forward kernel (A/B builds only) — x is the previous block's conv output [N][C_in][ldx], its BatchNorm + ReLU +
-// MaxPool(2) applied while the x tile is staged.
-template <int M_T, int R_T, int WM, int WR, int WK, int KK, int FL = 1, bool XBN = false>
+template <int M_T, int R_T, int WM, int WR, int WK, int KK, int FL = 1>
 __global__ __launch_bounds__(256, 2) void conv1d_mfma_wgrad_dma_kernel(
     const float *__restrict__ dy, const float *__restrict__ x, float *__restrict__ slab, int N,
-    int Cin, int Cout, int L, int Lo, int ldy, int pad, int S, const float *__restrict__ xbn = nullptr, int ldx = 0) {
+    int Cin, int Cout, int L, int Lo, int ldy, int pad, int S) {
     static_assert(WM * WR * WK == 4, "4 waves per workgroup");
     constexpr int T_T = 64;
     constexpr int MC = M_T / WM / 32, MR = R_T / WR / 32;
@@ -830,8 +806,7 @@ __global__ __launch_bounds__(256, 2) void conv1d_mfma_wgrad_dma_kernel(
     static_assert(XLOADS <= 32, "mask bits");
     static_assert(NST >= 2 * XLOADS + DPW, "not enough steps to spread the staging over");
 
-    constexpr int XBNF = XBN ? 3 * NCI + 1 : 0;
-    __shared__ __attribute__((aligned(1024))) float lds[2 * IMG + XBNF];
+    __shared__ __attribute__((aligned(1024))) float lds[2 * IMG];
     ECG_STAMP_AT(0);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -846,11 +821,6 @@ __global__ __launch_bounds__(256, 2) void conv1d_mfma_wgrad_dma_kernel(
     const int wm0 = wm * (M_T / WM), wr0 = wr * (R_T / WR), wt0 = wk * TW;
     const int ci_base = r0 / KK;
     const int ntt = (Lo + T_T - 1) / T_T;
-    const int xrs = XBN ? ldx : L;                      // row stride of the x tensor
-    if (XBN) {
-        for (int i = threadIdx.x; i < 3 * NCI; i += 256) lds[2 * IMG + i] = xbn[3 * min(ci_base + i / 3, Cin - 1) + i % 3];
-        __syncthreads();
-    }
     // the split runs over stages (n, t tile), not whole samples: finer balance, and enough workgroups for
     // layers with a single output tile
     const int it_begin = (int)((long long)N * ntt * s / S), it_end = (int)((long long)N * ntt * (s + 1) / S);
@@ -888,10 +858,10 @@ __global__ __launch_bounds__(256, 2) void conv1d_mfma_wgrad_dma_kernel(
 #pragma unroll
     for (int j = 0; j < XLOADS; ++j) {
         const int e = min(tid + 256 * j, XEL - 1);
-        xci[j] = min(ci_base + e / XS, Cin - 1) * xrs;
+        xci[j] = min(ci_base + e / XS, Cin - 1) * L;
         xpos[j] = e % XS - pad;
     }
-    float xreg[XLOADS], xreg1[XBN ? XLOADS : 1];
+    float xreg[XLOADS];
     unsigned xmask = 0, cxmask = 0;
     const int total = it_end - it_begin;
 
@@ -907,27 +877,17 @@ __global__ __launch_bounds__(256, 2) void conv1d_mfma_wgrad_dma_kernel(
                (unsigned)__builtin_amdgcn_readfirstlane((int)(lds_base + (unsigned)((img - lds) + (j * 4 + wave_u) * 256) * 4u)));
     };
     auto load_x = [&](int j) {                          // x tile element of stage (sn, stt)
-        const float *xn = x + (size_t)min(sn, N - 1) * Cin * xrs;
+        const float *xn = x + (size_t)min(sn, N - 1) * Cin * L;
         const int sidx = stt * T_T + xpos[j];
-        if (XBN) {
-            const float2 v = *reinterpret_cast<const float2 *>(xn + xci[j] + 2 * min(max(sidx, 0), L - 1));
-            xreg[j] = v.x; xreg1[j] = v.y;
-        } else xreg[j] = xn[xci[j] + min(max(sidx, 0), L - 1)];
+        xreg[j] = xn[xci[j] + min(max(sidx, 0), L - 1)];
         const unsigned bit = ((sidx >= 0) && (sidx < L)) ? (1u << j) : 0u;
         xmask = (j == 0) ? bit : (xmask | bit);
     };
     auto commit_x = [&](int j, float *img) {
         const int e = tid + 256 * j;
         const unsigned keep = 0u - ((cxmask >> j) & 1u);
-        float v = xreg[j];
-        if (XBN) {
-            const float *tb = lds + 2 * IMG + 3 * (min(e, XEL - 1) / XS);
-            const float mu = tb[0], sc = tb[1], be = tb[2];
-            const float a0 = bn_apply1(xreg[j], mu, sc, be), a1 = bn_apply1(xreg1[j], mu, sc, be);
-            v = fmaxf(a1 > a0 ? a1 : a0, 0.f);
-        }
         if (256 * (j + 1) <= XEL || e < XEL)
-            img[AEL + e] = __uint_as_float(__float_as_uint(v) & keep);
+            img[AEL + e] = __uint_as_float(__float_as_uint(xreg[j]) & keep);
     };
 
     // prologue: stage 0 -> image 0, x tile of stage 1 -> registers
@@ -1177,40 +1137,6 @@ int mfma_wgrad(const float *dy, int ldy, const float *x, float *dw, float *db, f
 }
 
 }  // namespace ecg
-
-#if defined(ECG_XBN) && ECG_XBN
-// A/B build only (make VARIANT=xbn EXTRA=-DECG_XBN=1; tools/layer_bench.py --xbn): the forward conv and the weight gradient with
-// the previous block's BatchNorm + ReLU + MaxPool(2) applied while the x tile is staged (the pooled activation never exists).
-extern "C" __attribute__((visibility("default"))) int ecg_whatif_conv1d_fwd_xbn(
-    const float *yprev, int ldx, const float *xbn, const float *w_fwd, const float *bias, float *y, float *partials, int N,
-    int Cin, int Cout, int L, void *stream) {
-    using namespace ecg;
-    const int T_T = 128, tiles_t = cdiv(L, T_T), P = N * tiles_t;
-    dim3 grid((unsigned)((size_t)tiles_t * (Cout / 64) * N)), block(256);
-    const EvalEpi none{nullptr, nullptr, nullptr, nullptr, 0.f, 0};
-    hipLaunchKernelGGL((conv1d_mfma_fwd_kernel<64, 128, 2, 2, EPI_STATS, true>), grid, block, 0, (hipStream_t)stream, yprev, w_fwd,
-                       bias, y, partials, Cin, Cout, L, ldx, L, 7, P, tiles_t, none, xbn);
-    return check_launch("conv1d_mfma_fwd_kernel<xbn>");
-}
-extern "C" __attribute__((visibility("default"))) int ecg_whatif_conv1d_wgrad_xbn(
-    const float *dy, int ldy, const float *yprev, int ldx, const float *xbn, float *dw, float *db, float *ws, int N, int Cin,
-    int Cout, int L, void *stream) {
-    using namespace ecg;
-    const int R = Cin * 15;
-    const WgCfg c = wgrad_cfg(N, Cin, Cout, L, true);
-    dim3 grid((unsigned)(cdiv(R, c.r_t) * (Cout / c.m_t) * c.splits)), block(256);
-    hipStream_t st = (hipStream_t)stream;
-    if (c.m_t == 128)
-        hipLaunchKernelGGL((conv1d_mfma_wgrad_dma_kernel<128, 128, 2, 2, 1, kKM, ECG_WG_FL, true>), grid, block, 0, st, dy, yprev, ws, N,
-                           Cin, Cout, L, L, ldy, 7, c.splits, xbn, ldx);
-    else
-        hipLaunchKernelGGL((conv1d_mfma_wgrad_dma_kernel<64, 128, 2, 2, 1, kKM, ECG_WG_FL, true>), grid, block, 0, st, dy, yprev, ws, N,
-                           Cin, Cout, L, L, ldy, 7, c.splits, xbn, ldx);
-    int rc = check_launch("conv1d_mfma_wgrad_dma_kernel<xbn>");
-    if (rc) return rc;
-    return wgrad_reduce(ws, dw, db, (size_t)Cout * R, Cout, c.splits, st);
-}
-#endif
 
 #ifdef ECG_STAMP
 extern "C" __attribute__((visibility("default"))) int ecg_debug_set_stamp_buffer(unsigned long long *buf) {
