@@ -861,6 +861,49 @@ def test_bf16_tk_weight_grad_is_exact_on_bf16_rounded_operands(hip, oracle, case
                L.f32(db), L.f32(ws), N, Ci, Co, Lin, 15, 7, L.stream())
 
 
+def _tk_random_cases():
+    rng = np.random.default_rng(20260)
+    out = []
+    for _ in range(28):
+        co = int(rng.choice([32, 64, 96, 128, 160, 256]))
+        ci = int(rng.integers(1, 41)) * int(rng.choice([1, 4]))
+        xbf = bool(rng.integers(0, 2))
+        L_ = int(rng.integers(16, 700))
+        if not xbf:
+            L_ = max(16, L_ // 8 * 8)                     # the fp32-input form needs whole 8-element chunks
+        out.append((int(rng.integers(1, 7)), ci, co, L_, xbf))
+    return out
+
+
+@pytest.mark.parametrize("case", _tk_random_cases())
+def test_bf16_tk_weight_grad_random_shapes(hip, case):
+    """Seeded random shapes (any C_in, every tile plan, ragged last stages, rows shorter than a stage, both x forms) against
+    stock torch on the bf16-rounded operands — the bounds of every staged tile are exercised, not just the model's shapes."""
+    from ecg_hip import _lib as L
+    N, Ci, Co, Lin, xbf = case
+    g = torch.Generator().manual_seed(N * 7 + Ci + Co + Lin)
+    x = torch.randn(N, Ci, Lin, generator=g)
+    dy = torch.randn(N, Co, Lin, generator=g)
+    ldy = L.query("ecg_conv1d_bf16_tk_dy_stride", Lin)
+    dyh = torch.zeros(N, Co, ldy, dtype=torch.bfloat16, device="cuda")
+    dyh[:, :, :Lin] = dy.cuda().to(torch.bfloat16)
+    if xbf:
+        ldx = (Lin + 7) & ~7
+        xd = torch.zeros(N, Ci, ldx, dtype=torch.bfloat16, device="cuda")
+        xd[:, :, :Lin] = x.cuda().to(torch.bfloat16)
+    else:
+        ldx, xd = Lin, x.cuda()
+    dw, db = torch.full((Co, Ci, 15), float("nan"), device="cuda"), torch.full((Co,), float("nan"), device="cuda")
+    ws = torch.empty(L.query("ecg_conv1d_bwd_weight_bf16_ncl_ws_floats", N, Ci, Co, Lin, 15, 7), device="cuda")
+    L.call("ecg_conv1d_bwd_weight_bias_bf16_ncl", L.ptr(dyh), ldy, L.ptr(xd), 1 if xbf else 0, ldx, L.f32(dw), L.f32(db),
+           L.f32(ws), N, Ci, Co, Lin, 15, 7, L.stream())
+    rnd = lambda t: t.to(torch.bfloat16).to(torch.float64)      # noqa: E731
+    rdw = torch.nn.grad.conv1d_weight(rnd(x), (Co, Ci, 15), rnd(dy), padding=7)
+    scale = float(np.sqrt(N * Lin))
+    np.testing.assert_allclose(host(dw), rdw.numpy(), atol=3e-6 * float(rdw.abs().max()) + 2e-5)
+    np.testing.assert_allclose(host(db), rnd(dy).sum(dim=(0, 2)).numpy(), atol=3e-6 * scale * 4 + 2e-5)
+
+
 def _unpack_n16(buf, G, C, P):
     """bf16 [G][C][P][16] (a flat torch.bfloat16 tensor) -> float32 numpy [16*G][C][P]."""
     a = buf.view(G, C, P, 16).to(torch.float32).cpu().numpy()
@@ -926,7 +969,8 @@ def test_bn_relu_pool_n16_producers_match_the_plain_passes(hip, oracle, shape):
         assert np.array_equal(_unpack_n16(dyb, G, C, PA), want)
 
 
-@pytest.mark.parametrize("shape", [(19, 32, 300), (5, 64, 257), (18, 128, 125), (3, 256, 78), (33, 32, 16), (256, 64, 250)])
+@pytest.mark.parametrize("shape", [(19, 32, 300), (5, 64, 257), (18, 128, 125), (3, 256, 78), (33, 32, 16), (256, 64, 250),
+                                   (7, 33, 19), (3, 1, 1001), (65, 17, 128), (2, 300, 34)])
 @pytest.mark.parametrize("gap", [False, True])
 def test_bf16_row_passes_equal_the_n16_producers(hip, shape, gap):
     """Round 4: the BatchNorm + ReLU + pool passes on bf16 ROWS only (csrc/bn_relu_pool_h.hip: 16 bytes per lane, no n16
