@@ -108,10 +108,13 @@ class FlatGradDDP(nn.Module):
             if self._params and self._params[0].is_cuda:
                 import weakref
                 from . import functional as F
-                F.declare_backward_collectives(self._params, False)
-                # withdraw the statement when the wrapper goes away: the table is keyed by parameter address, and a later
-                # model whose parameters land on the same addresses must start undeclared
-                weakref.finalize(self, F.declare_backward_collectives, [p.data_ptr() for p in self._params], None)
+                # (an optimizer that re-homes the parameters later and states its own exchange mode overrides this, as it
+                # should: a hooked FlatAdamW exchange IS busy under backward; a stock / adopted optimizer says nothing)
+                token = ("FlatGradDDP", id(self))
+                F.declare_backward_collectives(self._params, False, owner=token)
+                # withdraw the statement when the wrapper goes away (by object id + owner token: a later parameter that
+                # reuses an id was declared by someone else and keeps its statement)
+                weakref.finalize(self, F.declare_backward_collectives, [id(p) for p in self._params], None, token)
 
     def _on_grad(self, _param):
         self._pending += 1

@@ -87,7 +87,9 @@ import os as _os
 _bn_one_launch = (_os.environ.get("ECG_BN_BWD_RESIDENT", "1") != "0"
                   and _os.environ.get("ECG_HIP_REHEARSE_ON_ONE_GPU") != "1")
 _bn_spin_polls = int(_os.environ.get("ECG_BN_BWD_RESIDENT_SPIN", "-1"))     # tests: 0 = nobody waits (self-service path)
-_backward_collectives = {}      # parameter data_ptr -> True (busy) / False (quiet)
+_backward_collectives = {}      # id(parameter) -> (weakref(parameter), busy, owner): keyed by the OBJECT, not its address —
+                                # FlatAdamW / adopt_stock_adamw re-home parameter storage after a wrapper has spoken
+_collectives_by_ptr = None      # {data_ptr now: busy}, rebuilt lazily after a declaration or a re-homing
 _bn_counters = {}               # (device index, raw stream) -> zeroed int32 tensor: the kernel's exchange words
 
 
@@ -101,16 +103,28 @@ def set_bn_backward_one_launch(on, spin_polls=None):
     return prev
 
 
-def declare_backward_collectives(params, busy):
+def declare_backward_collectives(params, busy, owner=None):
     """The owner of `params` says whether collectives can run on the device while their backward kernels do (True: the
     BatchNorm backward of their blocks keeps the two-pass form), that they cannot (False), or withdraws its statement
-    (None).  Cheap; call it whenever the exchange mode changes."""
+    (None; with an `owner` token only a statement made under the same token is withdrawn, so an optimizer going away
+    does not take a live wrapper's statement with it).  `params` are the parameter tensors themselves (or their id()s,
+    for a withdrawal from a finalizer).  Cheap; call it whenever the exchange mode changes."""
+    global _collectives_by_ptr
     for p in params:
-        k = p if isinstance(p, int) else p.data_ptr()
+        k = p if isinstance(p, int) else id(p)
         if busy is None:
-            _backward_collectives.pop(k, None)
-        else:
-            _backward_collectives[k] = bool(busy)
+            ent = _backward_collectives.get(k)
+            if ent is not None and (owner is None or ent[2] == owner):
+                del _backward_collectives[k]
+        elif not isinstance(p, int):
+            _backward_collectives[k] = (_weakref.ref(p), bool(busy), owner)
+    _collectives_by_ptr = None
+
+
+def parameters_rehomed():
+    """Parameter storage moved (flatten_tensors_): the address -> statement table is rebuilt at the next backward."""
+    global _collectives_by_ptr
+    _collectives_by_ptr = None
 
 
 def _multi_rank():
@@ -120,9 +134,19 @@ def _multi_rank():
 
 def bn_backward_one_launch_allowed(key):
     """The per-call decision described above for the block whose conv weight has data_ptr `key`."""
+    global _collectives_by_ptr
     if not _bn_one_launch:
         return False
-    busy = _backward_collectives.get(key)
+    if _collectives_by_ptr is None:
+        tab = {}
+        for k, (ref, busy, _owner) in list(_backward_collectives.items()):
+            p = ref()
+            if p is None:
+                del _backward_collectives[k]          # the parameter is gone (and its id may be reused)
+            else:
+                tab[p.data_ptr()] = busy
+        _collectives_by_ptr = tab
+    busy = _collectives_by_ptr.get(key)
     return (not _multi_rank()) if busy is None else (not busy)
 
 

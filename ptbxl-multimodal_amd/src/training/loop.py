@@ -18,6 +18,7 @@ from torch.utils.data import DataLoader
 
 from ecg_hip import functional as hipF
 from ecg_hip.graph import LoopStepper
+from ecg_hip.optim import adopt_stock_adamw
 from src.training.metrics import compute_metrics
 
 try:
@@ -42,6 +43,7 @@ def _eager_step(model, optimizer, x, y, weighted):
 
 def train_one_epoch(model, loader: DataLoader, optimizer, device) -> float:
     model.train()
+    optimizer = adopt_stock_adamw(optimizer)     # the scripts' torch.optim.AdamW steps through the fused flat launch
     stepper = LoopStepper.for_loop(model, optimizer, loss_weight_is_batch=True)
     weighted = None if stepper is None else stepper.running
     for x, y in tqdm(loader, desc="Train", leave=False, disable=None):

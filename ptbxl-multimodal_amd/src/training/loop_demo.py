@@ -12,6 +12,7 @@ import torch
 
 from ecg_hip import functional as hipF
 from ecg_hip.graph import LoopStepper
+from ecg_hip.optim import adopt_stock_adamw
 from src.training.metrics import compute_metrics
 
 try:
@@ -40,6 +41,7 @@ def _eager_step(model, optimizer, x_ecg, x_demo, y, running):
 
 def train_one_epoch_demo(model, loader, optimizer, device):
     model.train()
+    optimizer = adopt_stock_adamw(optimizer)     # the scripts' torch.optim.AdamW steps through the fused flat launch
     stepper = LoopStepper.for_loop(model, optimizer, loss_weight_is_batch=False)
     running, batches = (None if stepper is None else stepper.running), 0
     for x_ecg, x_demo, y in tqdm(loader, desc="Train-ECG+Demo", leave=False, disable=None):

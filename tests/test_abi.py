@@ -83,6 +83,7 @@ def test_one_launch_batchnorm_backward_is_decided_per_call_from_the_parameters(m
     from ecg_hip import functional as F
     monkeypatch.setattr(F, "_bn_one_launch", True)
     monkeypatch.setattr(F, "_backward_collectives", {})
+    monkeypatch.setattr(F, "_collectives_by_ptr", None)
     a, b = torch.nn.Parameter(torch.zeros(3)), torch.nn.Parameter(torch.zeros(3))
     ka, kb = a.data_ptr(), b.data_ptr()
     assert F.bn_backward_one_launch_allowed(ka) and F.bn_backward_one_launch_allowed(kb)
@@ -98,6 +99,21 @@ def test_one_launch_batchnorm_backward_is_decided_per_call_from_the_parameters(m
     assert F.set_bn_backward_one_launch(False) is True
     assert not F.bn_backward_one_launch_allowed(ka) and not F.bn_backward_one_launch_allowed(kb)
     assert F.set_bn_backward_one_launch(True) is False
+    # statements follow the parameter OBJECT: an optimizer that re-homes the storage afterwards (FlatAdamW, the adopted stock
+    # AdamW) does not leave a wrapper's statement on a dead address, and an owner only withdraws what it said itself
+    from ecg_hip.optim import flatten_tensors_
+    monkeypatch.setattr(F, "_multi_rank", lambda: True)
+    F.declare_backward_collectives([a, b], False, owner="wrapper")
+    old = (a.data_ptr(), b.data_ptr())
+    flat = flatten_tensors_([a, b])
+    F.parameters_rehomed()               # (flatten_tensors_ calls it for device tensors)
+    assert a.data_ptr() == flat.data_ptr() and a.data_ptr() != old[0]
+    assert F.bn_backward_one_launch_allowed(a.data_ptr()) and F.bn_backward_one_launch_allowed(b.data_ptr())
+    assert not F.bn_backward_one_launch_allowed(old[1])           # the abandoned address is undeclared again
+    F.declare_backward_collectives([a, b], None, owner="optimizer")   # somebody else's withdrawal: no effect
+    assert F.bn_backward_one_launch_allowed(a.data_ptr())
+    F.declare_backward_collectives([id(a), id(b)], None, "wrapper")   # the finalizer's form: ids + the owner's token
+    assert not F.bn_backward_one_launch_allowed(a.data_ptr())
 
 
 def test_library_reads_no_environment_and_allocates_nothing():
