@@ -129,37 +129,114 @@ def main():
     # discrete decisions of the float64 run that a fp32 run takes differently: ReLU sign of the pooled maximum, and
     # which element of a pooling pair wins.  One flipped routing moves one dY element by one position: ~1/sqrt(terms)
     # of a channel's weight gradient — orders of magnitude above any rounding of the sums.
-    def decisions(m, args, hip):
+    # Round 5: every differing decision is ITEMISED — (block, n, c, j), the float64 margin between the two candidates,
+    # the float64 upstream gradient of that pooled output (a flip under a zero gradient changes nothing) and which runs
+    # take it differently.  The HIP path is looked at in BOTH of its forms: the fused ConvBlock launches the train step
+    # and the tests run (the BatchNorm input is re-derived block by block with the very kernels of the fused path: conv +
+    # statistics epilogue, the folded finalize arithmetic, bn_apply1), and the unfused leaves a hooked model takes
+    # (round 4 counted THOSE, through forward hooks on the BatchNorm modules, and printed them as "HIP").
+    def bn_outputs_by_hooks(m, args):
         zs, hs = [], []
-        bns = [b for b in m.modules() if isinstance(b, torch.nn.BatchNorm1d)]
-        for b in bns:
+        for b in (b for b in m.modules() if isinstance(b, torch.nn.BatchNorm1d)):
             hs.append(b.register_forward_hook(lambda mod, inp, o: zs.append(o.detach().cpu())))
         m.zero_grad()
         m(*args)
         for h in hs:
             h.remove()
-        res = []
-        for z in zs:
-            Lp = z.shape[2] // 2
-            pr = z[:, :, :2 * Lp].reshape(z.shape[0], z.shape[1], Lp, 2)
-            res.append(((pr[..., 1] > pr[..., 0]), (pr.max(-1).values > 0)))
-        return res
-    d64 = decisions(ref64, b64[:-1], False)
+        return zs
+
+    def bn_outputs_fused(m, args):
+        """BatchNorm outputs of the FUSED path: hooks on the ConvBlock modules only (a block stays one fused launch
+        sequence), then y / mean / invstd / z of each block from the same kernels on the captured block input."""
+        from src.models.ecg_cnn import ConvBlock
+        xs, hs = [], []
+        blocks = [b for b in m.modules() if isinstance(b, ConvBlock)]
+        for b in blocks:
+            hs.append(b.register_forward_hook(lambda mod, inp, o: xs.append(inp[0].detach())))
+        m.zero_grad()
+        m(*args)
+        for h in hs:
+            h.remove()
+        zs = []
+        for b, x in zip(blocks, xs):
+            conv, bn = b.net[0], b.net[1]
+            wf, _ = hipF.conv1d_pack(conv.weight.detach(), need_bwd=False)
+            y, part, P = hipF.conv1d_forward_raw(x.contiguous(), wf, conv.bias.detach(), conv.out_channels,
+                                                 conv.kernel_size[0], conv.padding[0], want_stats=True)
+            mean, invstd = hipF.bn_batch_stats(y, part, P, None, None, None, 0.1, bn.eps)
+            z = torch.empty_like(y)
+            L.call("ecg_bn_apply_fwd", L.f32(y), L.f32(bn.weight.detach()), L.f32(bn.bias.detach()), L.f32(mean),
+                   L.f32(invstd), L.f32(z), y.shape[0], y.shape[1], y.shape[2], L.stream())
+            zs.append(z.cpu())
+        return zs
+
+    def split(z):
+        Lp = z.shape[2] // 2
+        pr = z[:, :, :2 * Lp].reshape(z.shape[0], z.shape[1], Lp, 2)
+        return pr, (pr[..., 1] > pr[..., 0]), (pr.max(-1).values > 0)
+
+    # float64: BatchNorm outputs + the gradient that reaches every pooled output
+    dps = {}
+    pools64 = [m for m in ref64.modules() if isinstance(m, torch.nn.MaxPool1d)]
+    def grab_dp(i):
+        def fwd_hook(mod, inp, o):
+            o.register_hook(lambda g: dps.__setitem__(i, g.detach()))      # (returns None: the output is left alone)
+        return fwd_hook
+    hp = [pl.register_forward_hook(grab_dp(i)) for i, pl in enumerate(pools64)]
+    z64 = []
+    hb = [b.register_forward_hook(lambda mod, inp, o: z64.append(o.detach())) for b in ref64.modules()
+          if isinstance(b, torch.nn.BatchNorm1d)]
+    R.seed_all(a.seed)
+    fresh64 = None          # ref64 still has its initial parameters (no optimizer step ran): reuse it
+    ref64.zero_grad()
+    torch.nn.functional.binary_cross_entropy_with_logits(ref64(*b64[:-1]), b64[-1]).backward()
+    for h in hp + hb:
+        h.remove()
     R.seed_all(a.seed)
     fresh32 = rctor().train()          # (ref32 / model have taken a step's worth of BN statistics already: fresh copies)
-    d32 = decisions(fresh32, batch[:-1], False)
+    z32 = bn_outputs_by_hooks(fresh32, batch[:-1])
     set_seed(a.seed)
-    fresh_h = ctor().to(dev).train()
-    dh = decisions(fresh_h, db[:-1], True)
-    print("\ndecisions that differ from the float64 run (block: pooling winner where the maximum is active | ReLU sign of the maximum)")
-    for i in range(len(d64)):
-        a64, m64 = d64[i]
-        def cnt(d):
-            a, m = d[i]
-            return int(((a != a64) & m64 & m).sum()), int((m != m64).sum())
-        rh, rc = cnt(dh), cnt(d32)
-        print(f"block {i}: HIP {rh[0]:>4} | {rh[1]:>4}     CPU fp32 {rc[0]:>4} | {rc[1]:>4}     of {a64.numel()} pairs")
-        out.setdefault("decisions", []).append({"block": i, "hip": rh, "cpu_fp32": rc, "pairs": a64.numel()})
+    zh_fused = bn_outputs_fused(ctor().to(dev).train(), db[:-1])
+    set_seed(a.seed)
+    zh_leaf = bn_outputs_by_hooks(ctor().to(dev).train(), db[:-1])
+    runs = [("HIP fused", zh_fused), ("HIP hooked leaves", zh_leaf), ("CPU fp32", z32)]
+    print("\ndecisions that differ from the float64 run (block: pooling winner where the maximum is active | ReLU sign of the "
+          "maximum), and how many of them sit under a NON-ZERO float64 upstream gradient [live]")
+    items = []
+    for i in range(len(z64)):
+        pr64, a64, m64 = split(z64[i])
+        dp = dps[i]
+        row = f"block {i}:"
+        rec = {"block": i, "pairs": int(a64.numel())}
+        for name, zs in runs:
+            _, ar, mr = split(zs[i])
+            pool = (ar != a64) & m64 & mr
+            relu = (mr != m64)
+            live = int(((pool | relu) & (dp != 0)).sum())
+            row += f"   {name} {int(pool.sum()):>3} | {int(relu.sum()):>3} [{live} live]"
+            rec[name] = [int(pool.sum()), int(relu.sum()), live]
+            for kind, mask in (("pool", pool), ("relu", relu)):
+                for n, c, j in mask.nonzero().tolist():
+                    items.append((i, n, c, j, kind, name))
+        print(row + f"     of {a64.numel()} pairs")
+        out.setdefault("decisions", []).append(rec)
+    if items:
+        print("\nitemised (float64 values; margin = |a0 - a1| for a pooling flip, |max(a0, a1)| for a ReLU flip; "
+              "dp = float64 gradient of the loss w.r.t. that pooled output)")
+        print(f"{'block':>5} {'n':>4} {'c':>4} {'j':>5}  {'kind':<5} {'a0':>14} {'a1':>14} {'margin':>11} {'dp (float64)':>14}  flipped by")
+        seen = {}
+        for i, n, c, j, kind, name in items:
+            seen.setdefault((i, n, c, j, kind), []).append(name)
+        for (i, n, c, j, kind), who in sorted(seen.items()):
+            pr64, _, _ = split(z64[i])
+            a0, a1 = float(pr64[n, c, j, 0]), float(pr64[n, c, j, 1])
+            margin = abs(a0 - a1) if kind == "pool" else abs(max(a0, a1))
+            g = float(dps[i][n, c, j])
+            print(f"{i:>5} {n:>4} {c:>4} {j:>5}  {kind:<5} {a0:>14.6e} {a1:>14.6e} {margin:>11.3e} {g:>14.6e}  {', '.join(who)}")
+            out.setdefault("decision_items", []).append({"block": i, "n": n, "c": c, "j": j, "kind": kind, "a0": a0, "a1": a1,
+                                                         "margin": margin, "dp": g, "flipped_by": who})
+    else:
+        print("(no run takes any decision differently from float64)")
 
     print("\nend to end: first-step parameter gradients, rel-RMS error vs the float64 model")
     print(f"{'parameter':<40}{'HIP':>12}{'CPU fp32':>12}{'HIP/CPU':>9}")
