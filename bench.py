@@ -418,6 +418,7 @@ def input_pipeline_bench(B0, lengths, iters, cpu_seconds):
             for _ in ld:
                 pass
             torch.cuda.synchronize()
+            ld.stage_seconds.update(gather=0.0, enqueue=0.0, slot_wait=0.0, batches=0)      # (the warm-up epoch: page faults, allocator)
             t0 = time.perf_counter()
             cnt = 0
             for ep in range(3):
@@ -426,6 +427,35 @@ def input_pipeline_bench(B0, lengths, iters, cpu_seconds):
                     cnt += bt[0].shape[0]
             torch.cuda.synchronize()
             out["loader_windows_per_s_pcie_inclusive"] = round(cnt / (time.perf_counter() - t0), 1)
+            # where a batch's time goes: host gather (thread pool, out of the mapped file into the pinned slot), the H2D copy
+            # of its int16 samples alone (HIP events around one pinned -> device copy), the kernels (ms_per_batch above)
+            st, nb = ld.stage_seconds, max(1, ld.stage_seconds["batches"])
+            pinned = torch.empty((B, T, 12), dtype=torch.int16).pin_memory()
+            dst = torch.empty((B, T, 12), dtype=torch.int16, device="cuda")
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            dst.copy_(pinned, non_blocking=True)
+            torch.cuda.synchronize()
+            e0.record()
+            for _ in range(10):
+                dst.copy_(pinned, non_blocking=True)
+            e1.record()
+            torch.cuda.synchronize()
+            h2d = e0.elapsed_time(e1) / 10
+            out["loader_breakdown_ms_per_batch"] = {
+                "host_gather": round(st["gather"] / nb * 1e3, 4), "gather_threads": ld.gather_threads, "slots": ld.n_slots,
+                "slot_wait": round(st["slot_wait"] / nb * 1e3, 4), "enqueue": round(st["enqueue"] / nb * 1e3, 4),
+                "h2d_int16": round(h2d, 4), "h2d_GBps": round(B * T * 12 * 2 / (h2d * 1e-3) / 1e9, 1), "kernels": round(ms, 4)}
+            # the same epochs UNSHUFFLED: every batch is one contiguous run of the mapped file
+            ld2 = pack.PackedBatchLoader(path, B, shuffle=False)
+            for _ in ld2:
+                pass
+            torch.cuda.synchronize()
+            t0, cnt = time.perf_counter(), 0
+            for ep in range(3):
+                for bt in ld2:
+                    cnt += bt[0].shape[0]
+            torch.cuda.synchronize()
+            out["loader_windows_per_s_unshuffled"] = round(cnt / (time.perf_counter() - t0), 1)
         # CPU baseline: the reference's numpy arithmetic on a bounded sample (the only use of the oracle here)
         from oracle import input_oracle as io_ref
         t0, done = time.perf_counter(), 0

@@ -477,6 +477,12 @@ int ecg_wfdb16_zscore(const int16_t *d, const double *gain, const int *baseline,
 /* Per-lead z-score, (x-mean)/(std+1e-6) with population std.  x [rows][T] -> out [rows][T] (in place
  * allowed); stats [rows][2] receives (mean, std + 1e-6) per row. */
 int ecg_zscore_rows(const float *x, float *out, float *stats, int rows, int T, ecg_stream_t stream);
+/* HOST side of the same step — what torch's DataLoader collate does for the reference (one `Dataset.__getitem__` per record,
+ * src/datasets/ptbxl.py:25,122-127, stacked into a batch): rows `rows[0..n)` of a row-major host table (row_bytes each, e.g.
+ * the int16 records of a memory-mapped pack) copied to consecutive rows of `dst` (the pinned staging slot).  Plain memcpy
+ * per row, no thread, no allocation, no device call: the caller runs one call per gather thread on disjoint shares
+ * (ecg_hip/pack.py; ctypes drops the GIL for the duration, which a per-record numpy copy does not). */
+int ecg_host_gather_rows(const void *src, size_t row_bytes, const long long *rows, int n, void *dst);
 
 #ifdef __cplusplus
 }

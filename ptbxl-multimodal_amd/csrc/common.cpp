@@ -37,3 +37,18 @@ ECG_API int ecg_check_device(void) {
                          prop.gcnArchName);
     return ECG_OK;
 }
+
+ECG_API int ecg_host_gather_rows(const void *src, size_t row_bytes, const long long *rows, int n, void *dst) {
+    ECG_REQUIRE(n >= 0 && (n == 0 || (src && rows && dst && row_bytes > 0)), "host_gather_rows: n=%d row_bytes=%zu", n, row_bytes);
+    const char *s = static_cast<const char *>(src);
+    char *d = static_cast<char *>(dst);
+    int i = 0;
+    while (i < n) {                                    // consecutive records (an unshuffled epoch): one copy per run
+        ECG_REQUIRE(rows[i] >= 0, "host_gather_rows: negative row index %lld", rows[i]);
+        int j = i + 1;
+        while (j < n && rows[j] == rows[j - 1] + 1) ++j;
+        memcpy(d + (size_t)i * row_bytes, s + (size_t)rows[i] * row_bytes, (size_t)(j - i) * row_bytes);
+        i = j;
+    }
+    return ECG_OK;
+}

@@ -106,6 +106,7 @@ SIGNATURES = {
     "ecg_wfdb16_physical": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "ecg_wfdb16_zscore": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "ecg_zscore_rows": (_i, [_vp, _vp, _vp, _i, _i, _vp]),
+    "ecg_host_gather_rows": (_i, [_vp, _sz, _vp, _i, _vp]),
 }
 
 _lock = threading.Lock()

@@ -22,6 +22,7 @@ File layout (little-endian):
 """
 import json
 import os
+import time
 
 import numpy as np
 import torch
@@ -220,7 +221,7 @@ class PackedBatchLoader:
     wfdb16_to_windows); the consumer's stream waits on the batch's event."""
 
     def __init__(self, pack, batch_size, shuffle=False, seed=0, drop_last=False, device="cuda",
-                 rank=0, world_size=1, with_demo=None, normalize=True):
+                 rank=0, world_size=1, with_demo=None, normalize=True, gather_threads=None, slots=3):
         self.pack = pack if isinstance(pack, EcgPack) else EcgPack(pack)
         self.batch_size, self.shuffle, self.seed, self.drop_last = int(batch_size), shuffle, seed, drop_last
         self.rank, self.world_size = rank, world_size
@@ -236,6 +237,14 @@ class PackedBatchLoader:
         L.load()
         self._stream = torch.cuda.Stream(device=self.device)
         self._slots = None
+        # host gather: the records of a batch are copied out of the mapped file into the pinned slot by a small thread
+        # pool (numpy releases the GIL for these copies); round 4's single-threaded gather ran at 18.7 GB/s = 156 k
+        # windows/s of 12x5000, below the bf16 train step it feeds.  gather_threads=1 keeps everything on the caller.
+        self.gather_threads = max(1, int(gather_threads if gather_threads is not None
+                                         else min(8, (os.cpu_count() or 2) // 2)))
+        self.n_slots = max(2, int(slots))
+        self._pool = None
+        self.stage_seconds = {"gather": 0.0, "enqueue": 0.0, "slot_wait": 0.0, "batches": 0}
         self.dataset = _IteratedWindows(self)      # train_one_epoch / eval_one_epoch end with len(loader.dataset)
 
     def set_epoch(self, epoch):
@@ -252,7 +261,7 @@ class PackedBatchLoader:
     def _make_slots(self):
         p, B = self.pack, self.batch_size
         slots = []
-        for _ in range(2):
+        for _ in range(self.n_slots):
             s = {"d": torch.empty((B, p.T, p.leads), dtype=torch.int16).pin_memory(),
                  "gain": torch.empty((B, p.leads), dtype=torch.float64).pin_memory(),
                  "base": torch.empty((B, p.leads), dtype=torch.int32).pin_memory(),
@@ -268,14 +277,19 @@ class PackedBatchLoader:
         stream.  Returns (tensors..., ready_event)."""
         from . import functional as F
         p, b = self.pack, len(idx)
+        t0 = time.perf_counter()
         if slot["free"] is not None:
             slot["free"].synchronize()           # the H2D copies that last used this slot are done
-        dst = slot["d"].numpy()
-        for j, i in enumerate(idx):                   # one memcpy per record out of the mapped file: 3x the rate
-            dst[j] = p.samples[i]                     # numpy's fancy indexing reaches on rows this long
+        t1 = time.perf_counter()
+        self._gather_samples(slot["d"].numpy(), idx)
         for key, src in (("gain", p.gain), ("base", p.baseline), ("y", p.labels)) + \
                 ((("demo", p.demo),) if self.with_demo else ()):
             np.take(src, idx, axis=0, out=slot[key].numpy()[:b])
+        t2 = time.perf_counter()
+        st = self.stage_seconds
+        st["slot_wait"] += t1 - t0
+        st["gather"] += t2 - t1
+        st["batches"] += 1
         with torch.cuda.stream(self._stream):
             dev = {k: slot[k][:b].to(self.device, non_blocking=True)
                    for k in ("d", "gain", "base", "y") + (("demo",) if self.with_demo else ())}
@@ -285,8 +299,41 @@ class PackedBatchLoader:
             ready = torch.cuda.Event()
             ready.record(self._stream)
         slot["free"] = copied
+        st["enqueue"] += time.perf_counter() - t2
         out = (x, dev["demo"], dev["y"]) if self.with_demo else (x, dev["y"])
         return out, ready
+
+    def _gather_samples(self, dst, idx):
+        """int16 records `idx` of the mapped file -> rows 0.. of the pinned slot, by `ecg_host_gather_rows` (a memcpy per
+        run of consecutive records, GIL released for the whole call), the batch cut into contiguous shares for the gather
+        threads.  (Measured on the way: per-record numpy copies from a Python thread pool were SLOWER than one thread — 3.9 ms
+        against 0.6 ms per batch of 256 x 12x1000 — every copy hands the GIL over; numpy's fancy indexing reaches a third
+        of the memcpy rate on rows this long.)"""
+        src = self.pack.samples
+        idx = np.ascontiguousarray(idx, dtype=np.int64)
+        n, row = len(idx), src[0].nbytes
+        if n == 0:
+            return
+        if idx.min() < 0 or idx.max() >= len(src):
+            raise IndexError("PackedBatchLoader: record index out of range")
+        lib = L.load()
+        s_ptr, d_ptr, i_ptr = src.ctypes.data, dst.ctypes.data, idx.ctypes.data
+
+        def work(a, b):
+            rc = lib.ecg_host_gather_rows(s_ptr, row, i_ptr + 8 * a, b - a, d_ptr + a * row)
+            if rc != 0:
+                raise L.EcgHipError(f"ecg_host_gather_rows failed: {L.last_error()}")
+        W = min(self.gather_threads, n, max(1, (n * row) >> 20))         # at least ~1 MB per share
+        if W <= 1:
+            return work(0, n)
+        cuts = [n * k // W for k in range(W + 1)]
+        if self._pool is None:
+            from concurrent.futures import ThreadPoolExecutor
+            self._pool = ThreadPoolExecutor(max_workers=self.gather_threads, thread_name_prefix="ecgpack-gather")
+        futs = [self._pool.submit(work, cuts[k], cuts[k + 1]) for k in range(1, W)]
+        work(cuts[0], cuts[1])
+        for f in futs:
+            f.result()
 
     def __iter__(self):
         if self._slots is None:
@@ -297,7 +344,7 @@ class PackedBatchLoader:
         batches = [order[i * B:(i + 1) * B] for i in range(nb)]
         pending = None
         for i, idx in enumerate(batches):
-            staged = self._stage(self._slots[i % 2], idx)
+            staged = self._stage(self._slots[i % self.n_slots], idx)
             if pending is not None:
                 yield self._hand_over(pending)
             pending = staged

@@ -193,3 +193,33 @@ def test_loader_refuses_cpu(tmp_path):
             pack.PackedBatchLoader(path, 4, device="cuda")
     with pytest.raises(EcgHipError, match="prepares batches on the GPU"):
         pack.PackedBatchLoader(path, 4, device="cpu")
+
+
+def test_loader_gather_through_the_native_row_copy(tmp_path):
+    """The host side of PackedBatchLoader._stage without a GPU: records -> pinned slot through ecg_host_gather_rows (a
+    stateless memcpy loop of libecg_hip.so, one call per gather thread); any thread count gives the same bytes, runs of
+    consecutive records included, and a bad index is refused before anything is copied."""
+    L = pack.PackedBatchLoader
+    rng = np.random.default_rng(0)
+    samples = rng.integers(-3000, 3000, size=(64, 20000, 12)).astype(np.int16)     # 480 KB per record: the pool is used
+
+    class FakePack:
+        pass
+    for idx in (np.arange(8, 40), rng.permutation(64)[:37], np.array([3]), np.array([7, 8, 9, 1, 2, 60, 61, 62, 63, 0]),
+                np.array([], dtype=np.int64)):
+        want = samples[idx]
+        for threads in (1, 2, 5, 8):
+            ld = object.__new__(L)
+            ld.pack, ld.gather_threads, ld._pool = FakePack(), threads, None
+            ld.pack.samples = samples
+            dst = np.zeros((40, 20000, 12), np.int16)
+            ld._gather_samples(dst, idx)
+            assert np.array_equal(dst[:len(idx)], want) and not dst[len(idx):].any(), (len(idx), threads)
+            if ld._pool is not None:
+                ld._pool.shutdown()
+    ld = object.__new__(L)
+    ld.pack, ld.gather_threads, ld._pool = FakePack(), 2, None
+    ld.pack.samples = samples
+    for bad in ([0, 64], [-1, 3]):
+        with pytest.raises(IndexError):
+            ld._gather_samples(np.zeros((4, 20000, 12), np.int16), np.array(bad))
