@@ -43,17 +43,14 @@ PEAK_BF16_TFLOPS = 2500.0    # dense bf16 MFMA
 PEAK_HBM_GBS = 8000.0
 CONV_GEOM = [(12, 32), (32, 64), (64, 128), (128, 256)]
 FWD, DGRAD, WGRAD = "fwd", "dgrad", "wgrad"
-CONV_ENTRY = {"ecg_conv1d_fwd": (FWD, "f32"), "ecg_conv1d_fwd_bf16": (FWD, "bf16"),
+CONV_ENTRY = {"ecg_conv1d_fwd": (FWD, "f32"),
               "ecg_conv1d_bwd_data": (DGRAD, "f32"), "ecg_conv1d_bwd_data_ld": (DGRAD, "f32"),
-              "ecg_conv1d_bwd_data_bf16": (DGRAD, "bf16"), "ecg_conv1d_bwd_data_bf16h": (DGRAD, "bf16"),
               "ecg_conv1d_bwd_weight_bias": (WGRAD, "f32"), "ecg_conv1d_bwd_weight_bias_ld": (WGRAD, "f32"),
-              "ecg_conv1d_bwd_weight_bias_bf16": (WGRAD, "bf16"), "ecg_conv1d_bwd_weight_bias_bf16_packed": (WGRAD, "bf16"),
               "ecg_conv1d_fwd_bf16_yh": (FWD, "bf16"), "ecg_conv1d_bwd_data_bf16hh": (DGRAD, "bf16"),
               "ecg_conv1d_bwd_weight_bias_bf16_ncl": (WGRAD, "bf16")}
 # bytes per element of the two activation operands an entry point streams (reduction-side tensor, result-side tensor);
 # everything not listed reads and writes fp32.  ecg_conv1d_fwd_bf16_yh reads fp32 only for the network input (x_bf16 = 0).
-IO_BYTES = {"ecg_conv1d_bwd_data_bf16h": (4, 2), "ecg_conv1d_bwd_weight_bias_bf16_packed": (2, 2),
-            "ecg_conv1d_bwd_data_bf16hh": (2, 2), "ecg_conv1d_bwd_weight_bias_bf16_ncl": (2, 2)}
+IO_BYTES = {"ecg_conv1d_bwd_data_bf16hh": (2, 2), "ecg_conv1d_bwd_weight_bias_bf16_ncl": (2, 2)}
 
 
 # ------------------------------------------------------------------------------------------------

@@ -121,96 +121,52 @@ int ecg_conv1d_bwd_weight_bias(const float *dy, const float *x, float *dw, float
                                ecg_stream_t stream);
 
 /* ---- mixed precision (opt-in; BASELINE.json config 5: AF binary 12x5000, bf16) ----------------
- * Forward and input-grad with bf16 operands on the matrix cores (fp32 accumulate, fp32
- * activations in HBM); the weight gradient has its own bf16 entry point below (C_out % 32 == 0)
- * and otherwise stays on ecg_conv1d_bwd_weight_bias (fp32).
+ * ONE form (round 5): a training ConvBlock runs its three convs with bf16 operands on the matrix cores (fp32 accumulate)
+ * and keeps every tensor BETWEEN its kernels as bf16 rows [N][C][ld] — what torch.autocast stores too; the BatchNorm passes
+ * are HBM-bound and these are their operands:
+ *   y   conv output        bf16 [N][C][ldy], ldy % 8 == 0 (ecg_conv1d_fwd_bf16_yh; the BatchNorm statistics are taken over
+ *                          the ROUNDED values, i.e. over the tensor the passes read)
+ *   p   pooled activation  bf16 [N][C][ldp], rows zero-filled from L/2 to ldp (ecg_bn_stats_relu_pool_fwd_h) — read by the
+ *                          next block's ecg_conv1d_fwd_bf16_yh (x_bf16 != 0) and by its weight gradient
+ *   dY  conv output grad   bf16 [N][C][ldt], rows zero-filled to a multiple of 128 (ecg_bn_relu_pool_bwd_h) — read by the
+ *                          weight gradient (ecg_conv1d_bwd_weight_bias_bf16_ncl) and the input gradient (..._bf16hh)
+ *   dp  gradient of p      bf16 [N][C][ldp] (ecg_conv1d_bwd_data_bf16hh of the next block) — read by ecg_bn_relu_pool_bwd_h
+ * Parameters, statistics, parameter gradients, the network input (fp32, read by block 0 and rounded while it is staged) and
+ * the tail stay fp32.  Everything that does not fit (eval / frozen BatchNorm, other kernel sizes or channel counts, an fp32
+ * input that needs an input gradient) runs the fp32 entry points above: there is no second bf16 form.  (Rounds 2-4 also
+ * shipped fp32-activation variants and a sample-on-K weight gradient with its "n16" operand copies; removed in round 5.)
  * Packed weights are bf16: wb_fwd [ceil(C_in/16)][K][C_out][16], wb_bwd [ceil(C_out/16)][K][C_in][16]
  * (tap-flipped), ecg_conv1d_bf16_packed_elems(C_reduce, C_result, K) 2-byte elements each.
- * K must be 15; forward needs C_in % 4 == 0 and C_out % 32 == 0, the input-grad the same with the
- * roles swapped.  ecg_conv1d_bf16_supported returns a bit mask: 1 = forward, 2 = input-grad, 4 = weight-grad. */
+ * K must be 15; forward needs C_in % 4 == 0 and C_out % 32 == 0, the input-grad the same with the roles swapped, the weight
+ * gradient K == 15, pad == 7, C_out % 32 == 0.  ecg_conv1d_bf16_supported returns a bit mask: 1 = forward, 2 = input-grad,
+ * 4 = weight-grad.  Same reference call sites as the fp32 entry points: src/models/ecg_cnn.py:13-16 and their autograd. */
 int ecg_conv1d_bf16_supported(int C_in, int C_out, int K, int pad);
-/* Weight gradient with bf16 operands (bit 2 of ecg_conv1d_bf16_supported: K == 15, pad == 7,
- * C_out % 32 == 0): dY and x are re-laid as [sample group of 16][channel][time][16] bf16 inside the
- * workspace, the MFMA reduces over 16 samples per step; dW / db come out in fp32 (db from the bf16-rounded
- * dY).  dy rows at stride ldy >= Lo.  Workspace in floats from the _ws_floats helper, 16-byte aligned. */
-size_t ecg_conv1d_bwd_weight_bf16_ws_floats(int N, int C_in, int C_out, int L, int K, int pad);
-int ecg_conv1d_bwd_weight_bias_bf16(const float *dy, int ldy, const float *x, float *dw, float *db,
-                                    float *ws, int N, int C_in, int C_out, int L, int K, int pad,
-                                    ecg_stream_t stream);
 size_t ecg_conv1d_bf16_packed_elems(int C_reduce, int C_result, int K);
 int ecg_conv1d_pack_weights_bf16(const float *w, void *wb_fwd, void *wb_bwd, int C_out, int C_in,
                                  int K, ecg_stream_t stream);
-int ecg_conv1d_fwd_bf16_stat_partials(int N, int C_in, int C_out, int L, int K, int pad);
-int ecg_conv1d_fwd_bf16(const float *x, const void *wb_fwd, const float *bias, float *y,
-                        float *stat_partials, int N, int C_in, int C_out, int L, int K, int pad,
-                        ecg_stream_t stream);
-int ecg_conv1d_bwd_data_bf16(const float *dy, const void *wb_bwd, float *dx, int N, int C_in,
-                             int C_out, int L, int K, int pad, ecg_stream_t stream);
-/* The weight gradient's operand layout, written by the PRODUCERS instead of by packing passes: "n16" = bf16
- * [sample group of 16][channel][position][16 samples], zero outside the row and past N.
- *   ecg_conv1d_n16_positions(L, K, pad, which): positions per row of the dY operand (which = 0: PA = Lo rounded up
- *     to 16) and of the x operand (which = 1: PX = PA + 16; x[.., t] sits at position t + pad, i.e. the conv's zero
- *     padding is part of the layout).  0 when the shape is not served (K != 15 or pad != 7).
- *   ecg_pack_n16: fp32 [N][C][ld] -> n16 with P positions, element t at position t + shift (the first layer's input).
- *   ecg_bn_relu_pool_fwd_n16: ecg_bn_relu_pool_fwd that ALSO writes the pooled activation as the next layer's x
- *     operand (p may be NULL when only the n16 form is wanted).
- *   ecg_bn_relu_pool_bwd_n16: ecg_bn_relu_pool_bwd_ld (gap != 0: ..._gap_bwd_ld) that ALSO writes dY as the dY
- *     operand; dy may be NULL when no fp32 dY is wanted (first layer, or when dy_bf16 feeds the input gradient).
- *   ecg_conv1d_bwd_weight_bias_bf16_packed: the weight gradient on operands already in that layout; workspace
- *     (slabs only) from ecg_conv1d_bwd_weight_bf16_packed_ws_floats. */
-int ecg_conv1d_n16_positions(int L, int K, int pad, int which);
-int ecg_pack_n16(const float *src, void *dst, int N, int C, int ld, int L, int P, int shift,
-                 ecg_stream_t stream);
-int ecg_bn_relu_pool_fwd_n16(const float *y, const float *gamma, const float *beta, const float *mean,
-                             const float *invstd, float *p, void *p_n16, int N, int C, int L, int PX,
-                             int shift, ecg_stream_t stream);
-int ecg_bn_relu_pool_bwd_n16(const float *y, const float *dp, const float *gamma, const float *beta,
-                             const float *mean, const float *invstd, float *dy, int ldy, void *dy_n16,
-                             int PA, float *dgamma, float *dbeta, float *ws, int N, int C, int L,
-                             int train, int gap, void *dy_bf16, ecg_stream_t stream);
-/* dy_bf16 (may be NULL): dY once more as bf16 [N][C][PA] (rows zero-filled past L) for ecg_conv1d_bwd_data_bf16h, the
- * input gradient that reads a bf16 dY (ldy even, K-1-pad odd): half the bytes of the fp32 dY on both sides. */
-int ecg_conv1d_bwd_data_bf16h(const void *dy_bf16, int ldy, const void *wb_bwd, float *dx, int N, int C_in,
-                              int C_out, int L, int K, int pad, ecg_stream_t stream);
-/* bf16 ACTIVATION STORAGE for the mixed-precision train step (what torch.autocast stores too): the tensors BETWEEN the
- * kernels of a training block chain are kept as bf16 — the BatchNorm passes are HBM-bound and these are their operands.
- *   y   conv output:            bf16 [N][C][ldy], ldy even >= L (ecg_conv1d_fwd_bf16_yh; the BatchNorm statistics are
- *       taken over the ROUNDED values, i.e. over the tensor the passes read)
- *   p   pooled activation:      bf16 [N][C][ldp], rows zero-filled from L/2 to ldp (ecg_bn_stats_relu_pool_fwd_yh, mode 2,
- *       p_bf16 non-NULL; the fp32 `out` may then be NULL) — read by the next block's ecg_conv1d_fwd_bf16_yh (x_bf16 != 0)
- *   dp  gradient of p:          bf16 [N][C][ldp] (ecg_conv1d_bwd_data_bf16hh of the next block) — read by
- *       ecg_bn_relu_pool_bwd_n16_yh (dp_bf16 != 0)
- * ecg_bn_stats_relu_pool_fwd_yh = ecg_bn_stats_relu_pool_fwd modes 1 / 2 and ecg_bn_relu_pool_bwd_n16_yh =
- * ecg_bn_relu_pool_bwd_n16 on such tensors: bit-identical to the fp32-input passes run on the rounded values. */
+/* Train-mode forward: x fp32 [N][C_in][L] (x_bf16 == 0, ldx ignored) or bf16 [N][C_in][ldx] with rows zero-filled from L to
+ * ldx, ldx even, pad odd (x_bf16 != 0) -> y_bf16 [N][C_out][ldy] (+ bias) and the BatchNorm statistics partials
+ * [C_out][P][2] = (sum, sum of squares) over the rounded values. */
 int ecg_conv1d_fwd_bf16_yh(const void *x, int x_bf16, int ldx, const void *wb_fwd, const float *bias, void *y_bf16,
                            int ldy, float *stat_partials, int N, int C_in, int C_out, int L, int K, int pad,
                            ecg_stream_t stream);
 /* How many (sum, sum^2) partials per channel ecg_conv1d_fwd_bf16_yh writes for exactly these arguments — ALWAYS size
- * stat_partials with this query, never with ecg_conv1d_fwd_bf16_stat_partials.  Long rows with bf16 on both sides
- * (x_bf16 != 0, ldy % 8 == 0) take the round-3 ring kernel (csrc/conv1d_bf16_ring.hip: 640 / 1280 time steps per
- * workgroup, weights through an LDS-DMA ring, transposed accumulators), and so does the fp32 network input (x_bf16 == 0)
- * of at most 16 channels on rows of even length where 512-step tiles pad no more than 256-step ones (one chunk per
- * tile, weights resident, two workgroups per CU); their workgroup counts differ from the kernel behind
- * ecg_conv1d_fwd_bf16_stat_partials.  Same reference call site: src/models/ecg_cnn.py:13-14. */
+ * stat_partials with this query.  Long rows with bf16 on both sides (x_bf16 != 0, ldy % 8 == 0) take the round-3 ring kernel
+ * (csrc/conv1d_bf16_ring.hip: 640 / 1280 time steps per workgroup, weights through an LDS-DMA ring, transposed
+ * accumulators), and so does the fp32 network input (x_bf16 == 0) of at most 16 channels on rows of even length where
+ * 512-step tiles pad no more than 256-step ones (one chunk per tile, weights resident, two workgroups per CU); everything
+ * else the round-2 kernel of csrc/conv1d_mfma_bf16.hip, with other workgroup counts. */
 int ecg_conv1d_fwd_bf16_yh_stat_partials(int N, int C_in, int C_out, int L, int K, int pad, int x_bf16, int ldx, int ldy);
 /* Which kernel a conv with bf16 tensors on both sides takes (ecg_conv1d_fwd_bf16_yh with x_bf16 != 0: C_red = C_in,
  * C_res = C_out, pad; ecg_conv1d_bwd_data_bf16hh: C_red = C_out, C_res = C_in, pad = K-1-pad): the ring kernel's time
  * steps per workgroup tile (640 / 1280), or 0 = the round-2 kernel of conv1d_mfma_bf16.hip.  Tests and profiles. */
 int ecg_conv1d_bf16_ring_tile(int N, int C_red, int C_res, int L_out, int K, int pad, int ld_in, int ld_out);
-int ecg_bn_stats_relu_pool_fwd_yh(const float *stat_partials, int P, long long count, float *running_mean,
-                                  float *running_var, long long *num_batches_tracked, float momentum, float eps,
-                                  const void *y_bf16, int ldy, const float *gamma, const float *beta, float *mean,
-                                  float *invstd, float *out, void *p_n16, void *p_bf16, int ldp, int N, int C, int L,
-                                  int PX, int shift, int mode, ecg_stream_t stream);
-int ecg_bn_relu_pool_bwd_n16_yh(const void *y_bf16, int ldyy, const void *dp, int dp_bf16, int ldp, const float *gamma,
-                                const float *beta, const float *mean, const float *invstd, float *dy, int ldy,
-                                void *dy_n16, int PA, float *dgamma, float *dbeta, float *ws, int N, int C, int L,
-                                int train, int gap, void *dy_bf16, ecg_stream_t stream);
-/* The same passes on bf16 [N][C][ld] tensors ONLY (round 4, csrc/bn_relu_pool_h.hip; 16 bytes per lane, no n16 copies — the
- * producers of the time-on-K weight gradient ecg_conv1d_bwd_weight_bias_bf16_ncl):
+/* The BatchNorm passes on bf16 [N][C][ld] tensors (csrc/bn_relu_pool_h.hip; 16 bytes per lane in and out):
  *   ecg_bn_stats_relu_pool_fwd_h: statistics combine + BN + ReLU + MaxPool(2): y_bf16 [N][C][ldy] -> p_bf16 [N][C][ldp], rows
  *     zero-filled from L/2 to ldp (ldy, ldp multiples of 8); mean / invstd are outputs, running statistics and the counter
  *     are updated as by ecg_bn_stats_relu_pool_fwd.
+ *   ecg_bn_stats_relu_pool_gap_fwd_yh: the same with the global average pool of the last block folded in:
+ *     y_bf16 [N][C][ldy] (ldy even) -> out fp32 [N][C] (csrc/bn_relu_pool.hip).
  *   ecg_bn_relu_pool_bwd_h: reduction pass + dx pass: dp bf16 [N][C][ldp] (dp_kind 0), fp32 dg [N][C] of the fused global
  *     average pool (1) or fp32 dp [N][C][ldp] (2) -> dy_bf16 [N][C][ldy]
  *     with rows zero-filled from L to ldy (give ldy = ecg_conv1d_bf16_tk_dy_stride(L)), dgamma, dbeta; ws from
@@ -219,28 +175,31 @@ int ecg_bn_stats_relu_pool_fwd_h(const float *stat_partials, int P, long long co
                                  float *running_var, long long *num_batches_tracked, float momentum, float eps,
                                  const void *y_bf16, int ldy, const float *gamma, const float *beta, float *mean,
                                  float *invstd, void *p_bf16, int ldp, int N, int C, int L, ecg_stream_t stream);
+int ecg_bn_stats_relu_pool_gap_fwd_yh(const float *stat_partials, int P, long long count, float *running_mean,
+                                      float *running_var, long long *num_batches_tracked, float momentum, float eps,
+                                      const void *y_bf16, int ldy, const float *gamma, const float *beta, float *mean,
+                                      float *invstd, float *out, int N, int C, int L, ecg_stream_t stream);
 int ecg_bn_relu_pool_bwd_h(const void *y_bf16, int ldyy, const void *dp, int dp_kind, int ldp, const float *gamma,
                            const float *beta, const float *mean, const float *invstd, void *dy_bf16, int ldy,
                            float *dgamma, float *dbeta, float *ws, int N, int C, int L, int train,
                            ecg_stream_t stream);
+/* Input gradient from the bf16 dY (ldy even, K-1-pad odd) to dx as bf16 [N][C_in][ldx] (ldx even, >= L): the dp the previous
+ * block's ecg_bn_relu_pool_bwd_h reads. */
 int ecg_conv1d_bwd_data_bf16hh(const void *dy_bf16, int ldy, const void *wb_bwd, void *dx_bf16, int ldx, int N,
                                int C_in, int C_out, int L, int K, int pad, ecg_stream_t stream);
-/* Weight + bias gradient on the bf16 tensors the other two convs read — TIME on the MFMA's K axis, no n16 copies (round 4,
+/* Weight + bias gradient on the bf16 tensors the other two convs read — TIME on the MFMA's K axis (round 4,
  * csrc/conv1d_wgrad_bf16_tk.hip): dy_bf16 [N][C_out][ldy] with ldy = ecg_conv1d_bf16_tk_dy_stride(Lo) (rows zero-filled to a
  * multiple of 128), x either bf16 [N][C_in][ldx] (x_is_bf16 != 0: ldx % 8 == 0, rows zero-filled past L — the previous
- * block's pooled activation as ecg_bn_stats_relu_pool_fwd_yh writes it) or the fp32 network input [N][C_in][ldx] (L % 8 == 0),
+ * block's pooled activation as ecg_bn_stats_relu_pool_fwd_h writes it) or the fp32 network input [N][C_in][ldx] (L % 8 == 0),
  * rounded to bf16 while it is staged.  K == 15, pad == 7, C_out % 32 == 0 (ecg_conv1d_bf16_tk_supported).  Exact on the
- * bf16-rounded operands up to fp32 accumulation order.  Same reference call site as ecg_conv1d_bwd_weight_bias. */
+ * bf16-rounded operands up to fp32 accumulation order; split partial slabs in ws are summed in a fixed order.  Same
+ * reference call site as ecg_conv1d_bwd_weight_bias. */
 int ecg_conv1d_bf16_tk_supported(int C_in, int C_out, int K, int pad);
 int ecg_conv1d_bf16_tk_dy_stride(int Lo);
 size_t ecg_conv1d_bwd_weight_bf16_ncl_ws_floats(int N, int C_in, int C_out, int L, int K, int pad);
 int ecg_conv1d_bwd_weight_bias_bf16_ncl(const void *dy_bf16, int ldy, const void *x, int x_is_bf16, int ldx,
                                         float *dw, float *db, float *ws, int N, int C_in, int C_out, int L,
                                         int K, int pad, ecg_stream_t stream);
-size_t ecg_conv1d_bwd_weight_bf16_packed_ws_floats(int N, int C_in, int C_out, int L, int K, int pad);
-int ecg_conv1d_bwd_weight_bias_bf16_packed(const void *dy_n16, const void *x_n16, float *dw, float *db,
-                                           float *ws, int N, int C_in, int C_out, int L, int K, int pad,
-                                           ecg_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
  * BatchNorm1d / ReLU / MaxPool1d(2) — ConvBlock.net[1..3]: src/models/ecg_cnn.py:14-16.
@@ -270,13 +229,11 @@ int ecg_bn_relu_pool_fwd(const float *y, const float *gamma, const float *beta,
 /* ecg_bn_finalize + BN-apply + ReLU + MaxPool(2) in ONE launch: the statistics combine is folded into the streaming
  * pass (every workgroup re-derives mean / invstd of its channel from the P partials — same arithmetic and bits as
  * ecg_bn_finalize — one workgroup per channel stores them and updates running statistics / counter).  mean and
- * invstd are OUTPUTS.  mode 0: out = p [N][C][L/2]; mode 1: + global average pool, out = g [N][C]; mode 2: out = p
- * (may be NULL) and p_n16 = the bf16 "n16" copy with PX positions at `shift` (mixed precision, see below). */
+ * invstd are OUTPUTS.  mode 0: out = p [N][C][L/2]; mode 1: + global average pool, out = g [N][C]. */
 int ecg_bn_stats_relu_pool_fwd(const float *stat_partials, int P, long long count, float *running_mean,
                                float *running_var, long long *num_batches_tracked, float momentum, float eps,
                                const float *y, const float *gamma, const float *beta, float *mean,
-                               float *invstd, float *out, void *p_n16, int N, int C, int L, int PX, int shift,
-                               int mode, ecg_stream_t stream);
+                               float *invstd, float *out, int N, int C, int L, int mode, ecg_stream_t stream);
 
 /* ONE-LAUNCH form of ecg_bn_relu_pool_bwd_ld / ecg_bn_relu_pool_gap_bwd_ld (same reference call site: autograd of
  * ConvBlock.net[1..3], src/models/ecg_cnn.py:14-16): when the (dp, y) slice of a block fits the register file of the

@@ -249,12 +249,12 @@ __device__ __forceinline__ bool pool_route(float y0, float y1, float mu, float s
 // otherwise da = dout (plain BatchNorm backward).  grid = (C, S).
 // bcast != 0 (FUSED only): dp[row][j] = g[row] * bcast for every j — the gradient of a global
 // average pool that was fused behind the max-pool (g = dG [N*C], bcast = 1/Lp).
-template <bool FUSED, bool AL8, bool YH = false, bool DH = false>
+template <bool FUSED, bool AL8>
 __global__ __launch_bounds__(kBlock) void bn_bwd_reduce_kernel(
     const float *__restrict__ y, const float *__restrict__ g, const float *__restrict__ gamma,
     const float *__restrict__ beta, const float *__restrict__ mean,
     const float *__restrict__ invstd, float *__restrict__ partials, int N, int C, int L, int S,
-    float bcast, int ldyy, int ldp) {
+    float bcast) {
     __shared__ float red[4][2];
     const int c = blockIdx.x, s = blockIdx.y, tl = threadIdx.x;
     const int n0 = (int)((long long)N * s / S), n1 = (int)((long long)N * (s + 1) / S);
@@ -279,12 +279,10 @@ __global__ __launch_bounds__(kBlock) void bn_bwd_reduce_kernel(
             const int nl = ic / per, j = ic - nl * per;
             const size_t row = (size_t)(n0 + nl) * C + c;
             if (FUSED) {
-                ld_pair_y<AL8, YH>(y, row, ldyy, 2 * j, y0[u], y1[u]);
-                if (DH)         // dp is bf16 [N][C][ldp] (the next block's input gradient, written as bf16)
-                    d[u] = __uint_as_float((unsigned)reinterpret_cast<const unsigned short *>(g)[row * ldp + j] << 16);
-                else d[u] = bcast != 0.f ? g[row] * bcast : g[row * Lp + j];
+                ld_pair<AL8>(y + row * L + 2 * j, y0[u], y1[u]);
+                d[u] = bcast != 0.f ? g[row] * bcast : g[row * Lp + j];
             } else {
-                y0[u] = y[row * ldyy + j]; y1[u] = 0.f;
+                y0[u] = y[row * L + j]; y1[u] = 0.f;
                 d[u] = g[row * L + j];
             }
         }
@@ -614,158 +612,6 @@ __global__ __launch_bounds__(kResThreads) void bn_bwd_resident_kernel(
 }
 
 // ---------------------------------------------------------------------------------------
-// mixed-precision producers: the same two passes, ALSO emitting their result in the layout the bf16
-// weight-gradient kernel consumes (conv1d_wgrad_bf16.hip): bf16 [sample group of 16][channel][position][16 samples]
-// ("n16"), zero-filled outside the row and past N.  That removes the separate fp32 -> n16 packing passes
-// (a read of the fp32 tensor + a write each) from the bf16 train step.
-// thread <-> (group g, channel c, position): 16 samples per thread, 32 contiguous bytes per store, adjacent lanes
-// adjacent positions.
-// ---------------------------------------------------------------------------------------
-typedef unsigned short u16n;
-typedef unsigned u32x4n __attribute__((ext_vector_type(4)));
-
-__device__ __forceinline__ unsigned pack2n(float lo, float hi) {
-    const u16n a = __builtin_bit_cast(u16n, (__bf16)lo), b = __builtin_bit_cast(u16n, (__bf16)hi);
-    return (unsigned)a | ((unsigned)b << 16);
-}
-__device__ __forceinline__ void store_n16(u16n *dst, const float *v) {
-    u32x4n lo, hi;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        lo[q] = pack2n(v[2 * q], v[2 * q + 1]);
-        hi[q] = pack2n(v[8 + 2 * q], v[8 + 2 * q + 1]);
-    }
-    u32x4n *o = reinterpret_cast<u32x4n *>(dst);
-    o[0] = lo;
-    o[1] = hi;
-}
-
-// p [N][C][Lp] fp32 (may be NULL) and pb[g][c][pos][16] with pb[.., j + shift, s] = p[16g + s][c][j].
-// grid = (ceil(PX/256), C, G)  (an item loop over one round of resident workgroups, as the fp32 passes use, measured
-// SLOWER here: 38.0 vs 34.1 us at 12x5000 — these kernels keep 16-32 loads per lane in flight and want the parallelism)
-template <bool FIN, bool AL8, bool YH = false>
-__global__ __launch_bounds__(kBlock) void bn_relu_pool_fwd_n16_kernel(
-    const float *__restrict__ y, const float *__restrict__ gamma, const float *__restrict__ beta,
-    const float *__restrict__ mean, const float *__restrict__ invstd, float *__restrict__ p,
-    u16n *__restrict__ pb, int N, int C, int L, int Lp, int PX, int shift, BnFin fin, int ldyy,
-    u16n *__restrict__ ph, int ldp) {
-    // grid = (ceil(G * PX / 256), C): the (sample group, position) pairs of a channel are walked FLAT — a grid of
-    // ceil(PX / 256) blocks per group left up to a third of the threads idle on the short rows of the deep blocks
-    // (PX = 656: 3 blocks = 768 threads)
-    const int flat = blockIdx.x * kBlock + threadIdx.x, c = blockIdx.y;
-    const int g = flat / PX, pos = flat - g * PX;
-    float mu, is;
-    if (FIN) bn_finalize_block(fin, c, blockIdx.x == 0, mu, is);
-    else { mu = mean[c]; is = invstd[c]; }
-    if (g >= (N + 15) / 16) return;
-    const float sc = is * gamma[c], be = beta[c];
-    const int j = pos - shift;
-    const bool in_row = (j >= 0) && (j < Lp);
-    const int jc = min(max(j, 0), Lp - 1);
-    float y0[16], y1[16];
-#pragma unroll
-    for (int s = 0; s < 16; ++s)                     // 16 unconditional, clamped pair loads in flight
-        ld_pair_y<AL8, YH>(y, (size_t)min(16 * g + s, N - 1) * C + c, ldyy, 2 * jc, y0[s], y1[s]);
-    __builtin_amdgcn_sched_barrier(0);
-    float v[16];
-#pragma unroll
-    for (int s = 0; s < 16; ++s) {
-        const float a0 = bn_apply1(y0[s], mu, sc, be), a1 = bn_apply1(y1[s], mu, sc, be);
-        float m = a1 > a0 ? a1 : a0;
-        m = m > 0.f ? m : 0.f;
-        const bool live = in_row && 16 * g + s < N;
-        v[s] = live ? m : 0.f;
-        if (live && p) p[((size_t)(16 * g + s) * C + c) * Lp + j] = m;
-        // ph: p once more as bf16 [N][C][ldp] with the rows zero-filled from Lp to ldp — the NEXT conv's forward input
-        // (it reads half the bytes of the fp32 p, which is then not written at all)
-        if (ph && 16 * g + s < N && j >= 0 && j < ldp)
-            ph[((size_t)(16 * g + s) * C + c) * ldp + j] = __builtin_bit_cast(u16n, (__bf16)v[s]);
-    }
-    store_n16(pb + (((size_t)g * C + c) * PX + pos) * 16, v);
-}
-
-// dy [N][C][ldy] fp32 (may be NULL: the first layer has no input gradient) and dyb[g][c][t][16], t < PA, zero
-// past the row; the combine of the S reduce partials is folded in as in bn_bwd_dx_kernel.
-// grid = (ceil(PA/2/256), C, G); thread <-> output pair (2j, 2j+1) of the 16 samples of group g.
-template <bool AL8, bool YH = false, bool DH = false>
-__global__ __launch_bounds__(kBlock) void bn_bwd_dx_n16_kernel(
-    const float *__restrict__ y, const float *__restrict__ g_in, const float *__restrict__ gamma,
-    const float *__restrict__ beta, const float *__restrict__ mean, const float *__restrict__ invstd,
-    const float *__restrict__ partials, int S, double M, float *__restrict__ dgamma,
-    float *__restrict__ dbeta, float *__restrict__ dy, int ldy, u16n *__restrict__ dyb, int PA, int N,
-    int C, int L, float bcast, int train, unsigned *__restrict__ dyh, int ldyy, int ldp) {
-    __shared__ double red[4][2];
-    __shared__ float kk[2];
-    // grid = (ceil(G * PA/2 / 256), C): flat walk over (sample group, output pair) of a channel (rows of 625 have 320
-    // pairs: one block per 256 pairs and group left 37 % of the threads idle)
-    const int c = blockIdx.y, tl = threadIdx.x;
-    const int HP = PA >> 1, flat = blockIdx.x * kBlock + tl, g = flat / HP;
-    {
-        double a = 0.0, q = 0.0;
-        for (int pp = tl; pp < S; pp += kBlock) {
-            a += (double)partials[((size_t)c * S + pp) * 2];
-            q += (double)partials[((size_t)c * S + pp) * 2 + 1];
-        }
-        a = wave_sum(a); q = wave_sum(q);
-        if ((tl & 63) == 0) { red[tl >> 6][0] = a; red[tl >> 6][1] = q; }
-        __syncthreads();
-        if (tl == 0) {
-            a = ((red[0][0] + red[1][0]) + red[2][0]) + red[3][0];
-            q = ((red[0][1] + red[1][1]) + red[2][1]) + red[3][1];
-            if (blockIdx.x == 0) {
-                if (dbeta) dbeta[c] = (float)a;
-                if (dgamma) dgamma[c] = (float)q;
-            }
-            kk[0] = train ? (float)(a / M) : 0.f;
-            kk[1] = train ? (float)(q / M) : 0.f;
-        }
-        __syncthreads();
-    }
-    const int j = flat - g * HP, t0 = 2 * j;
-    if (g >= (N + 15) / 16) return;
-    const float k1 = kk[0], k2 = kk[1];
-    const float mu = mean[c], is = invstd[c], ga = gamma[c], sc = is * ga, gi = ga * is, be = beta[c];
-    const int Lp = L >> 1;
-    const bool in0 = t0 < L, has1 = t0 + 1 < L;
-    const int ta = min(t0, L - 1), tb = min(t0 + 1, L - 1), jc = min(j, max(Lp - 1, 0));
-    float y0[16], y1[16], d[16];
-#pragma unroll
-    for (int s = 0; s < 16; ++s) {                   // 48 unconditional, clamped loads in flight
-        const size_t row = (size_t)min(16 * g + s, N - 1) * C + c;
-        if (YH) ld_pair_y<true, true>(y, row, ldyy, min(t0, (L - 1) & ~1), y0[s], y1[s]);   // (odd L: the last dword's high half is row padding, unused)
-        else if (AL8) ld_pair<true>(y + row * L + min(t0, L - 2), y0[s], y1[s]);      // (pad pairs read the row's last pair: unused)
-        else { y0[s] = y[row * L + ta]; y1[s] = y[row * L + tb]; }
-        if (DH) d[s] = __uint_as_float((unsigned)reinterpret_cast<const unsigned short *>(g_in)[row * ldp + jc] << 16);
-        else d[s] = bcast != 0.f ? g_in[row] * bcast : (Lp > 0 ? g_in[row * Lp + jc] : 0.f);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    float v0[16], v1[16];
-#pragma unroll
-    for (int s = 0; s < 16; ++s) {
-        const bool valid = 16 * g + s < N;
-        float da0 = 0.f, da1 = 0.f;
-        if (has1) {      // an odd tail sample never reaches the pool: da = 0
-            int am;
-            if (pool_route(y0[s], y1[s], mu, sc, be, am)) {
-                if (am) da1 = d[s]; else da0 = d[s];
-            }
-        }
-        v0[s] = (valid && in0) ? gi * (da0 - k1 - (y0[s] - mu) * is * k2) : 0.f;
-        v1[s] = (valid && has1) ? gi * (da1 - k1 - (y1[s] - mu) * is * k2) : 0.f;
-        if (dy && valid) {
-            float *dr = dy + ((size_t)(16 * g + s) * C + c) * ldy;
-            if (t0 < ldy) dr[t0] = v0[s];
-            if (t0 + 1 < ldy) dr[t0 + 1] = v1[s];
-        }
-        // bf16 [N][C][PA] for the input-gradient conv (rows zero-filled past L: v0 / v1 are 0 there): one dword per pair
-        if (dyh && valid) dyh[(((size_t)(16 * g + s) * C + c) * PA + t0) >> 1] = pack2n(v0[s], v1[s]);
-    }
-    u16n *o = dyb + (((size_t)g * C + c) * PA + t0) * 16;
-    store_n16(o, v0);
-    store_n16(o + 16, v1);
-}
-
-// ---------------------------------------------------------------------------------------
 // unfused ReLU / MaxPool leaves
 // ---------------------------------------------------------------------------------------
 __global__ void relu_fwd_kernel(const float *__restrict__ x, float *__restrict__ out, size_t n) {
@@ -902,35 +748,6 @@ static int pool_gap_fwd_impl(const BnFin *fin, const float *y, const float *gamm
     return check_launch("bn_relu_pool_gap_fwd_kernel");
 }
 
-static int pool_fwd_n16_impl(const BnFin *fin, const float *y, const float *gamma, const float *beta,
-                             const float *mean, const float *invstd, float *p, void *p_n16, int N, int C, int L,
-                             int PX, int shift, hipStream_t st, bool yh = false, int ldy = 0, void *p_bf16 = nullptr,
-                             int ldp = 0) {
-    int rc = check_ncl("bn_relu_pool_fwd_n16", N, C, L);
-    if (rc) return rc;
-    ECG_REQUIRE(y && gamma && beta && mean && invstd && p_n16, "bn_relu_pool_fwd_n16: null pointer");
-    const int Lp = L / 2;
-    ECG_REQUIRE(Lp >= 1 && shift >= 0 && PX >= shift + Lp, "bn_relu_pool_fwd_n16: PX=%d cannot hold %d positions at shift %d",
-                PX, Lp, shift);
-    ECG_REQUIRE((reinterpret_cast<uintptr_t>(p_n16) & 15) == 0, "bn_relu_pool_fwd_n16: n16 output must be 16-byte aligned");
-    const int G = cdiv(N, 16);
-    const bool al8 = pairs_aligned(y, L);
-    const BnFin f = fin ? *fin : BnFin{};
-#define ECG_POOLN(FIN, AL8) hipLaunchKernelGGL((bn_relu_pool_fwd_n16_kernel<FIN, AL8>), dim3(cdiv((long long)G * PX, kBlock), C), \
-                                               dim3(kBlock), 0, st, y, gamma, beta, mean, invstd, p,                   \
-                                               static_cast<u16n *>(p_n16), N, C, L, Lp, PX, shift, f, L, nullptr, 0)
-    ECG_REQUIRE(!p_bf16 || (yh && ldp >= Lp && ldp % 2 == 0 && ldp <= PX - shift),
-                "bn_relu_pool_fwd_n16: the bf16 copy of p needs an even row stride in [L/2, PX - shift]");
-    if (yh)
-        hipLaunchKernelGGL((bn_relu_pool_fwd_n16_kernel<true, true, true>), dim3(cdiv((long long)G * PX, kBlock), C), dim3(kBlock), 0, st,
-                           y, gamma, beta, mean, invstd, p, static_cast<u16n *>(p_n16), N, C, L, Lp, PX, shift, f, ldy,
-                           static_cast<u16n *>(p_bf16), ldp);
-    else if (fin) { if (al8) ECG_POOLN(true, true); else ECG_POOLN(true, false); }
-    else { if (al8) ECG_POOLN(false, true); else ECG_POOLN(false, false); }
-#undef ECG_POOLN
-    return check_launch("bn_relu_pool_fwd_n16_kernel");
-}
-
 ECG_API int ecg_bn_relu_pool_fwd(const float *y, const float *gamma, const float *beta,
                                  const float *mean, const float *invstd, float *p, int N, int C,
                                  int L, ecg_stream_t stream) {
@@ -943,51 +760,37 @@ ECG_API int ecg_bn_relu_pool_gap_fwd(const float *y, const float *gamma, const f
     return pool_gap_fwd_impl(nullptr, y, gamma, beta, mean, invstd, g, N, C, L, as_stream(stream));
 }
 
-ECG_API int ecg_bn_relu_pool_fwd_n16(const float *y, const float *gamma, const float *beta, const float *mean,
-                                     const float *invstd, float *p, void *p_n16, int N, int C, int L, int PX,
-                                     int shift, ecg_stream_t stream) {
-    return pool_fwd_n16_impl(nullptr, y, gamma, beta, mean, invstd, p, p_n16, N, C, L, PX, shift, as_stream(stream));
-}
-
 // ecg_bn_finalize + the pass above in ONE launch: mean / invstd are OUTPUTS here (and the running statistics and the
 // counter are updated), written by one workgroup per channel while every workgroup re-derives them for itself.
-// mode: 0 = pool -> out [N][C][L/2]; 1 = pool + global average -> out [N][C]; 2 = pool, fp32 out (may be NULL) and
-// the n16 bf16 copy p_n16 with PX positions at `shift`.
+// mode: 0 = pool -> out [N][C][L/2]; 1 = pool + global average -> out [N][C].
 ECG_API int ecg_bn_stats_relu_pool_fwd(const float *stat_partials, int P, long long count, float *running_mean,
                                        float *running_var, long long *num_batches_tracked, float momentum, float eps,
                                        const float *y, const float *gamma, const float *beta, float *mean,
-                                       float *invstd, float *out, void *p_n16, int N, int C, int L, int PX, int shift,
-                                       int mode, ecg_stream_t stream) {
+                                       float *invstd, float *out, int N, int C, int L, int mode, ecg_stream_t stream) {
     const BnFin f{stat_partials, P, (double)count, mean, invstd, running_mean, running_var, num_batches_tracked,
                   momentum, eps};
     int rc = check_fin("bn_stats_relu_pool_fwd", f, C);
     if (rc) return rc;
-    ECG_REQUIRE(mode >= 0 && mode <= 2, "bn_stats_relu_pool_fwd: mode %d", mode);
+    ECG_REQUIRE(mode == 0 || mode == 1, "bn_stats_relu_pool_fwd: mode %d", mode);
     if (mode == 0) return pool_fwd_impl(&f, y, gamma, beta, mean, invstd, out, N, C, L, as_stream(stream));
-    if (mode == 1) return pool_gap_fwd_impl(&f, y, gamma, beta, mean, invstd, out, N, C, L, as_stream(stream));
-    return pool_fwd_n16_impl(&f, y, gamma, beta, mean, invstd, out, p_n16, N, C, L, PX, shift, as_stream(stream));
+    return pool_gap_fwd_impl(&f, y, gamma, beta, mean, invstd, out, N, C, L, as_stream(stream));
 }
 
-// the same for a y that ecg_conv1d_fwd_bf16_yh wrote as bf16 [N][C][ldy] (bf16 activation storage);
-// mode 1 (pool + global average) or 2 (pool -> fp32 out (may be NULL) + n16 copy + (p_bf16 non-NULL) p as bf16
-// [N][C][ldp], rows zero-filled from L/2 to ldp: the next conv's forward input) only
-ECG_API int ecg_bn_stats_relu_pool_fwd_yh(const float *stat_partials, int P, long long count, float *running_mean,
-                                          float *running_var, long long *num_batches_tracked, float momentum,
-                                          float eps, const void *y_bf16, int ldy, const float *gamma,
-                                          const float *beta, float *mean, float *invstd, float *out, void *p_n16,
-                                          void *p_bf16, int ldp, int N, int C, int L, int PX, int shift, int mode,
-                                          ecg_stream_t stream) {
+// pool + global average (the last block of the backbone) for a y that ecg_conv1d_fwd_bf16_yh wrote as bf16 [N][C][ldy]
+// (the mixed-precision form; the pool-only pass on bf16 rows is ecg_bn_stats_relu_pool_fwd_h, bn_relu_pool_h.hip)
+ECG_API int ecg_bn_stats_relu_pool_gap_fwd_yh(const float *stat_partials, int P, long long count, float *running_mean,
+                                              float *running_var, long long *num_batches_tracked, float momentum,
+                                              float eps, const void *y_bf16, int ldy, const float *gamma,
+                                              const float *beta, float *mean, float *invstd, float *out, int N, int C,
+                                              int L, ecg_stream_t stream) {
     const BnFin f{stat_partials, P, (double)count, mean, invstd, running_mean, running_var, num_batches_tracked,
                   momentum, eps};
-    int rc = check_fin("bn_stats_relu_pool_fwd_yh", f, C);
+    int rc = check_fin("bn_stats_relu_pool_gap_fwd_yh", f, C);
     if (rc) return rc;
-    ECG_REQUIRE(mode == 1 || mode == 2, "bn_stats_relu_pool_fwd_yh: mode %d", mode);
     ECG_REQUIRE(y_bf16 && ldy >= L && ldy % 2 == 0 && (reinterpret_cast<uintptr_t>(y_bf16) & 3) == 0,
-                "bn_stats_relu_pool_fwd_yh: bf16 y needs an even row stride >= L and a 4-byte aligned base");
-    const float *y = static_cast<const float *>(y_bf16);
-    if (mode == 1) return pool_gap_fwd_impl(&f, y, gamma, beta, mean, invstd, out, N, C, L, as_stream(stream), true, ldy);
-    return pool_fwd_n16_impl(&f, y, gamma, beta, mean, invstd, out, p_n16, N, C, L, PX, shift, as_stream(stream), true, ldy,
-                             p_bf16, ldp);
+                "bn_stats_relu_pool_gap_fwd_yh: bf16 y needs an even row stride >= L and a 4-byte aligned base");
+    return pool_gap_fwd_impl(&f, static_cast<const float *>(y_bf16), gamma, beta, mean, invstd, out, N, C, L,
+                             as_stream(stream), true, ldy);
 }
 
 ECG_API size_t ecg_bn_relu_pool_bwd_ws_floats(int N, int C, int L) {
@@ -1037,10 +840,10 @@ static int bn_bwd_impl(const float *y, const float *g, const float *gamma, const
     const bool al8 = FUSED && pairs_aligned(y, L);
     if (al8)
         hipLaunchKernelGGL((bn_bwd_reduce_kernel<FUSED, true>), dim3(C, S), dim3(kBlock), 0, st, y, g, gamma,
-                           beta, mean, invstd, partials, N, C, L, S, bcast, L, 0);
+                           beta, mean, invstd, partials, N, C, L, S, bcast);
     else
         hipLaunchKernelGGL((bn_bwd_reduce_kernel<FUSED, false>), dim3(C, S), dim3(kBlock), 0, st, y, g, gamma,
-                           beta, mean, invstd, partials, N, C, L, S, bcast, L, 0);
+                           beta, mean, invstd, partials, N, C, L, S, bcast);
     int rc = check_launch("bn_bwd_reduce_kernel");
     if (rc) return rc;
     // dx pass with the combine of the reduce partials folded in (no finalize launch)
@@ -1192,67 +995,4 @@ ECG_API int ecg_bn_relu_pool_gap_bwd(const float *y, const float *dg, const floa
                                      int C, int L, int train, ecg_stream_t stream) {
     return ecg_bn_relu_pool_gap_bwd_ld(y, dg, gamma, beta, mean, invstd, dy, L, dgamma, dbeta, ws, N, C,
                                        L, train, stream);
-}
-
-// ---- mixed-precision producers (see the kernels above) -------------------------------------------------
-// y: fp32 [N][C][L], or (yh) bf16 [N][C][ldyy] with an even row stride
-static int bwd_n16_impl(const char *who, const float *y, bool yh, int ldyy, const float *dp, bool dh, int ldp,
-                        const float *gamma,
-                        const float *beta, const float *mean, const float *invstd, float *dy, int ldy, void *dy_n16,
-                        int PA, float *dgamma, float *dbeta, float *ws, int N, int C, int L, int train, int gap,
-                        void *dy_bf16, hipStream_t st) {
-    int rc = check_ncl(who, N, C, L);
-    if (rc) return rc;
-    ECG_REQUIRE(y && dp && gamma && beta && mean && invstd && dy_n16 && ws, "%s: null pointer", who);
-    ECG_REQUIRE(L >= 2, "%s: L=%d leaves an empty pooled row", who, L);
-    ECG_REQUIRE(PA >= L && PA % 2 == 0, "%s: PA=%d must be even and >= L=%d", who, PA, L);
-    ECG_REQUIRE(!dy || (ldy >= L && ldy <= PA), "%s: dY row stride %d outside [L, PA]", who, ldy);
-    ECG_REQUIRE((reinterpret_cast<uintptr_t>(dy_n16) & 15) == 0, "%s: n16 output must be 16-byte aligned", who);
-    ECG_REQUIRE((reinterpret_cast<uintptr_t>(dy_bf16) & 3) == 0, "%s: bf16 dY must be 4-byte aligned", who);
-    ECG_REQUIRE(!yh || (ldyy >= L && ldyy % 2 == 0 && (reinterpret_cast<uintptr_t>(y) & 3) == 0),
-                "%s: bf16 y needs an even row stride >= L and a 4-byte aligned base", who);
-    ECG_REQUIRE(!dh || (yh && !gap && ldp >= L / 2), "%s: a bf16 dp needs a bf16 y, no global average pool and a row stride >= L/2",
-                who);
-    const float bcast = gap ? 1.0f / (float)(L / 2) : 0.f;
-    const int S = stat_splits(N, C, true);       // (the whole n16 family: its bf16- and fp32-operand forms then add the same numbers in the same order)
-    const bool al8 = !yh && pairs_aligned(y, L);
-#define ECG_RED(AL8, YH, DH) hipLaunchKernelGGL((bn_bwd_reduce_kernel<true, AL8, YH, DH>), dim3(C, S), dim3(kBlock), 0, st, y, \
-                                                dp, gamma, beta, mean, invstd, ws, N, C, L, S, bcast, yh ? ldyy : L, ldp)
-    if (dh) ECG_RED(true, true, true);
-    else if (yh) ECG_RED(true, true, false);
-    else if (al8) ECG_RED(true, false, false);
-    else ECG_RED(false, false, false);
-#undef ECG_RED
-    rc = check_launch("bn_bwd_reduce_kernel");
-    if (rc) return rc;
-    const int G = cdiv(N, 16);
-#define ECG_DXN(AL8, YH, DH) hipLaunchKernelGGL((bn_bwd_dx_n16_kernel<AL8, YH, DH>), dim3(cdiv((long long)G * (PA / 2), kBlock), C), \
-                                                dim3(kBlock), 0, st, y, dp, gamma, beta, mean, invstd, ws, S, (double)N * L,  \
-                                                dgamma, dbeta, dy, ldy, static_cast<u16n *>(dy_n16), PA, N, C, L, bcast,     \
-                                                train, static_cast<unsigned *>(dy_bf16), yh ? ldyy : L, ldp)
-    if (dh) ECG_DXN(true, true, true);
-    else if (yh) ECG_DXN(true, true, false);
-    else if (al8) ECG_DXN(true, false, false);
-    else ECG_DXN(false, false, false);
-#undef ECG_DXN
-    return check_launch("bn_bwd_dx_n16_kernel");
-}
-
-ECG_API int ecg_bn_relu_pool_bwd_n16(const float *y, const float *dp, const float *gamma, const float *beta,
-                                     const float *mean, const float *invstd, float *dy, int ldy, void *dy_n16,
-                                     int PA, float *dgamma, float *dbeta, float *ws, int N, int C, int L,
-                                     int train, int gap, void *dy_bf16, ecg_stream_t stream) {
-    return bwd_n16_impl("bn_relu_pool_bwd_n16", y, false, L, dp, false, 0, gamma, beta, mean, invstd, dy, ldy, dy_n16, PA, dgamma,
-                        dbeta, ws, N, C, L, train, gap, dy_bf16, as_stream(stream));
-}
-
-// the same with y as ecg_conv1d_fwd_bf16_yh wrote it: bf16 [N][C][ldyy]; dp fp32 [N][C][L/2] ([N][C] with gap), or
-// (dp_bf16 != 0, no gap) bf16 [N][C][ldp] as ecg_conv1d_bwd_data_bf16hh of the next block wrote it
-ECG_API int ecg_bn_relu_pool_bwd_n16_yh(const void *y_bf16, int ldyy, const void *dp, int dp_bf16, int ldp,
-                                        const float *gamma, const float *beta, const float *mean, const float *invstd,
-                                        float *dy, int ldy, void *dy_n16, int PA, float *dgamma, float *dbeta, float *ws,
-                                        int N, int C, int L, int train, int gap, void *dy_bf16, ecg_stream_t stream) {
-    return bwd_n16_impl("bn_relu_pool_bwd_n16_yh", static_cast<const float *>(y_bf16), true, ldyy,
-                        static_cast<const float *>(dp), dp_bf16 != 0, ldp, gamma, beta, mean, invstd, dy, ldy, dy_n16, PA,
-                        dgamma, dbeta, ws, N, C, L, train, gap, dy_bf16, as_stream(stream));
 }

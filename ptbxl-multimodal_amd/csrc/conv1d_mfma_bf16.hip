@@ -481,20 +481,17 @@ static void launch_bf16(const void *x, int ldx, bool xh, const u16 *wb, const fl
 #define ECG_BF(STATS, XH, WRES, YH)                                                                                    \
     hipLaunchKernelGGL((conv1d_mfma_bf16_fwd_kernel<CO_T, T_T, WCO, WT, STATS, XH, WRES, YH>), grid, block, 0, st, xf, \
                        wb, bias, y, partials, Cin, Cout, L, Lo, pad, tiles_t, N, G, ldx, ldyo)
-    if (yh && xh) { // bf16 in, bf16 out: the train-mode forward of an inner block (statistics), or its input gradient
+    // y / dx always leave as bf16 rows (round 5: the mixed-precision step has ONE form); x is the previous block's bf16
+    // activation / this block's bf16 dY (xh), or the fp32 network input of the first block
+    (void)yh;
+    if (xh) { // bf16 in, bf16 out: the train-mode forward of an inner block (statistics), or its input gradient (none)
         if (!partials) ECG_BF(false, true, false, true);
         else if (Cin <= 2 * kCB) ECG_BF(true, true, true, true);
         else ECG_BF(true, true, false, true);
-    } else if (yh) { // bf16 activation storage (train-mode forward: always with statistics)
+    } else { // fp32 network input (train-mode forward: always with statistics)
         if (Cin <= 2 * kCB) ECG_BF(true, false, true, true);
         else ECG_BF(true, false, false, true);
-    } else if (xh)  // bf16 input (the input-gradient conv: no bias, no statistics)
-        ECG_BF(false, true, false, false);
-    else if (Cin <= 2 * kCB) {          // at most two chunks: the weight slice stays resident in the two LDS images
-        if (partials) ECG_BF(true, false, true, false);
-        else ECG_BF(false, false, true, false);
-    } else if (partials) ECG_BF(true, false, false, false);
-    else ECG_BF(false, false, false, false);
+    }
 #undef ECG_BF
 }
 
@@ -529,11 +526,6 @@ static int bf16_fwd_any(const void *x, int ldx, bool xh, const void *wb, const f
     return check_launch("conv1d_mfma_bf16_fwd_kernel");
 }
 
-int bf16_fwd(const float *x, const void *wb, const float *bias, float *y, float *partials, int N,
-             int Cin, int Cout, int L, int K, int pad, hipStream_t st) {
-    return bf16_fwd_any(x, L, false, wb, bias, y, L + 2 * pad - K + 1, false, partials, N, Cin, Cout, L, K, pad, st);
-}
-
 int bf16_pack(const float *w, void *wb_fwd, void *wb_bwd, int Co, int Ci, int K, hipStream_t st) {
     const size_t n = bf16_packed_elems(Ci, Co, K), m = bf16_packed_elems(Co, Ci, K);
     const size_t total = n > m ? n : m;
@@ -553,75 +545,15 @@ static int check_bf16_shape(const char *who, int N, int Cin, int Cout, int L, in
 }
 
 namespace ecg {
-// conv1d_wgrad_bf16.hip
-bool wgrad_bf16_supported(int Cin, int Cout, int K, int pad);
-size_t wgrad_bf16_ws_floats(int N, int Cin, int Cout, int L, int K, int pad);
-int wgrad_bf16(const float *dy, int ldy, const float *x, float *dw, float *db, float *ws, int N, int Cin,
-               int Cout, int L, int K, int pad, hipStream_t st);
-void wgrad_bf16_positions(int L, int K, int pad, int *PA, int *PX);
-size_t wgrad_bf16_packed_ws_floats(int N, int Cin, int Cout, int L, int K, int pad);
-int wgrad_bf16_packed(const void *dyb, const void *xb, float *dw, float *db, float *ws, int N, int Cin, int Cout,
-                      int L, int K, int pad, hipStream_t st);
-int pack_n16(const float *src, void *dst, int N, int C, int ld, int Lsrc, int P, int shift, hipStream_t st);
+bool wgrad_bf16_tk_supported(int Cin, int Cout, int K, int pad);      // conv1d_wgrad_bf16_tk.hip
 }  // namespace ecg
 
 ECG_API int ecg_conv1d_bf16_supported(int C_in, int C_out, int K, int pad) {
     // bit 0: forward (C_in % 4 == 0, C_out % 32 == 0); bit 1: input-grad (roles swapped);
-    // bit 2: weight-grad (K == 15, pad == 7, C_out % 32 == 0)
+    // bit 2: weight-grad, the time-on-K kernel (K == 15, pad == 7, C_out % 32 == 0)
     return (bf16_fwd_supported(C_in, C_out, K, pad) ? 1 : 0) |
            (bf16_fwd_supported(C_out, C_in, K, K - 1 - pad) ? 2 : 0) |
-           (wgrad_bf16_supported(C_in, C_out, K, pad) ? 4 : 0);
-}
-
-ECG_API size_t ecg_conv1d_bwd_weight_bf16_ws_floats(int N, int C_in, int C_out, int L, int K, int pad) {
-    if (!wgrad_bf16_supported(C_in, C_out, K, pad) || N <= 0 || L + 2 * pad - K + 1 <= 0) return 0;
-    return wgrad_bf16_ws_floats(N, C_in, C_out, L, K, pad);
-}
-
-ECG_API int ecg_conv1d_bwd_weight_bias_bf16(const float *dy, int ldy, const float *x, float *dw, float *db,
-                                            float *ws, int N, int C_in, int C_out, int L, int K, int pad,
-                                            ecg_stream_t stream) {
-    int rc = check_bf16_shape("conv1d_bwd_weight_bias_bf16", N, C_in, C_out, L, K, pad);
-    if (rc) return rc;
-    ECG_REQUIRE(dy && x && dw && ws, "conv1d_bwd_weight_bias_bf16: null pointer");
-    ECG_REQUIRE(wgrad_bf16_supported(C_in, C_out, K, pad),
-                "conv1d_bwd_weight_bias_bf16: needs K == 15, pad == 7, C_out %% 32 == 0 (query ecg_conv1d_bf16_supported)");
-    ECG_REQUIRE(ldy >= L + 2 * pad - K + 1, "conv1d_bwd_weight_bias_bf16: dY row stride %d too small", ldy);
-    ECG_REQUIRE((reinterpret_cast<uintptr_t>(ws) & 15) == 0, "conv1d_bwd_weight_bias_bf16: workspace must be 16-byte aligned");
-    return wgrad_bf16(dy, ldy, x, dw, db, ws, N, C_in, C_out, L, K, pad, as_stream(stream));
-}
-
-ECG_API int ecg_conv1d_n16_positions(int L, int K, int pad, int which) {
-    if (K != kKB || pad != kKB / 2 || L + 2 * pad - K + 1 <= 0) return 0;
-    int PA = 0, PX = 0;
-    wgrad_bf16_positions(L, K, pad, &PA, &PX);
-    return which ? PX : PA;
-}
-
-ECG_API int ecg_pack_n16(const float *src, void *dst, int N, int C, int ld, int L, int P, int shift,
-                         ecg_stream_t stream) {
-    ECG_REQUIRE(src && dst && N > 0 && N <= 16 * 65535 && C > 0 && C <= 65535 && L > 0 && ld >= L && P > 0 && shift >= 0,
-                "pack_n16: bad argument");
-    ECG_REQUIRE((reinterpret_cast<uintptr_t>(dst) & 15) == 0, "pack_n16: destination must be 16-byte aligned");
-    return pack_n16(src, dst, N, C, ld, L, P, shift, as_stream(stream));
-}
-
-ECG_API size_t ecg_conv1d_bwd_weight_bf16_packed_ws_floats(int N, int C_in, int C_out, int L, int K, int pad) {
-    if (!wgrad_bf16_supported(C_in, C_out, K, pad) || N <= 0 || L + 2 * pad - K + 1 <= 0) return 0;
-    return wgrad_bf16_packed_ws_floats(N, C_in, C_out, L, K, pad);
-}
-
-ECG_API int ecg_conv1d_bwd_weight_bias_bf16_packed(const void *dy_n16, const void *x_n16, float *dw, float *db,
-                                                   float *ws, int N, int C_in, int C_out, int L, int K, int pad,
-                                                   ecg_stream_t stream) {
-    int rc = check_bf16_shape("conv1d_bwd_weight_bias_bf16_packed", N, C_in, C_out, L, K, pad);
-    if (rc) return rc;
-    ECG_REQUIRE(dy_n16 && x_n16 && dw && ws, "conv1d_bwd_weight_bias_bf16_packed: null pointer");
-    ECG_REQUIRE(wgrad_bf16_supported(C_in, C_out, K, pad),
-                "conv1d_bwd_weight_bias_bf16_packed: needs K == 15, pad == 7, C_out %% 32 == 0");
-    ECG_REQUIRE(((reinterpret_cast<uintptr_t>(dy_n16) | reinterpret_cast<uintptr_t>(x_n16)) & 15) == 0,
-                "conv1d_bwd_weight_bias_bf16_packed: operands must be 16-byte aligned");
-    return wgrad_bf16_packed(dy_n16, x_n16, dw, db, ws, N, C_in, C_out, L, K, pad, as_stream(stream));
+           (wgrad_bf16_tk_supported(C_in, C_out, K, pad) ? 4 : 0);
 }
 
 ECG_API size_t ecg_conv1d_bf16_packed_elems(int C_reduce, int C_result, int K) {
@@ -635,13 +567,8 @@ ECG_API int ecg_conv1d_pack_weights_bf16(const float *w, void *wb_fwd, void *wb_
     return bf16_pack(w, wb_fwd, wb_bwd, C_out, C_in, K, as_stream(stream));
 }
 
-ECG_API int ecg_conv1d_fwd_bf16_stat_partials(int N, int C_in, int C_out, int L, int K, int pad) {
-    (void)C_in;
-    return bf16_fwd_stat_partials(N, C_out, L + 2 * pad - K + 1);
-}
-
 // partials per channel that ecg_conv1d_fwd_bf16_yh writes for these arguments (it picks its kernel by the operand
-// types and row strides too, so the count can differ from ecg_conv1d_fwd_bf16_stat_partials)
+// types and row strides too)
 ECG_API int ecg_conv1d_fwd_bf16_yh_stat_partials(int N, int C_in, int C_out, int L, int K, int pad, int x_bf16, int ldx,
                                                  int ldy) {
     const int Lo = L + 2 * pad - K + 1;
@@ -659,21 +586,12 @@ ECG_API int ecg_conv1d_bf16_ring_tile(int N, int C_red, int C_res, int L_out, in
     return rp.ok ? rp.t_t : 0;
 }
 
-ECG_API int ecg_conv1d_fwd_bf16(const float *x, const void *wb_fwd, const float *bias, float *y,
-                                float *stat_partials, int N, int C_in, int C_out, int L, int K,
-                                int pad, ecg_stream_t stream) {
-    int rc = check_bf16_shape("conv1d_fwd_bf16", N, C_in, C_out, L, K, pad);
-    if (rc) return rc;
-    ECG_REQUIRE(x && wb_fwd && y, "conv1d_fwd_bf16: null pointer");
-    ECG_REQUIRE(bf16_fwd_supported(C_in, C_out, K, pad), "conv1d_fwd_bf16: needs C_in %% 4 == 0, C_out %% 32 == 0");
-    return bf16_fwd(x, wb_fwd, bias, y, stat_partials, N, C_in, C_out, L, K, pad, as_stream(stream));
-}
-
 // Train-mode forward with bf16 ACTIVATION STORAGE: y is written as bf16 [N][C_out][ldy] (ldy >= Lo, even), the
-// BatchNorm statistics partials (layout as ecg_conv1d_fwd_bf16) are taken over the rounded values.  The consumers are
-// ecg_bn_stats_relu_pool_fwd_yh and ecg_bn_relu_pool_bwd_n16_yh.
+// BatchNorm statistics partials ([C_out][P][2] = (sum, sum of squares), P from ecg_conv1d_fwd_bf16_yh_stat_partials) are taken
+// over the rounded values.  The consumers are ecg_bn_stats_relu_pool_fwd_h / ecg_bn_stats_relu_pool_gap_fwd_yh and
+// ecg_bn_relu_pool_bwd_h.
 // x: fp32 [N][C_in][L] (x_bf16 == 0, ldx ignored) or bf16 [N][C_in][ldx] with rows zero-filled from L to ldx, ldx even,
-// pad odd (x_bf16 != 0: the previous block's ecg_bn_stats_relu_pool_fwd_yh wrote it that way).
+// pad odd (x_bf16 != 0: the previous block's ecg_bn_stats_relu_pool_fwd_h wrote it that way).
 ECG_API int ecg_conv1d_fwd_bf16_yh(const void *x, int x_bf16, int ldx, const void *wb_fwd, const float *bias,
                                    void *y_bf16, int ldy, float *stat_partials, int N, int C_in, int C_out, int L, int K,
                                    int pad, ecg_stream_t stream) {
@@ -689,23 +607,9 @@ ECG_API int ecg_conv1d_fwd_bf16_yh(const void *x, int x_bf16, int ldx, const voi
                         stat_partials, N, C_in, C_out, L, K, pad, as_stream(stream));
 }
 
-// input gradient from a dY that is itself bf16: [N][C_out][ldy] u16, rows zero-filled from Lo to ldy, ldy even
-// (ecg_bn_relu_pool_bwd_n16 writes it that way) — half the bytes of the fp32 dY on both sides
-ECG_API int ecg_conv1d_bwd_data_bf16h(const void *dy_bf16, int ldy, const void *wb_bwd, float *dx, int N, int C_in,
-                                      int C_out, int L, int K, int pad, ecg_stream_t stream) {
-    int rc = check_bf16_shape("conv1d_bwd_data_bf16h", N, C_in, C_out, L, K, pad);
-    if (rc) return rc;
-    ECG_REQUIRE(dy_bf16 && wb_bwd && dx, "conv1d_bwd_data_bf16h: null pointer");
-    const int Lo = L + 2 * pad - K + 1, padb = K - 1 - pad;
-    ECG_REQUIRE(bf16_fwd_supported(C_out, C_in, K, padb), "conv1d_bwd_data_bf16h: needs C_out %% 4 == 0, C_in %% 32 == 0");
-    ECG_REQUIRE(ldy >= Lo && ldy % 2 == 0 && (padb & 1) == 1 && (reinterpret_cast<uintptr_t>(dy_bf16) & 3) == 0,
-                "conv1d_bwd_data_bf16h: needs an even row stride >= Lo, odd K-1-pad and a 4-byte aligned dY");
-    return bf16_fwd_any(dy_bf16, ldy, true, wb_bwd, nullptr, dx, L, false, nullptr, N, C_out, C_in, Lo, K, padb,
-                        as_stream(stream));
-}
-
-// ... and writes dx itself as bf16 [N][C_in][ldx] (ldx even, >= L; the row padding is left unwritten or zeroed): the dp that the
-// previous block's ecg_bn_relu_pool_bwd_n16_yh reads
+// Input gradient from a dY that is itself bf16 — [N][C_out][ldy], rows zero-filled from Lo to ldy, ldy even, as
+// ecg_bn_relu_pool_bwd_h writes it — to dx as bf16 [N][C_in][ldx] (ldx even, >= L; the row padding is left unwritten or
+// zeroed): the dp that the previous block's ecg_bn_relu_pool_bwd_h reads
 ECG_API int ecg_conv1d_bwd_data_bf16hh(const void *dy_bf16, int ldy, const void *wb_bwd, void *dx_bf16, int ldx, int N,
                                        int C_in, int C_out, int L, int K, int pad, ecg_stream_t stream) {
     int rc = check_bf16_shape("conv1d_bwd_data_bf16hh", N, C_in, C_out, L, K, pad);
@@ -719,16 +623,6 @@ ECG_API int ecg_conv1d_bwd_data_bf16hh(const void *dy_bf16, int ldy, const void 
                 "conv1d_bwd_data_bf16hh: needs an even dx row stride >= L and a 4-byte aligned dx");
     return bf16_fwd_any(dy_bf16, ldy, true, wb_bwd, nullptr, static_cast<float *>(dx_bf16), ldx, true, nullptr, N, C_out,
                         C_in, Lo, K, padb, as_stream(stream));
-}
-
-ECG_API int ecg_conv1d_bwd_data_bf16(const float *dy, const void *wb_bwd, float *dx, int N, int C_in,
-                                     int C_out, int L, int K, int pad, ecg_stream_t stream) {
-    int rc = check_bf16_shape("conv1d_bwd_data_bf16", N, C_in, C_out, L, K, pad);
-    if (rc) return rc;
-    ECG_REQUIRE(dy && wb_bwd && dx, "conv1d_bwd_data_bf16: null pointer");
-    const int Lo = L + 2 * pad - K + 1, padb = K - 1 - pad;
-    ECG_REQUIRE(bf16_fwd_supported(C_out, C_in, K, padb), "conv1d_bwd_data_bf16: needs C_out %% 4 == 0, C_in %% 32 == 0");
-    return bf16_fwd(dy, wb_bwd, nullptr, dx, nullptr, N, C_out, C_in, Lo, K, padb, as_stream(stream));
 }
 
 #ifdef ECG_STAMP

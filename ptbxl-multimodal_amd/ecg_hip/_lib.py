@@ -40,22 +40,9 @@ SIGNATURES = {
     "ecg_conv1d_bf16_supported": (_i, [_i, _i, _i, _i]),
     "ecg_conv1d_bf16_packed_elems": (_sz, [_i, _i, _i]),
     "ecg_conv1d_pack_weights_bf16": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),
-    "ecg_conv1d_fwd_bf16_stat_partials": (_i, [_i, _i, _i, _i, _i, _i]),
-    "ecg_conv1d_fwd_bf16": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
-    "ecg_conv1d_bwd_data_bf16": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
-    "ecg_conv1d_bwd_weight_bf16_ws_floats": (_sz, [_i] * 6),
-    "ecg_conv1d_bwd_weight_bias_bf16": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
-    "ecg_conv1d_n16_positions": (_i, [_i, _i, _i, _i]),
-    "ecg_pack_n16": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
-    "ecg_bn_relu_pool_fwd_n16": (_i, [_vp] * 7 + [_i] * 5 + [_vp]),
-    "ecg_bn_relu_pool_bwd_n16": (_i, [_vp] * 7 + [_i, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
-    "ecg_conv1d_bwd_data_bf16h": (_i, [_vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "ecg_conv1d_fwd_bf16_yh": (_i, [_vp, _i, _i, _vp, _vp, _vp, _i, _vp] + [_i] * 6 + [_vp]),
     "ecg_conv1d_fwd_bf16_yh_stat_partials": (_i, [_i] * 9),
     "ecg_conv1d_bf16_ring_tile": (_i, [_i] * 8),
-    "ecg_bn_stats_relu_pool_fwd_yh": (_i, [_vp, _i, _ll, _vp, _vp, _vp, _f, _f, _vp, _i] + [_vp] * 7 + [_i] * 7 + [_vp]),
-    "ecg_bn_relu_pool_bwd_n16_yh": (_i, [_vp, _i, _vp, _i, _i] + [_vp] * 5 +
-                                    [_i, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "ecg_bn_stats_relu_pool_fwd_h": (_i, [_vp, _i, _ll, _vp, _vp, _vp, _f, _f, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "ecg_bn_relu_pool_bwd_h": (_i, [_vp, _i, _vp, _i, _i] + [_vp] * 5 + [_i] + [_vp] * 3 + [_i] * 4 + [_vp]),
     "ecg_conv1d_bwd_data_bf16hh": (_i, [_vp, _i, _vp, _vp, _i] + [_i] * 6 + [_vp]),
@@ -63,14 +50,13 @@ SIGNATURES = {
     "ecg_conv1d_bf16_tk_dy_stride": (_i, [_i]),
     "ecg_conv1d_bwd_weight_bf16_ncl_ws_floats": (_sz, [_i] * 6),
     "ecg_conv1d_bwd_weight_bias_bf16_ncl": (_i, [_vp, _i, _vp, _i, _i, _vp, _vp, _vp] + [_i] * 6 + [_vp]),
-    "ecg_conv1d_bwd_weight_bf16_packed_ws_floats": (_sz, [_i] * 6),
-    "ecg_conv1d_bwd_weight_bias_bf16_packed": (_i, [_vp] * 5 + [_i] * 6 + [_vp]),
     "ecg_bn_stat_partials_count": (_i, [_i, _i, _i]),
     "ecg_bn_stat_partials": (_i, [_vp, _vp, _i, _i, _i, _vp]),
     "ecg_bn_finalize": (_i, [_vp, _i, _ll, _vp, _vp, _vp, _vp, _vp, _i, _f, _f, _vp]),
     "ecg_bn_invstd": (_i, [_vp, _vp, _i, _f, _vp]),
     "ecg_bn_relu_pool_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
-    "ecg_bn_stats_relu_pool_fwd": (_i, [_vp, _i, _ll, _vp, _vp, _vp, _f, _f] + [_vp] * 7 + [_i] * 6 + [_vp]),
+    "ecg_bn_stats_relu_pool_fwd": (_i, [_vp, _i, _ll, _vp, _vp, _vp, _f, _f] + [_vp] * 6 + [_i] * 4 + [_vp]),
+    "ecg_bn_stats_relu_pool_gap_fwd_yh": (_i, [_vp, _i, _ll, _vp, _vp, _vp, _f, _f, _vp, _i] + [_vp] * 5 + [_i] * 3 + [_vp]),
     "ecg_bn_relu_pool_bwd_ws_floats": (_sz, [_i, _i, _i]),
     "ecg_bn_relu_pool_bwd": (_i, [_vp] * 10 + [_i, _i, _i, _i, _vp]),
     "ecg_bn_relu_pool_bwd_ld": (_i, [_vp] * 7 + [_i] + [_vp] * 3 + [_i, _i, _i, _i, _vp]),

@@ -176,43 +176,6 @@ def _key(t):
     return None if t is None else t.data_ptr()
 
 
-# --------------------------------------------------------------------------------------
-# Side stream for weight gradients.  In a ConvBlock's backward only the input-gradient is on the
-# critical path (the next block's BN-backward passes wait for it); the weight-gradient (MFMA
-# kernel + slab reduce) has no consumer until the optimizer.  It is launched on a second HIP
-# stream so that the HBM-bound BN-backward passes of the following block run underneath it
-# instead of leaving the matrix cores idle.  The main stream re-joins the side stream once,
-# when the backward pass ends (autograd engine callback).
-# Measured on MI355X (B=256, 12x1000): no net gain — 1.94 ms/step with the overlap vs 1.92 without;
-# two MFMA-bound kernels sharing the CUs slow each other by what the hidden BN passes save — so it
-# is OFF by default and kept as an experiment switch (ECG_HIP_OVERLAP=1).
-# --------------------------------------------------------------------------------------
-import os as _os
-
-_OVERLAP = _os.environ.get("ECG_HIP_OVERLAP", "0") == "1"
-_side_streams = {}
-_join_pending = set()
-
-
-def _side_stream(device):
-    key = device.index if device.index is not None else torch.cuda.current_device()
-    if key not in _side_streams:
-        _side_streams[key] = torch.cuda.Stream(device=device)
-    return key, _side_streams[key]
-
-
-def _join_at_end_of_backward(key, side):
-    if key in _join_pending:
-        return
-    _join_pending.add(key)
-
-    def _join():
-        _join_pending.discard(key)
-        torch.cuda.current_stream().wait_stream(side)
-
-    torch.autograd.Variable._execution_engine.queue_callback(_join)
-
-
 def _contig(t):
     return t if t.is_contiguous() else t.contiguous()
 
@@ -229,9 +192,15 @@ def conv1d_pack(w, need_bwd=True):
 
 
 # --------------------------------------------------------------------------------------
-# Conv precision: "fp32" (default, the parity path: exact-fp32 MFMA) or "bf16" (opt-in mixed
-# precision, BASELINE.json config 5: bf16 operands / fp32 accumulate in forward, input-grad and
-# weight-grad; fp32 activations, gradients, BatchNorm, tail, optimizer).  ECG_HIP_CONV_PRECISION sets the process default.
+# Conv precision: "fp32" (default, the parity path: exact-fp32 MFMA) or "bf16" (opt-in mixed precision, BASELINE.json
+# config 5).  The mixed-precision step has ONE form (round 5): a TRAINING ConvBlock (batch statistics, gradients wanted,
+# K = 15, pad = 7, channel counts the bf16 MFMA kernels tile) runs its three convs on bf16 operands with fp32 accumulation
+# and keeps every tensor between its kernels as bf16 rows [N][C][ld] — y, the pooled activation handed to the next
+# block, dY and the input gradient handed back — while parameters, statistics, gradients of parameters, the network
+# input, the tail and the optimizer stay fp32.  A block that does not fit that form (frozen or eval-mode BatchNorm, no
+# gradient wanted, other kernel sizes or channel counts) runs the exact fp32 kernels instead, and tensors crossing between the
+# two forms are fp32: inference is always the fp32 one-launch path.
+# ECG_HIP_CONV_PRECISION sets the process default.
 # --------------------------------------------------------------------------------------
 _conv_precision = _os.environ.get("ECG_HIP_CONV_PRECISION", "fp32")
 
@@ -262,28 +231,6 @@ class conv_precision:
         return False
 
 
-_bf16_activation_storage = True
-
-
-_bf16_row_operands = True      # round 4: the weight gradient reads plain bf16 rows (time on the MFMA's K axis), no n16 copies
-
-
-def set_bf16_row_operands(on):
-    """A/B switch for the mixed-precision train step: True (default) = BatchNorm passes on bf16 rows only + the time-on-K
-    weight gradient (csrc/conv1d_wgrad_bf16_tk.hip, bn_relu_pool_h.hip); False = the rounds-2/3 form, in which the BatchNorm
-    passes also write every p and dY in the "n16" layout of the sample-on-K weight gradient.  Returns the previous setting."""
-    global _bf16_row_operands
-    prev, _bf16_row_operands = _bf16_row_operands, bool(on)
-    return prev
-
-
-def set_bf16_activation_storage(on):
-    """bf16 mode only: store the conv output y of a training ConvBlock as bf16 (what torch.autocast does) — the
-    BatchNorm passes are HBM-bound and y is their largest operand.  On by default; off keeps y in fp32."""
-    global _bf16_activation_storage
-    _bf16_activation_storage = bool(on)
-
-
 def conv1d_pack_bf16(w, need_bwd=True):
     Co, Ci, K = w.shape
     nf = _query("ecg_conv1d_bf16_packed_elems", Ci, Co, K)
@@ -293,19 +240,6 @@ def conv1d_pack_bf16(w, need_bwd=True):
         wb_bwd = torch.empty(_query("ecg_conv1d_bf16_packed_elems", Co, Ci, K), dtype=torch.bfloat16, device=w.device)
     _call("ecg_conv1d_pack_weights_bf16", _f32(w), L.ptr(wb_fwd), L.ptr(wb_bwd), Co, Ci, K, _st())
     return wb_fwd, wb_bwd
-
-
-def conv1d_forward_bf16_raw(x, wb_fwd, bias, Co, K, pad, want_stats):
-    N, Ci, Lin = x.shape
-    Lo = Lin + 2 * pad - K + 1
-    y = _empty(x, N, Co, Lo)
-    partials, P = None, 0
-    if want_stats:
-        P = _query("ecg_conv1d_fwd_bf16_stat_partials", N, Ci, Co, Lin, K, pad)
-        partials = _empty(x, Co * P * 2)
-    _call("ecg_conv1d_fwd_bf16", _f32(x), L.ptr(wb_fwd), _f32(bias), _f32(y), _f32(partials),
-          N, Ci, Co, Lin, K, pad, _st())
-    return y, partials, P
 
 
 class WeightPacker:
@@ -331,7 +265,7 @@ class WeightPacker:
         bf16 kernels take, (w_fwd, w_bwd, wb_fwd, wb_bwd) with the fp32 pair None — the bf16 operands come out of the
         same launch (one launch per step instead of one per layer plus the fp32 one)."""
         srcs = [c.weight for c in convs] + [l.weight for l in linears]
-        mixed = _conv_precision == "bf16"
+        mixed = _conv_precision == "bf16" and bool(need_bwd)       # (without gradients every block runs the fp32 kernels)
         key = (need_bwd, mixed) + tuple((w.data_ptr(), tuple(w.shape)) for w in srcs)
         if key != self._key:
             self._key = key
@@ -340,8 +274,9 @@ class WeightPacker:
                 w = _contig(c.weight)
                 Co, Ci, K = w.shape
                 want_bwd = need_bwd and i > 0                # block 0 has no input-grad
-                sup = _query("ecg_conv1d_bf16_supported", Ci, Co, K, c.padding[0]) if (mixed and K <= 15) else 0
-                if (sup & 1) and (not want_bwd or (sup & 2)):
+                # (bf16 operands for a conv whose geometry fits the mixed-precision form; whether the block really takes it
+                # is decided per call — a block that does not repacks its fp32 operands itself, ConvBlockFn._weights)
+                if mixed and _bf16_block_ok(Ci, Co, K, c.padding[0], 16, want_bwd):
                     wf = wb = None
                     hwf = torch.empty(_query("ecg_conv1d_bf16_packed_elems", Ci, Co, K), dtype=torch.bfloat16, device=w.device)
                     hwb = (torch.empty(_query("ecg_conv1d_bf16_packed_elems", Co, Ci, K), dtype=torch.bfloat16,
@@ -383,48 +318,23 @@ def conv1d_forward_raw(x, w_fwd, bias, Co, K, pad, want_stats):
     return y, partials, P
 
 
-def conv1d_backward_raw(x, dy, w_shape, w_bwd, pad, need_dx, need_db=True, overlap=False, bf16=False,
-                        ldy=None, sink_keys=(None, None)):
-    """dy is [N, C_out, ldy] with ldy >= Lo (row-padded, zero pad) when ldy is given."""
+def conv1d_backward_raw(x, dy, w_shape, w_bwd, pad, need_dx, need_db=True, ldy=None, sink_keys=(None, None)):
+    """fp32 weight / bias / input gradient.  dy is [N, C_out, ldy] with ldy >= Lo (row-padded, zero pad) when ldy is given.
+    (Weight gradient on a side stream under the next block's BatchNorm passes: measured 1.94 against 1.92 ms per step in round 1,
+    1.604 against 1.580 in round 3 — two MFMA-bound kernels sharing the CUs lose what the hidden passes save; removed.)"""
     N, Ci, Lin = x.shape
     Co, _, K = w_shape
     if ldy is None:
         ldy = Lin + 2 * pad - K + 1
-    main = torch.cuda.current_stream()
-    # mixed precision: bf16-operand weight gradient where the shape allows it (bit 2), fp32 otherwise
-    wg_bf16 = bf16 and bool(_query("ecg_conv1d_bf16_supported", Ci, Co, K, pad) & 4)
-    ws_floats = max(1, _query("ecg_conv1d_bwd_weight_bf16_ws_floats" if wg_bf16 else "ecg_conv1d_bwd_weight_ws_floats",
-                              N, Ci, Co, Lin, K, pad))
-
-    def weight_grad():
-        dw = _grad_out(sink_keys[0], x, Co, Ci, K)
-        db = _grad_out(sink_keys[1], x, Co) if need_db else None
-        ws = _empty(x, ws_floats)
-        _call("ecg_conv1d_bwd_weight_bias_bf16" if wg_bf16 else "ecg_conv1d_bwd_weight_bias_ld", _f32(dy), ldy,
-              _f32(x), _f32(dw), _f32(db), _f32(ws), N, Ci, Co, Lin, K, pad, _st())
-        return dw, db
-
-    if overlap and _OVERLAP and need_dx:
-        key, side = _side_stream(x.device)
-        side.wait_stream(main)                     # dy (and x) are complete on the main stream
-        with torch.cuda.stream(side):
-            dw, db = weight_grad()
-        for t in (dy, x):
-            t.record_stream(side)                  # the allocator must not recycle them under the side stream
-        for t in (dw, db):
-            if t is not None:
-                t.record_stream(main)              # consumed on the main stream after the join
-        _join_at_end_of_backward(key, side)
-    else:
-        dw, db = weight_grad()
+    dw = _grad_out(sink_keys[0], x, Co, Ci, K)
+    db = _grad_out(sink_keys[1], x, Co) if need_db else None
+    ws = _empty(x, max(1, _query("ecg_conv1d_bwd_weight_ws_floats", N, Ci, Co, Lin, K, pad)))
+    _call("ecg_conv1d_bwd_weight_bias_ld", _f32(dy), ldy, _f32(x), _f32(dw), _f32(db), _f32(ws), N, Ci, Co, Lin, K, pad,
+          _st())
     dx = None
     if need_dx:
         dx = torch.empty_like(x)
-        if bf16:
-            _call("ecg_conv1d_bwd_data_bf16", _f32(dy), L.ptr(w_bwd), _f32(dx), N, Ci, Co, Lin, K, pad, _st())
-        else:
-            _call("ecg_conv1d_bwd_data_ld", _f32(dy), ldy, _f32(w_bwd), _f32(dx), N, Ci, Co, Lin, K, pad,
-                  _st())
+        _call("ecg_conv1d_bwd_data_ld", _f32(dy), ldy, _f32(w_bwd), _f32(dx), N, Ci, Co, Lin, K, pad, _st())
     return dx, dw, db
 
 
@@ -459,236 +369,141 @@ def _bn_momentum(momentum, nbt):
 # --------------------------------------------------------------------------------------
 # Fused ConvBlock: Conv1d -> BatchNorm1d -> ReLU -> MaxPool1d(2)
 # --------------------------------------------------------------------------------------
+def _bf16_block_ok(Ci, Co, K, pad, Lin, need_dx):
+    """Geometry test of the mixed-precision block form: the bf16 forward (bit 0 of ecg_conv1d_bf16_supported), the time-on-K
+    weight gradient (bit 2: K == 15, pad == 7, C_out % 32 == 0 — which also gives the odd pad / odd K-1-pad the position-pair
+    staging of bf16 rows needs), the bf16 input gradient when one is wanted (bit 1), and a pooled row that is not empty."""
+    if K > 15:
+        return False
+    sup = _query("ecg_conv1d_bf16_supported", Ci, Co, K, pad)
+    return bool((sup & 1) and (sup & 4) and (not need_dx or (sup & 2)) and Lin + 2 * pad - K + 1 >= 2)
+
+
+_EVAL, _FP32, _BF16 = "eval", "fp32", "bf16"
+
+
 class ConvBlockFn(torch.autograd.Function):
-    """reference src/models/ecg_cnn.py:12-17 as 3 launches forward (conv + BN-statistics
-    epilogue, finalize, BN-apply+ReLU+pool) and 5-6 backward."""
+    """reference src/models/ecg_cnn.py:12-17 as 3 launches forward (conv + BN-statistics epilogue, statistics combine +
+    BN-apply + ReLU + pool) and 3-4 backward.  ONE dispatch at the top picks the form of the block, recorded in ctx.mode and
+    reused by backward:
+      eval   inference (running statistics, no gradient wanted): conv + folded BN + ReLU + pool [+ GAP] in one launch
+      bf16   the mixed-precision training form (set_conv_precision("bf16"), see _bf16_block_ok): bf16 rows between the kernels
+      fp32   everything else — the parity path"""
 
     @staticmethod
     def forward(ctx, x, w, b, gamma, beta, running_mean, running_var, nbt, training, momentum,
-                eps, pad, gap=False, packed=None, grad_enabled=True, x_n16=None, next_geom=None):
-        """Returns (p, p_n16).  p_n16 is None except in bf16 mode when `next_geom` = (K, pad[, C_out, trains]) of the
-        conv block that consumes p is given: then the BN+ReLU+pool pass also writes p in the bf16 "n16" layout that
-        conv's weight gradient reads (no packing pass later).  `x_n16` is this block's own input in that layout (from
-        the previous block), kept for backward — or the carry of conv_block_chain, (n16 tensor, true row length),
-        when x itself arrives as a bf16 [N][C][ld] activation.  With bf16 activation storage and a next block that
-        trains (all four fields of next_geom), p is returned as bf16 [N][C_out][ldp] instead of fp32."""
+                eps, pad, gap=False, packed=None, grad_enabled=True, x_len=None, next_bf16=False):
+        """Returns p: fp32 [N][C_out][Lo/2] ([N][C_out] with `gap`), or — bf16 form with `next_bf16` (the caller's promise that
+        the block consuming p takes the bf16 form too) — bf16 [N][C_out][ldp] with rows zero-filled past Lo/2.  `x_len` is
+        the true row length when x itself is such a bf16 activation [N][C_in][ldx]."""
         x, w = _contig(x), _contig(w)
-        Co, _, K = w.shape
-        x_len = None
-        if isinstance(x_n16, tuple):          # the carry of conv_block_chain: (n16 operand, true row length of a bf16 x)
-            x_n16, x_len = x_n16
-        x_h = x.dtype == torch.bfloat16       # bf16 activation storage: x is the previous block's p, bf16 [N][C][ldx]
+        Co, Ci, K = w.shape
+        x_h = x.dtype == torch.bfloat16
         use_batch = training or running_mean is None
         # grad mode is always off INSIDE forward and needs_input_grad ignores torch.no_grad(): the caller
         # samples torch.is_grad_enabled() and hands it in, so that inference takes the one-launch kernel
         need_grad = grad_enabled and any(ctx.needs_input_grad)
-        sup = _query("ecg_conv1d_bf16_supported", x.shape[1], Co, K, pad) if _conv_precision == "bf16" else 0
-        need_dx = need_grad and ctx.needs_input_grad[0]
-        bf16 = bool(sup & 1) and (not need_dx or bool(sup & 2))     # block 0 (no input-grad) only needs the forward
-        ctx.bf16 = bf16
-        if bf16 and packed is not None and len(packed) == 4 and (packed[3] is not None or not need_dx):
-            w_fwd, w_bwd = packed[2], packed[3]          # bf16 operands out of WeightPacker's one launch
-        elif bf16:
-            w_fwd, w_bwd = conv1d_pack_bf16(w, need_bwd=need_grad and ctx.needs_input_grad[0])
-        elif packed is not None and packed[0] is not None and (packed[1] is not None or not ctx.needs_input_grad[0]):
-            w_fwd, w_bwd = packed[0], packed[1]          # packed by WeightPacker for the whole model
-        else:
-            w_fwd, w_bwd = conv1d_pack(w, need_bwd=need_grad and ctx.needs_input_grad[0])
-        if not use_batch and not need_grad and not bf16:
-            # pure inference: conv + folded BN + ReLU + pool (+ global average pool) in ONE launch, y never written
-            N, Ci, Lin = x.shape
-            Lo = Lin + 2 * pad - K + 1
-            if not gap and _query("ecg_conv1d_bn_relu_pool_eval_supported", Ci, Co, K, pad):
-                p = _empty(x, N, Co, Lo // 2)
-                _call("ecg_conv1d_bn_relu_pool_eval_fwd", _f32(x), _f32(w_fwd), _f32(b), _f32(gamma),
-                      _f32(beta), _f32(running_mean), _f32(running_var), float(eps), _f32(p),
-                      N, Ci, Co, Lin, K, pad, _st())
-                return p, None
-            if gap and _query("ecg_conv1d_bn_relu_pool_gap_eval_supported", Ci, Co, Lin, K, pad):
-                g = _empty(x, N, Co)
-                _call("ecg_conv1d_bn_relu_pool_gap_eval_fwd", _f32(x), _f32(w_fwd), _f32(b), _f32(gamma),
-                      _f32(beta), _f32(running_mean), _f32(running_var), float(eps), _f32(g),
-                      N, Ci, Co, Lin, K, pad, _st())
-                return g, None
-        N, Ci, Lin = x.shape
-        ldx = 0
-        if x_h:
-            ldx, Lin = Lin, x_len
-            if not (bf16 and use_batch and need_grad and _bf16_chain_ok(Ci, Co, K, pad, Lin)):
-                raise L.EcgHipError("ConvBlock: a bf16 activation arrived at a block that cannot consume it")
+        need_dx = bool(need_grad and ctx.needs_input_grad[0])
+        Lin = x_len if x_h else x.shape[2]
         Lo = Lin + 2 * pad - K + 1
-        p_n16, PX, shift = None, 0, 0
-        # Round 4: when the NEXT block's weight gradient is the time-on-K kernel (csrc/conv1d_wgrad_bf16_tk.hip) every
-        # consumer of p reads plain bf16 rows: no n16 copy, and the statistics + pool pass is the row-streaming "h" kernel.
-        rows_next = bool(_bf16_row_operands and not gap and bf16 and _bf16_activation_storage and use_batch and need_grad and Lo >= 2
-                         and next_geom is not None and len(next_geom) >= 4 and next_geom[3]
-                         and _bf16_chain_ok(Co, next_geom[2], next_geom[0], next_geom[1], Lo // 2)
-                         and _query("ecg_conv1d_bf16_tk_supported", Co, next_geom[2], next_geom[0], next_geom[1]))
-        if not gap and bf16 and need_grad and next_geom is not None and Lo >= 2 and not rows_next:
-            # mixed precision: p also as the next conv's weight-gradient operand (bf16, n16 layout)
-            PX, shift = _query("ecg_conv1d_n16_positions", Lo // 2, next_geom[0], next_geom[1], 1), next_geom[1]
-        # bf16 activation storage: only when both consumers of y are the kernels that read it (the fused
-        # statistics + pool pass in its n16 / gap form now, the n16 BatchNorm backward later)
-        ldyh = 0
-        if (bf16 and _bf16_activation_storage and use_batch and need_grad and Lo >= 2 and (gap or PX or rows_next) and (sup & 4)
-                and _query("ecg_conv1d_n16_positions", Lin, K, pad, 0)):
-            ldyh = (Lo + 7) & ~7
-        # ... and p itself as bf16 [N][Co][ldp] (instead of fp32) when the next block is one that reads it: its forward
-        # conv then reads half the bytes, and its input gradient comes back as bf16 of the same shape
-        ldp = 0
-        if ldyh and (rows_next or (PX and len(next_geom) >= 4 and next_geom[3]
-                                   and _bf16_chain_ok(Co, next_geom[2], next_geom[0], next_geom[1], Lo // 2))):
-            ldp = (Lo // 2 + 7) & ~7
-        if x_h and not ldyh:
-            # the producer wrote p as bf16 because THIS block looked able to read it (_bf16_chain_ok), but the bf16-y
-            # forward is not taken here (the block after this one is not a K=15/pad=7 conv, or activation storage was
-            # switched off between the two calls): the fp32 kernels below cannot read a bf16 x
-            raise L.EcgHipError("ConvBlock: input arrived as a bf16 activation but this block does not take the bf16-"
-                                "storage forward (next block's geometry, or set_bf16_activation_storage() changed "
-                                "between blocks); run the chain with activation storage off")
-        if ldyh:
-            y = torch.empty(N, Co, ldyh, dtype=torch.bfloat16, device=x.device)
-            P = _query("ecg_conv1d_fwd_bf16_yh_stat_partials", N, Ci, Co, Lin, K, pad, 1 if x_h else 0, ldx, ldyh)
-            partials = _empty(x, Co * P * 2)
-            _call("ecg_conv1d_fwd_bf16_yh", L.ptr(x), 1 if x_h else 0, ldx, L.ptr(w_fwd), _f32(b), L.ptr(y), ldyh,
-                  _f32(partials), N, Ci, Co, Lin, K, pad, _st())
-        elif bf16:
-            y, partials, P = conv1d_forward_bf16_raw(x, w_fwd, b, Co, K, pad, want_stats=use_batch)
-        else:
-            y, partials, P = conv1d_forward_raw(x, w_fwd, b, Co, K, pad, want_stats=use_batch)
-        if PX:
-            p_n16 = torch.empty(((N + 15) // 16) * Co * PX * 16, dtype=torch.bfloat16, device=x.device)
-            ctx.mark_non_differentiable(p_n16)
-            ctx.set_materialize_grads(False)     # no zero-filled "gradient" for the n16 by-product (41 MB fill)
-        if ldp:
-            p, p_f32 = torch.empty(N, Co, ldp, dtype=torch.bfloat16, device=x.device), None
-        else:
-            p = p_f32 = _empty(x, N, Co) if gap else _empty(x, N, Co, Lo // 2)
-        mode = 1 if gap else (2 if PX else 0)
+        if Lo <= 0:
+            raise L.EcgHipError(f"conv1d: empty output for L={Lin}, K={K}, pad={pad}")
+        mode = _FP32
+        if _conv_precision == "bf16" and use_batch and need_grad and _bf16_block_ok(Ci, Co, K, pad, Lin, need_dx):
+            mode = _BF16
+        elif not use_batch and not need_grad:
+            mode = _EVAL
+        if x_h and mode != _BF16:
+            # the producer wrote p as bf16 because this block looked able to read it: the precision was switched, or a
+            # BatchNorm frozen, between the two calls
+            raise L.EcgHipError("ConvBlock: input arrived as a bf16 activation but this block does not take the mixed-"
+                                "precision form (conv precision / BatchNorm mode changed between blocks?)")
+        ctx.mode, ctx.pad, ctx.gap, ctx.batch_stats, ctx.Lin, ctx.Lo = mode, pad, gap, use_batch, Lin, Lo
+        ctx.sink_keys = (_key(w), _key(b), _key(gamma), _key(beta))
+        if mode == _EVAL:
+            p = ConvBlockFn._fwd_eval(x, w, b, gamma, beta, running_mean, running_var, eps, pad, gap, packed)
+            if p is not None:
+                return p
+            ctx.mode = mode = _FP32            # (a shape the one-launch kernel does not tile: the three-launch sequence)
+        if mode == _BF16:
+            return ConvBlockFn._fwd_bf16(ctx, x, w, b, gamma, beta, running_mean, running_var, nbt, training, momentum, eps,
+                                         packed, need_dx, next_bf16)
+        return ConvBlockFn._fwd_fp32(ctx, x, w, b, gamma, beta, running_mean, running_var, nbt, training, momentum, eps,
+                                     packed, need_grad, need_dx)
+
+    # ---- weights: from the model's grouped repack when it holds what this form needs, else packed here -------------------
+    @staticmethod
+    def _weights(w, packed, bf16, need_bwd):
+        if bf16:
+            if packed is not None and len(packed) == 4 and packed[2] is not None and (packed[3] is not None or not need_bwd):
+                return packed[2], packed[3]
+            return conv1d_pack_bf16(w, need_bwd=need_bwd)
+        if packed is not None and packed[0] is not None and (packed[1] is not None or not need_bwd):
+            return packed[0], packed[1]
+        return conv1d_pack(w, need_bwd=need_bwd)
+
+    # ---- eval: one launch, y never written --------------------------------------------------------------------------
+    @staticmethod
+    def _fwd_eval(x, w, b, gamma, beta, running_mean, running_var, eps, pad, gap, packed):
+        N, Ci, Lin = x.shape
+        Co, _, K = w.shape
+        Lo = Lin + 2 * pad - K + 1
+        if not gap and _query("ecg_conv1d_bn_relu_pool_eval_supported", Ci, Co, K, pad):
+            w_fwd, _ = ConvBlockFn._weights(w, packed, False, False)
+            p = _empty(x, N, Co, Lo // 2)
+            _call("ecg_conv1d_bn_relu_pool_eval_fwd", _f32(x), _f32(w_fwd), _f32(b), _f32(gamma), _f32(beta),
+                  _f32(running_mean), _f32(running_var), float(eps), _f32(p), N, Ci, Co, Lin, K, pad, _st())
+            return p
+        if gap and _query("ecg_conv1d_bn_relu_pool_gap_eval_supported", Ci, Co, Lin, K, pad):
+            w_fwd, _ = ConvBlockFn._weights(w, packed, False, False)
+            g = _empty(x, N, Co)
+            _call("ecg_conv1d_bn_relu_pool_gap_eval_fwd", _f32(x), _f32(w_fwd), _f32(b), _f32(gamma), _f32(beta),
+                  _f32(running_mean), _f32(running_var), float(eps), _f32(g), N, Ci, Co, Lin, K, pad, _st())
+            return g
+        return None
+
+    # ---- fp32: the parity path ----------------------------------------------------------------------------------------
+    @staticmethod
+    def _fwd_fp32(ctx, x, w, b, gamma, beta, running_mean, running_var, nbt, training, momentum, eps, packed, need_grad,
+                  need_dx):
+        N, Ci, Lin = x.shape
+        Co, _, K = w.shape
+        pad, gap, use_batch, Lo = ctx.pad, ctx.gap, ctx.batch_stats, ctx.Lo
+        w_fwd, w_bwd = ConvBlockFn._weights(w, packed, False, need_dx)
+        y, partials, P = conv1d_forward_raw(x, w_fwd, b, Co, K, pad, want_stats=use_batch)
+        p = _empty(x, N, Co) if gap else _empty(x, N, Co, Lo // 2)
         if use_batch:
             # statistics combine + BN-apply + ReLU + pool in ONE launch (ecg_bn_finalize folded into the streaming pass)
             rm, rv, cnt = (running_mean, running_var, nbt) if training else (None, None, None)
             if cnt is not None and cnt.dtype != torch.int64:
                 raise L.EcgHipError("num_batches_tracked must be int64")
             mean, invstd = _empty(x, Co), _empty(x, Co)
-            if ldyh and rows_next:
-                _call("ecg_bn_stats_relu_pool_fwd_h", _f32(partials), P, N * Lo, _f32(rm), _f32(rv), L.ptr(cnt),
-                      _bn_momentum(momentum, nbt), float(eps), L.ptr(y), ldyh, _f32(gamma), _f32(beta), _f32(mean),
-                      _f32(invstd), L.ptr(p), ldp, N, Co, Lo, _st())
-            elif ldyh:
-                _call("ecg_bn_stats_relu_pool_fwd_yh", _f32(partials), P, N * Lo, _f32(rm), _f32(rv), L.ptr(cnt),
-                      _bn_momentum(momentum, nbt), float(eps), L.ptr(y), ldyh, _f32(gamma), _f32(beta), _f32(mean),
-                      _f32(invstd), _f32(p_f32), L.ptr(p_n16), L.ptr(p) if ldp else None, ldp, N, Co, Lo, PX, shift, mode,
-                      _st())
-            else:
-                _call("ecg_bn_stats_relu_pool_fwd", _f32(partials), P, N * Lo, _f32(rm), _f32(rv), L.ptr(cnt),
-                      _bn_momentum(momentum, nbt), float(eps), _f32(y), _f32(gamma), _f32(beta), _f32(mean), _f32(invstd),
-                      _f32(p), L.ptr(p_n16), N, Co, Lo, PX, shift, mode, _st())
+            _call("ecg_bn_stats_relu_pool_fwd", _f32(partials), P, N * Lo, _f32(rm), _f32(rv), L.ptr(cnt),
+                  _bn_momentum(momentum, nbt), float(eps), _f32(y), _f32(gamma), _f32(beta), _f32(mean), _f32(invstd),
+                  _f32(p), N, Co, Lo, 1 if gap else 0, _st())
         else:
             mean, invstd = bn_eval_stats(running_mean, running_var, eps)
-            if gap:      # last block: AdaptiveAvgPool1d(1) folded in, the pooled tensor never exists
-                _call("ecg_bn_relu_pool_gap_fwd", _f32(y), _f32(gamma), _f32(beta), _f32(mean),
-                      _f32(invstd), _f32(p), N, Co, Lo, _st())
-            elif PX:
-                _call("ecg_bn_relu_pool_fwd_n16", _f32(y), _f32(gamma), _f32(beta), _f32(mean), _f32(invstd),
-                      _f32(p), L.ptr(p_n16), N, Co, Lo, PX, shift, _st())
-            else:
-                _call("ecg_bn_relu_pool_fwd", _f32(y), _f32(gamma), _f32(beta), _f32(mean), _f32(invstd),
-                      _f32(p), N, Co, Lo, _st())
+            # (last block: AdaptiveAvgPool1d(1) folded in, the pooled tensor never exists)
+            _call("ecg_bn_relu_pool_gap_fwd" if gap else "ecg_bn_relu_pool_fwd", _f32(y), _f32(gamma), _f32(beta),
+                  _f32(mean), _f32(invstd), _f32(p), N, Co, Lo, _st())
         ctx.save_for_backward(x, w, y, gamma, beta, mean, invstd)
-        ctx.w_bwd, ctx.pad, ctx.batch_stats, ctx.gap = w_bwd, pad, use_batch, gap
-        ctx.sink_keys = (_key(w), _key(b), _key(gamma), _key(beta))
-        ctx.x_n16 = x_n16 if bf16 else None
-        ctx.ldyh, ctx.Lo, ctx.Lin, ctx.ldp = ldyh, Lo, Lin, ldp
-        return p, p_n16
+        ctx.w_bwd = w_bwd
+        return p
 
     @staticmethod
-    def backward(ctx, dp, _dp_n16=None):
+    def _bwd_fp32(ctx, dp):
         x, w, y, gamma, beta, mean, invstd = ctx.saved_tensors
-        N, Co, Lo = y.shape[0], y.shape[1], ctx.Lo          # (y may be bf16 with padded rows: ctx.ldyh)
+        N, Co, Lo = y.shape
         if dp is None:          # (only possible with set_materialize_grads(False): p unused downstream)
-            dp = (torch.zeros(N, Co, ctx.ldp, dtype=torch.bfloat16, device=y.device) if ctx.ldp else
-                  torch.zeros(N, Co, *(() if ctx.gap else (Lo // 2,)), device=y.device))
+            dp = torch.zeros(N, Co, *(() if ctx.gap else (Lo // 2,)), device=y.device)
         dp = _contig(dp)
-        if ctx.ldp and (dp.dtype != torch.bfloat16 or dp.shape[2] != ctx.ldp):
-            raise L.EcgHipError("ConvBlock backward: the gradient of a bf16 activation must be bf16 of the same shape")
-        Ci, Lin, K = x.shape[1], ctx.Lin, w.shape[2]
-        x_h = x.dtype == torch.bfloat16
+        Ci, Lin, K = x.shape[1], x.shape[2], w.shape[2]
         need_dx = ctx.needs_input_grad[0]
         kw, kb, kg, kbe = ctx.sink_keys
         dgamma, dbeta = _grad_out(kg, y, Co), _grad_out(kbe, y, Co)
-        ws = _empty(y, _query("ecg_bn_relu_pool_bwd_ws_floats", N, Co, Lo))
-        nones = (None,) * 12
-        PA = _query("ecg_conv1d_n16_positions", Lin, K, ctx.pad, 0) if ctx.bf16 else 0
-        rows = bool(_bf16_row_operands and PA and ctx.ldyh and Lo >= 2 and ctx.batch_stats
-                    and _query("ecg_conv1d_bf16_tk_supported", Ci, Co, K, ctx.pad)
-                    and (x_h or (Lin % 8 == 0 and not need_dx)))
-        if rows:
-            # Round 4: plain bf16 rows end to end.  BatchNorm backward (reduction + dx, 16 bytes per lane) writes dY ONCE, as
-            # bf16 [N][Co][ldt] with rows zero-filled to a multiple of 128; the time-on-K weight gradient and the input
-            # gradient both read it; x is the previous block's bf16 activation (or the fp32 network input)
-            ldt = _query("ecg_conv1d_bf16_tk_dy_stride", Lo)
-            dyh = torch.empty(N, Co, ldt, dtype=torch.bfloat16, device=y.device)
-            # dp: the fp32 gradient of the fused global average pool [N][Co], bf16 rows [N][Co][ldp], or fp32 rows [N][Co][Lo/2]
-            dp_kind, dp_ld = (1, 0) if ctx.gap else ((0, ctx.ldp) if ctx.ldp else (2, Lo // 2))
-            _call("ecg_bn_relu_pool_bwd_h", L.ptr(y), ctx.ldyh, L.ptr(dp), dp_kind, dp_ld, _f32(gamma), _f32(beta), _f32(mean),
-                  _f32(invstd), L.ptr(dyh), ldt, _f32(dgamma), _f32(dbeta), _f32(ws), N, Co, Lo, 1, _st())
-            dw, db = _grad_out(kw, x, Co, Ci, K), _grad_out(kb, x, Co)
-            ws2 = _empty(y, max(1, _query("ecg_conv1d_bwd_weight_bf16_ncl_ws_floats", N, Ci, Co, Lin, K, ctx.pad)))
-            _call("ecg_conv1d_bwd_weight_bias_bf16_ncl", L.ptr(dyh), ldt, L.ptr(x), 1 if x_h else 0, x.shape[2], _f32(dw),
-                  _f32(db), _f32(ws2), N, Ci, Co, Lin, K, ctx.pad, _st())
-            dx = None
-            if need_dx:         # (rows implies x_h here: the previous block's dp comes back as bf16 of x's shape)
-                dx = torch.empty_like(x)
-                _call("ecg_conv1d_bwd_data_bf16hh", L.ptr(dyh), ldt, L.ptr(ctx.w_bwd), L.ptr(dx), x.shape[2], N, Ci, Co,
-                      Lin, K, ctx.pad, _st())
-            return (dx, dw, db, dgamma, dbeta) + nones
-        if PA and Lo >= 2 and (_query("ecg_conv1d_bf16_supported", Ci, Co, K, ctx.pad) & 4):
-            # mixed precision: the BatchNorm backward writes dY straight in the weight gradient's operand layout
-            # (bf16 n16) — and in fp32 only when an input gradient follows; x is already there from the forward
-            # pass of the previous block (or packed here for the first block)
-            G = (N + 15) // 16
-            # the input gradient reads dY as bf16 [N][C][PA] when its staging can pair positions (odd K-1-pad);
-            # the fp32 dY is then never written
-            dyh_ok = need_dx and ((K - 1 - ctx.pad) & 1) == 1
-            dy = _empty(y, N, Co, Lo) if (need_dx and not dyh_ok) else None
-            dyh = torch.empty(N * Co * PA, dtype=torch.bfloat16, device=y.device) if dyh_ok else None
-            dyb = torch.empty(G * Co * PA * 16, dtype=torch.bfloat16, device=y.device)
-            if ctx.ldyh:        # y was stored as bf16 [N][Co][ldyh]
-                _call("ecg_bn_relu_pool_bwd_n16_yh", L.ptr(y), ctx.ldyh, L.ptr(dp), 1 if ctx.ldp else 0, ctx.ldp,
-                      _f32(gamma), _f32(beta), _f32(mean), _f32(invstd), _f32(dy), Lo, L.ptr(dyb), PA, _f32(dgamma),
-                      _f32(dbeta), _f32(ws), N, Co, Lo, 1 if ctx.batch_stats else 0, 1 if ctx.gap else 0, L.ptr(dyh), _st())
-            else:
-                _call("ecg_bn_relu_pool_bwd_n16", _f32(y), _f32(dp), _f32(gamma), _f32(beta), _f32(mean), _f32(invstd),
-                      _f32(dy), Lo, L.ptr(dyb), PA, _f32(dgamma), _f32(dbeta), _f32(ws), N, Co, Lo,
-                      1 if ctx.batch_stats else 0, 1 if ctx.gap else 0, L.ptr(dyh), _st())
-            xb = ctx.x_n16
-            PX = _query("ecg_conv1d_n16_positions", Lin, K, ctx.pad, 1)
-            if xb is None or xb.numel() != G * Ci * PX * 16:
-                if x_h:
-                    raise L.EcgHipError("ConvBlock backward: a bf16 input came without its n16 operand")
-                xb = torch.empty(G * Ci * PX * 16, dtype=torch.bfloat16, device=y.device)
-                _call("ecg_pack_n16", _f32(x), L.ptr(xb), N, Ci, Lin, Lin, PX, ctx.pad, _st())
-            dw, db = _grad_out(kw, x, Co, Ci, K), _grad_out(kb, x, Co)
-            ws2 = _empty(x, max(1, _query("ecg_conv1d_bwd_weight_bf16_packed_ws_floats", N, Ci, Co, Lin, K, ctx.pad)))
-            _call("ecg_conv1d_bwd_weight_bias_bf16_packed", L.ptr(dyb), L.ptr(xb), _f32(dw), _f32(db), _f32(ws2),
-                  N, Ci, Co, Lin, K, ctx.pad, _st())
-            dx = None
-            if need_dx:
-                dx = torch.empty_like(x)
-                if x_h:         # the previous block's dp, bf16 [N][Ci][ldx] like x itself (x_h implies dyh_ok)
-                    _call("ecg_conv1d_bwd_data_bf16hh", L.ptr(dyh), PA, L.ptr(ctx.w_bwd), L.ptr(dx), x.shape[2], N, Ci, Co,
-                          Lin, K, ctx.pad, _st())
-                elif dyh_ok:
-                    _call("ecg_conv1d_bwd_data_bf16h", L.ptr(dyh), PA, L.ptr(ctx.w_bwd), _f32(dx), N, Ci, Co, Lin, K,
-                          ctx.pad, _st())
-                else:
-                    _call("ecg_conv1d_bwd_data_bf16", _f32(dy), L.ptr(ctx.w_bwd), _f32(dx), N, Ci, Co, Lin, K, ctx.pad, _st())
-            return (dx, dw, db, dgamma, dbeta) + nones
         # dY never leaves this function: give it the row stride the conv gradients stream best
         # (rows padded to 64 floats, zero pad -> LDS-DMA in the weight gradient)
-        ldy = Lo if (ctx.bf16 and need_dx) else _query("ecg_conv1d_dy_row_stride", N, Ci, Co, Lin, K, ctx.pad,
-                                                       int(bool(need_dx)))
+        ldy = _query("ecg_conv1d_dy_row_stride", N, Ci, Co, Lin, K, ctx.pad, int(bool(need_dx)))
         dy = _empty(y, N, Co, ldy)
         if bn_backward_one_launch_allowed(kw) and _query("ecg_bn_relu_pool_bwd_one_launch_splits", N, Co, Lo, ldy):
             # operands resident in registers: one launch, one read of (dp, y); the exchange words are ours
@@ -698,179 +513,113 @@ class ConvBlockFn(torch.autograd.Function):
                   _f32(invstd), _f32(dy), ldy, _f32(dgamma), _f32(dbeta), L.ptr(cnt), N, Co, Lo,
                   1 if ctx.batch_stats else 0, 1 if ctx.gap else 0, _bn_spin_polls, _st())
         else:
+            ws = _empty(y, _query("ecg_bn_relu_pool_bwd_ws_floats", N, Co, Lo))
             _call("ecg_bn_relu_pool_gap_bwd_ld" if ctx.gap else "ecg_bn_relu_pool_bwd_ld", _f32(y), _f32(dp),
                   _f32(gamma), _f32(beta), _f32(mean), _f32(invstd), _f32(dy), ldy, _f32(dgamma),
                   _f32(dbeta), _f32(ws), N, Co, Lo, 1 if ctx.batch_stats else 0, _st())
-        dx, dw, db = conv1d_backward_raw(x, dy, w.shape, ctx.w_bwd, ctx.pad, need_dx,
-                                         overlap=True, bf16=ctx.bf16, ldy=ldy, sink_keys=(kw, kb))
-        return (dx, dw, db, dgamma, dbeta) + nones
+        dx, dw, db = conv1d_backward_raw(x, dy, w.shape, ctx.w_bwd, ctx.pad, need_dx, ldy=ldy, sink_keys=(kw, kb))
+        return dx, dw, db, dgamma, dbeta
 
-
-# --------------------------------------------------------------------------------------
-# Unfused leaves (hook-compatible path)
-# --------------------------------------------------------------------------------------
-class Conv1dFn(torch.autograd.Function):
+    # ---- bf16: the mixed-precision training form (plain bf16 rows end to end) -----------------------------------------
     @staticmethod
-    def forward(ctx, x, w, b, pad):
-        x, w = _contig(x), _contig(w)
+    def _fwd_bf16(ctx, x, w, b, gamma, beta, running_mean, running_var, nbt, training, momentum, eps, packed, need_dx,
+                  next_bf16):
+        N, Ci = x.shape[0], x.shape[1]
         Co, _, K = w.shape
-        w_fwd, w_bwd = conv1d_pack(w, need_bwd=ctx.needs_input_grad[0])
-        y, _, _ = conv1d_forward_raw(x, w_fwd, b, Co, K, pad, want_stats=False)
-        ctx.save_for_backward(x, w)
-        ctx.w_bwd, ctx.pad, ctx.has_bias = w_bwd, pad, b is not None
-        return y
-
-    @staticmethod
-    def backward(ctx, dy):
-        x, w = ctx.saved_tensors
-        dx, dw, db = conv1d_backward_raw(x, _contig(dy), w.shape, ctx.w_bwd, ctx.pad,
-                                         ctx.needs_input_grad[0], need_db=ctx.has_bias)
-        return dx, dw, db, None
-
-
-class BatchNormFn(torch.autograd.Function):
-    @staticmethod
-    def forward(ctx, y, gamma, beta, running_mean, running_var, nbt, training, momentum, eps):
-        y = _contig(y)
-        N, C, Lo = y.shape
-        use_batch = training or running_mean is None
-        if use_batch:
-            rm, rv, cnt = (running_mean, running_var, nbt) if training else (None, None, None)
-            mean, invstd = bn_batch_stats(y, None, 0, rm, rv, cnt, _bn_momentum(momentum, nbt), eps)
+        pad, gap, Lin, Lo = ctx.pad, ctx.gap, ctx.Lin, ctx.Lo
+        x_h = x.dtype == torch.bfloat16
+        ctx.x_cast = False
+        if not x_h and (need_dx or Lin % 8 != 0 or x.data_ptr() % 16 != 0):
+            # an fp32 input the kernels cannot take as it is — an input gradient is wanted (it comes back as bf16 rows), the
+            # row length is not a multiple of 8, or the tensor is not 16-byte aligned (the network input read in place by
+            # block 0 is the aligned, gradient-free case): make the bf16 rows here, with torch ops; backward widens dx again
+            xh = torch.zeros(N, Ci, (Lin + 7) & ~7, dtype=torch.bfloat16, device=x.device)
+            xh[:, :, :Lin].copy_(x)
+            x, x_h, ctx.x_cast = xh, True, True
+        ldx = x.shape[2] if x_h else 0
+        w_fwd, w_bwd = ConvBlockFn._weights(w, packed, True, need_dx)
+        # y as bf16 [N][Co][ldyh] (what torch.autocast would keep): the BatchNorm passes are HBM-bound and y is their
+        # largest operand; the statistics are taken over the rounded values
+        ldyh = (Lo + 7) & ~7
+        y = torch.empty(N, Co, ldyh, dtype=torch.bfloat16, device=x.device)
+        P = _query("ecg_conv1d_fwd_bf16_yh_stat_partials", N, Ci, Co, Lin, K, pad, 1 if x_h else 0, ldx, ldyh)
+        partials = _empty(x, Co * P * 2)
+        _call("ecg_conv1d_fwd_bf16_yh", L.ptr(x), 1 if x_h else 0, ldx, L.ptr(w_fwd), _f32(b), L.ptr(y), ldyh,
+              _f32(partials), N, Ci, Co, Lin, K, pad, _st())
+        rm, rv, cnt = (running_mean, running_var, nbt) if training else (None, None, None)
+        if cnt is not None and cnt.dtype != torch.int64:
+            raise L.EcgHipError("num_batches_tracked must be int64")
+        mean, invstd = _empty(x, Co), _empty(x, Co)
+        ldp = 0
+        if gap:
+            p = _empty(x, N, Co)
+            _call("ecg_bn_stats_relu_pool_gap_fwd_yh", _f32(partials), P, N * Lo, _f32(rm), _f32(rv), L.ptr(cnt),
+                  _bn_momentum(momentum, nbt), float(eps), L.ptr(y), ldyh, _f32(gamma), _f32(beta), _f32(mean), _f32(invstd),
+                  _f32(p), N, Co, Lo, _st())
         else:
-            mean, invstd = bn_eval_stats(running_mean, running_var, eps)
-        out = torch.empty_like(y)
-        _call("ecg_bn_apply_fwd", _f32(y), _f32(gamma), _f32(beta), _f32(mean), _f32(invstd),
-              _f32(out), N, C, Lo, _st())
-        ctx.save_for_backward(y, gamma, mean, invstd)
-        ctx.batch_stats = use_batch
-        return out
-
-    @staticmethod
-    def backward(ctx, dout):
-        y, gamma, mean, invstd = ctx.saved_tensors
-        N, C, Lo = y.shape
-        dy = torch.empty_like(y)
-        dgamma, dbeta = _empty(y, C), _empty(y, C)
-        ws = _empty(y, _query("ecg_bn_bwd_ws_floats", N, C, Lo))
-        _call("ecg_bn_bwd", _f32(y), _f32(_contig(dout)), _f32(gamma), _f32(mean), _f32(invstd),
-              _f32(dy), _f32(dgamma), _f32(dbeta), _f32(ws), N, C, Lo,
-              1 if ctx.batch_stats else 0, _st())
-        return dy, dgamma, dbeta, None, None, None, None, None, None
-
-
-class ReLUFn(torch.autograd.Function):
-    @staticmethod
-    def forward(ctx, x):
-        x = _contig(x)
-        out = torch.empty_like(x)
-        _call("ecg_relu_fwd", _f32(x), _f32(out), x.numel(), _st())
-        ctx.save_for_backward(out)
-        return out
-
-    @staticmethod
-    def backward(ctx, dout):
-        (out,) = ctx.saved_tensors
-        dx = torch.empty_like(out)
-        _call("ecg_relu_bwd", _f32(out), _f32(_contig(dout)), _f32(dx), out.numel(), _st())
-        return dx
-
-
-class MaxPool2Fn(torch.autograd.Function):
-    @staticmethod
-    def forward(ctx, x):
-        x = _contig(x)
-        Lin = x.shape[-1]
-        rows = x.numel() // Lin
-        p = _empty(x, *x.shape[:-1], Lin // 2)
-        _call("ecg_maxpool2_fwd", _f32(x), _f32(p), rows, Lin, _st())
-        ctx.save_for_backward(x)
+            # p as bf16 rows [N][Co][ldp], zero-filled past Lo/2: the next conv's forward reads half the bytes, and its input
+            # gradient comes back as bf16 of the same shape
+            ldp = (Lo // 2 + 7) & ~7
+            p = torch.empty(N, Co, ldp, dtype=torch.bfloat16, device=x.device)
+            _call("ecg_bn_stats_relu_pool_fwd_h", _f32(partials), P, N * Lo, _f32(rm), _f32(rv), L.ptr(cnt),
+                  _bn_momentum(momentum, nbt), float(eps), L.ptr(y), ldyh, _f32(gamma), _f32(beta), _f32(mean),
+                  _f32(invstd), L.ptr(p), ldp, N, Co, Lo, _st())
+            if not next_bf16:
+                # the consumer is not a mixed-precision block (a model that mixes geometries, a frozen BatchNorm downstream):
+                # hand it fp32 rows; its gradient comes back as fp32 rows (dp_kind 2 of the backward pass)
+                p, ldp = p[:, :, :Lo // 2].float(), 0
+        ctx.save_for_backward(x, w, y, gamma, beta, mean, invstd)
+        ctx.w_bwd, ctx.ldyh, ctx.ldp = w_bwd, ldyh, ldp
+        ctx.set_materialize_grads(False)
         return p
 
     @staticmethod
+    def _bwd_bf16(ctx, dp):
+        x, w, y, gamma, beta, mean, invstd = ctx.saved_tensors
+        N, Co, Lo, Lin = y.shape[0], y.shape[1], ctx.Lo, ctx.Lin
+        if dp is None:
+            dp = (torch.zeros(N, Co, ctx.ldp, dtype=torch.bfloat16, device=y.device) if ctx.ldp else
+                  torch.zeros(N, Co, *(() if ctx.gap else (Lo // 2,)), device=y.device))
+        dp = _contig(dp)
+        if ctx.ldp and (dp.dtype != torch.bfloat16 or dp.shape[2] != ctx.ldp):
+            raise L.EcgHipError("ConvBlock backward: the gradient of a bf16 activation must be bf16 of the same shape")
+        Ci, K = x.shape[1], w.shape[2]
+        x_h = x.dtype == torch.bfloat16
+        need_dx = ctx.needs_input_grad[0]
+        kw, kb, kg, kbe = ctx.sink_keys
+        dgamma, dbeta = _grad_out(kg, y, Co), _grad_out(kbe, y, Co)
+        ws = _empty(y, _query("ecg_bn_relu_pool_bwd_ws_floats", N, Co, Lo))
+        # BatchNorm backward (reduction + dx, 16 bytes per lane) writes dY ONCE, as bf16 [N][Co][ldt] with rows zero-filled
+        # to a multiple of 128; the time-on-K weight gradient and the input gradient both read it
+        ldt = _query("ecg_conv1d_bf16_tk_dy_stride", Lo)
+        dyh = torch.empty(N, Co, ldt, dtype=torch.bfloat16, device=y.device)
+        # dp: the fp32 gradient of the fused global average pool [N][Co], bf16 rows [N][Co][ldp], or fp32 rows [N][Co][Lo/2]
+        dp_kind, dp_ld = (1, 0) if ctx.gap else ((0, ctx.ldp) if ctx.ldp else (2, Lo // 2))
+        _call("ecg_bn_relu_pool_bwd_h", L.ptr(y), ctx.ldyh, L.ptr(dp), dp_kind, dp_ld, _f32(gamma), _f32(beta), _f32(mean),
+              _f32(invstd), L.ptr(dyh), ldt, _f32(dgamma), _f32(dbeta), _f32(ws), N, Co, Lo, 1, _st())
+        dw, db = _grad_out(kw, x, Co, Ci, K), _grad_out(kb, x, Co)
+        ws2 = _empty(y, max(1, _query("ecg_conv1d_bwd_weight_bf16_ncl_ws_floats", N, Ci, Co, Lin, K, ctx.pad)))
+        _call("ecg_conv1d_bwd_weight_bias_bf16_ncl", L.ptr(dyh), ldt, L.ptr(x), 1 if x_h else 0, x.shape[2], _f32(dw),
+              _f32(db), _f32(ws2), N, Ci, Co, Lin, K, ctx.pad, _st())
+        dx = None
+        if need_dx:         # (x is bf16 rows here: the previous block's activation — dx is its dp — or the cast of an fp32 input)
+            dx = torch.empty_like(x)
+            _call("ecg_conv1d_bwd_data_bf16hh", L.ptr(dyh), ldt, L.ptr(ctx.w_bwd), L.ptr(dx), x.shape[2], N, Ci, Co,
+                  Lin, K, ctx.pad, _st())
+            if ctx.x_cast:
+                dx = dx[:, :, :Lin].float()
+        return dx, dw, db, dgamma, dbeta
+
+    @staticmethod
     def backward(ctx, dp):
-        (x,) = ctx.saved_tensors
-        Lin = x.shape[-1]
-        dx = torch.empty_like(x)
-        _call("ecg_maxpool2_bwd", _f32(x), _f32(_contig(dp)), _f32(dx), x.numel() // Lin, Lin, _st())
-        return dx
+        grads = ConvBlockFn._bwd_bf16(ctx, dp) if ctx.mode == _BF16 else ConvBlockFn._bwd_fp32(ctx, dp)
+        return grads + (None,) * 12
 
 
 # --------------------------------------------------------------------------------------
-# Tail
+# Unfused leaves (the hook-compatible path: Conv1dFn, BatchNormFn, ReLUFn, MaxPool2Fn, GapFn, LinearFn, FilmFn) live in
+# ecg_hip/leaves.py and are re-exported at the end of this module.
 # --------------------------------------------------------------------------------------
-class GapFn(torch.autograd.Function):
-    """AdaptiveAvgPool1d(1): [N,C,L] -> [N,C,1] (reference src/models/ecg_cnn.py:46)."""
-
-    @staticmethod
-    def forward(ctx, p):
-        p = _contig(p)
-        N, C, Lp = p.shape
-        g = _empty(p, N, C, 1)
-        _call("ecg_gap_fwd", _f32(p), _f32(g), N * C, Lp, _st())
-        ctx.shape = (N, C, Lp)
-        return g
-
-    @staticmethod
-    def backward(ctx, dg):
-        N, C, Lp = ctx.shape
-        dp = _empty(dg, N, C, Lp)
-        _call("ecg_gap_bwd", _f32(_contig(dg)), _f32(dp), N * C, Lp, _st())
-        return dp
-
-
-class LinearFn(torch.autograd.Function):
-    """y = act(x W^T + b); act = ReLU when relu (reference src/models/ecg_multimodal.py:52-55)."""
-
-    @staticmethod
-    def forward(ctx, x, w, b, relu):
-        x, w = _contig(x), _contig(w)
-        if x.dim() != 2:
-            raise L.EcgHipError(f"linear: expected a [M, In] input, got {tuple(x.shape)}")
-        M, In = x.shape
-        Out = w.shape[0]
-        y = _empty(x, M, Out)
-        _call("ecg_linear_fwd", _f32(x), _f32(w), _f32(b), _f32(y), M, In, Out, int(relu), _st())
-        ctx.save_for_backward(x, w, y if relu else None)
-        ctx.relu, ctx.has_bias = bool(relu), b is not None
-        return y
-
-    @staticmethod
-    def backward(ctx, dy):
-        x, w, y = ctx.saved_tensors
-        M, In = x.shape
-        Out = w.shape[0]
-        dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
-        dw = torch.empty_like(w) if ctx.needs_input_grad[1] else None
-        db = _empty(x, Out) if ctx.has_bias and ctx.needs_input_grad[2] else None
-        _call("ecg_linear_bwd", _f32(x), _f32(w), _f32(y), _f32(_contig(dy)), _f32(dx), _f32(dw),
-              _f32(db), None, M, In, Out, int(ctx.relu), _st())
-        return dx, dw, db, None
-
-
-class FilmFn(torch.autograd.Function):
-    """zc = (1 + tanh(film[:, :F])) * z + film[:, F:] (reference src/models/ecg_multimodal.py:92-96)."""
-
-    @staticmethod
-    def forward(ctx, z, film):
-        z, film = _contig(z), _contig(film)
-        M, F = z.shape
-        if film.shape != (M, 2 * F):
-            raise L.EcgHipError(f"film: expected film of shape {(M, 2 * F)}, got {tuple(film.shape)}")
-        zc = torch.empty_like(z)
-        _call("ecg_film_fwd", _f32(z), _f32(film), _f32(zc), M, F, _st())
-        ctx.save_for_backward(z, film)
-        return zc
-
-    @staticmethod
-    def backward(ctx, dzc):
-        z, film = ctx.saved_tensors
-        M, F = z.shape
-        dz, dfilm = torch.empty_like(z), torch.empty_like(film)
-        _call("ecg_film_bwd", _f32(z), _f32(film), _f32(_contig(dzc)), _f32(dz), _f32(dfilm), M, F, _st())
-        return dz, dfilm
-
-
 class BceWithLogitsFn(torch.autograd.Function):
     """mean BCE-with-logits; the gradient is produced by the same launch as the loss."""
 
@@ -920,33 +669,25 @@ def conv_block(x, conv, bn, gap=False, packed=None):
     return conv_block_chain(x, conv, bn, gap, packed)[0]
 
 
-def _bf16_chain_ok(Ci, Co, K, pad, Lin):
-    """Can a training block of this geometry take its input as bf16 [N][Ci][ld] and hand its input gradient back in the
-    same form?  Needs the bf16 forward, input-gradient and weight-gradient kernels, position-pair staging on both sides
-    (odd pad, odd K-1-pad) and the n16 BatchNorm backward."""
-    Lo = Lin + 2 * pad - K + 1
-    return bool(_bf16_activation_storage and (_query("ecg_conv1d_bf16_supported", Ci, Co, K, pad) & 7) == 7
-                and (pad & 1) and ((K - 1 - pad) & 1) and Lo >= 2 and _query("ecg_conv1d_n16_positions", Lin, K, pad, 0))
-
-
-def conv_block_chain(x, conv, bn, gap=False, packed=None, x_n16=None, next_conv=None, next_bn=None):
-    """conv_block for a chain of blocks: returns (p, carry).  In bf16 mode the carry holds p in the layout the NEXT
-    conv's weight gradient reads (next_conv given) — hand it to the next call as `x_n16` — so the mixed-precision train
-    step needs no packing pass except for the network input; with bf16 activation storage p itself is then a bf16
-    tensor [N][C][ld] (rows zero-filled past the pooled length, which travels in the carry) that only the next block of
-    the chain may consume."""
-    geom = None
-    if next_conv is not None and _conv_precision == "bf16":
-        geom = (next_conv.kernel_size[0], next_conv.padding[0], next_conv.out_channels,
-                bool(next_bn is not None and (next_bn.training or next_bn.running_mean is None)))
-    p, p_n16 = ConvBlockFn.apply(x, conv.weight, conv.bias, bn.weight, bn.bias, bn.running_mean,
-                                 bn.running_var, bn.num_batches_tracked, bn.training, bn.momentum,
-                                 bn.eps, conv.padding[0], gap, packed, torch.is_grad_enabled(), x_n16, geom)
-    if p.dtype == torch.bfloat16:
-        x_len = x_n16[1] if isinstance(x_n16, tuple) else x.shape[2]
+def conv_block_chain(x, conv, bn, gap=False, packed=None, carry=None, next_conv=None, next_bn=None):
+    """conv_block for a chain of blocks: returns (p, carry).  In the mixed-precision form p is a bf16 activation
+    [N][C][ld] (rows zero-filled past the pooled length) when the NEXT block of the chain (next_conv / next_bn given) takes
+    that form too; the carry is then the true pooled length, to be handed to the next call — only the next block of the
+    chain may consume such a tensor."""
+    nxt = False
+    if next_conv is not None and _conv_precision == "bf16" and not gap:
+        x_len = carry if x.dtype == torch.bfloat16 else x.shape[2]
         Lo = x_len + 2 * conv.padding[0] - conv.kernel_size[0] + 1
-        return p, (p_n16, Lo // 2)
-    return p, p_n16
+        nxt = bool(next_bn is not None and (next_bn.training or next_bn.running_mean is None) and torch.is_grad_enabled()
+                   and _bf16_block_ok(conv.out_channels, next_conv.out_channels, next_conv.kernel_size[0],
+                                      next_conv.padding[0], Lo // 2, True))
+    p = ConvBlockFn.apply(x, conv.weight, conv.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var,
+                          bn.num_batches_tracked, bn.training, bn.momentum, bn.eps, conv.padding[0], gap, packed,
+                          torch.is_grad_enabled(), carry, nxt)
+    if p.dtype == torch.bfloat16:
+        x_len = carry if x.dtype == torch.bfloat16 else x.shape[2]
+        return p, (x_len + 2 * conv.padding[0] - conv.kernel_size[0] + 1) // 2
+    return p, None
 
 
 class TailFn(torch.autograd.Function):
@@ -1091,3 +832,6 @@ def wfdb16_to_windows(d, gain, baseline, normalize=True, return_stats=False):
     stats = _empty(x, B * leads, 2)
     _call("ecg_wfdb16_zscore", L.ptr(d), L.ptr(gain), L.ptr(baseline), _f32(x), _f32(stats), B, T, leads, _st())
     return (x, stats) if return_stats else x
+
+
+from .leaves import BatchNormFn, Conv1dFn, FilmFn, GapFn, LinearFn, MaxPool2Fn, ReLUFn  # noqa: E402,F401

@@ -168,7 +168,7 @@ class LoopStepper:
 
     def _key(self, batch):
         grp = self.optimizer.param_groups[0]
-        return (tuple((tuple(t.shape), t.dtype) for t in batch), hipF.get_conv_precision(), hipF._bf16_activation_storage,
+        return (tuple((tuple(t.shape), t.dtype) for t in batch), hipF.get_conv_precision(),
                 float(grp["lr"]), tuple(grp["betas"]), float(grp["eps"]), float(grp["weight_decay"]),
                 self.optimizer.flat_param.data_ptr())
 

@@ -63,10 +63,10 @@ def fused_forward(packer, backbone, gap, x, x_demo, proj, head, mlp0=None, mlp2=
     blocks = list(backbone)
     linears = [proj] if x_demo is None else [proj, film_gen]
     packs, transposed = packer.pack([b.net[0] for b in blocks], linears, torch.is_grad_enabled())
-    xn = None              # mixed precision only: the activation in the weight gradient's operand layout
+    carry = None           # mixed precision only: the true row length of a bf16 activation handed from block to block
     for i, blk in enumerate(blocks):
         last = i == len(blocks) - 1
-        x, xn = hipF.conv_block_chain(x, blk.net[0], blk.net[1], gap=last, packed=packs[i], x_n16=xn,
+        x, carry = hipF.conv_block_chain(x, blk.net[0], blk.net[1], gap=last, packed=packs[i], carry=carry,
                                       next_conv=None if last else blocks[i + 1].net[0],
                                       next_bn=None if last else blocks[i + 1].net[1])
     return hipF.tail(x, x_demo, proj, head, mlp0, mlp2, film_gen, transposed=transposed)

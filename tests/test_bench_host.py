@@ -21,7 +21,7 @@ def test_layer_table_prices_entry_points_against_their_roofs(monkeypatch):
         ("ecg_conv1d_bwd_weight_bias_ld", (128, 256, 128, 256, 125, 15, 7)): [0.27],         # heaviest: dominant
         ("ecg_conv1d_fwd_bf16_yh", (1, 632, 632, 256, 128, 256, 625, 15, 7)): [0.18],
         ("ecg_conv1d_bwd_data_bf16hh", (640, 632, 256, 128, 256, 625, 15, 7)): [0.16],
-        ("ecg_bn_stats_relu_pool_fwd", (1024, 256000, 256, 32, 1000, 0, 0, 0)): [0.014],
+        ("ecg_bn_stats_relu_pool_fwd", (1024, 256000, 256, 32, 1000, 0)): [0.014],
     }
     rows, other_ms = bench.layer_table(timings, bench.leg_tag("cnn", 5, "f32", 1000))
     assert bench.leg_tag("multimodal", 5, "f32", 1000) == "mm_f32_1000" and bench.leg_tag("cnn", 1, "bf16", 5000) == "cnn1_bf16_5000"

@@ -15,16 +15,12 @@ from src.models.ecg_cnn import ECGCNN
 from src.utils.seed import set_seed
 out = {}
 for (B, T) in [(8, 5000), (19, 1000), (256, 5000)]:
-    for act in (True, False):
-        if B == 256 and not act:
-            continue
+    for act in (True,):          # (round 5: the mixed-precision step has one form, bf16 rows between the kernels)
         set_seed(42); model = ECGCNN(num_labels=1).cuda().train()
         R.seed_all(42); ref = R.RefECGCNN(num_labels=1).train()
         x, y = R.synthetic_batch(B, T, 1)
-        hipF.set_bf16_activation_storage(act)
         with hipF.conv_precision("bf16"):
             logits = model(x.cuda()); loss = hipF.binary_cross_entropy_with_logits(logits, y.cuda()); loss.backward()
-        hipF.set_bf16_activation_storage(True)
         rl = ref(x); rloss = torch.nn.functional.binary_cross_entropy_with_logits(rl, y); rloss.backward()
         rec = {"dlogit": float((logits.detach().cpu() - rl.detach()).abs().max()), "dloss": abs(loss.item() - rloss.item())}
         for (k, a), (_, b) in zip(model.named_parameters(), ref.named_parameters()):

@@ -93,15 +93,18 @@ def main():
             report(b, stamps, ["prologue", "first_stage", "other_stages", "exchange+slab"], stages=True)
             Lc //= 2
             continue
-        y = torch.empty(N, co, Lc, device=dev)
-        P = L.query("ecg_conv1d_fwd_bf16_stat_partials" if bf16 else "ecg_conv1d_fwd_stat_partials", N, ci, co, Lc, K, pad)
+        ldy = (Lc + 7) & ~7
+        y = torch.empty(N, co, ldy, dtype=torch.bfloat16, device=dev) if bf16 else torch.empty(N, co, Lc, device=dev)
+        P = (L.query("ecg_conv1d_fwd_bf16_yh_stat_partials", N, ci, co, Lc, K, pad, 0, 0, ldy) if bf16 else
+             L.query("ecg_conv1d_fwd_stat_partials", N, ci, co, Lc, K, pad))
         part = torch.empty(co * P * 2, device=dev)
         stamps = torch.zeros(16384 * 8, dtype=torch.int64, device=dev)
         for rep in range(3):
             stamps.zero_()
             setter(stamps.data_ptr())
             if bf16:
-                L.call("ecg_conv1d_fwd_bf16", L.f32(x), L.ptr(wf), L.f32(bias), L.f32(y), L.f32(part), N, ci, co, Lc, K, pad, L.stream())
+                L.call("ecg_conv1d_fwd_bf16_yh", L.f32(x), 0, 0, L.ptr(wf), L.f32(bias), L.ptr(y), ldy, L.f32(part), N, ci, co, Lc, K, pad,
+                       L.stream())
             else:
                 L.call("ecg_conv1d_fwd", L.f32(x), L.f32(wf), L.f32(bias), L.f32(y), L.f32(part), N, ci, co, Lc, K, pad, L.stream())
             torch.cuda.synchronize()

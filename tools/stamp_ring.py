@@ -44,7 +44,7 @@ def main():
     for b, (ci, co) in enumerate([(12, 32), (32, 64), (64, 128), (128, 256)]):
         Lc = 5000 >> b
         ld = (Lc + 7) & ~7
-        PA = L.query("ecg_conv1d_n16_positions", Lc, K, pad, 0)
+        PA = L.query("ecg_conv1d_bf16_tk_dy_stride", Lc)
         xh = torch.zeros(N, ci, ld, dtype=torch.bfloat16, device=dev)
         xh[:, :, :Lc] = torch.randn(N, ci, Lc, device=dev).to(torch.bfloat16)
         w = torch.randn(co, ci, K, device=dev) * 0.05
