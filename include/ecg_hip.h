@@ -247,7 +247,10 @@ int ecg_bn_stats_relu_pool_fwd(const float *stat_partials, int P, long long coun
  *                                     ordered on a stream; launches that may run CONCURRENTLY need separate buffers.  The
  *                                     library allocates nothing and keeps no state between calls.
  *   The exchange: each partial sum travels with its own "valid" tag in one 64-bit word (a single agent-scope atomic store;
- *   pollers use agent-scope atomic loads), so no ordering between different locations is assumed.  The wait is bounded:
+ *   pollers use agent-scope atomic loads), so no ordering between different locations is assumed — the self-reset included:
+ *   a workgroup counts itself out only after its own two words have been SEEN tagged (by its pollers, or, on the
+ *   self-service path, read back by the publishing thread), so the last one out clears words that are all in place.  The
+ *   wait is bounded:
  *   after `spin_polls` polls (< 0: the default, about 1 ms; 0: never wait) a workgroup recomputes its siblings' sums from
  *   memory itself, bit for bit what they publish — a co-tenant that keeps siblings off the device (another process, a
  *   communication kernel waiting for a late peer) costs time, never correctness.  Use the two-pass form while collectives

@@ -564,6 +564,15 @@ __global__ __launch_bounds__(kResThreads) void bn_bwd_resident_kernel(
             // count this workgroup out.  Its polled values have been CONSUMED (they sit in LDS, behind a barrier), and every
             // workgroup publishes before it leaves: when the count reaches S all 2 S words are set and nobody will read them
             // again, so the last one out clears them (and the count) for the next launch that is handed this buffer.
+            // The clear must not be overtaken by this workgroup's OWN publish: on the normal path its threads 2s / 2s + 1 have
+            // seen the tags (behind the barrier above); on the self-service path nobody has, so the publisher reads its two
+            // words back (agent scope, the same location: the read returns once the store is visible where the clear will
+            // land) before it counts out — no ordering between DIFFERENT locations is assumed anywhere.
+            if (!okf)
+                for (int w = 0; w < 2; ++w)
+                    while ((unsigned)(__hip_atomic_load(&words[((size_t)c * S + s) * 2 + w], __ATOMIC_RELAXED,
+                                                        __HIP_MEMORY_SCOPE_AGENT) >> 32) == 0u)
+                        __builtin_amdgcn_s_sleep(1);
             const unsigned gone = __hip_atomic_fetch_add(&left[c], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (gone == (unsigned)S - 1) {
                 for (int p = 0; p < 2 * S; ++p)

@@ -23,7 +23,8 @@
 //   x tile [NCI][152] bf16 is register-staged one stage ahead (zero padding by mask, the four copies written with four
 //     ds_write_b128 per 16-byte chunk); x is the previous block's bf16 activation [N][C_in][ldx] (rows zero-filled past L),
 //     or the fp32 network input, rounded to bf16 here (block 0: no packing pass at all).
-// Split over stages into <= 256 slabs summed in fixed order by wgrad_reduce_kernel, bias gradient on the dY fragments.
+// Split over stages into <= 256 slabs (<= 512 on the 32-channel plan) summed in fixed order by wgrad_reduce_kernel, bias
+// gradient on the dY fragments.
 // Exact on bf16-rounded operands up to fp32 accumulation order (tests/test_gpu_ops.py::test_bf16_tk_*).
 // Replaces autograd's conv weight-gradient (reference src/models/ecg_cnn.py:13 via loss.backward()).
 #include "common.h"
@@ -65,7 +66,7 @@ __global__ __launch_bounds__(512) void conv1d_wgrad_bf16_tk_kernel(
     constexpr int MC = M_T / WM / 32, MR = R_T / WR / 32;
     static_assert((MC == 2 && (MR == 4 || MR == 2)) || (MC == 1 && MR == 3), "wave tile 64 x 128, 64 x 64 or 32 x 96");
     constexpr int KPW = KS / WK;                            // k-steps per wave and stage
-    static_assert(KS % WK == 0 && KPW % (WK > 1 ? WR : 1) == 0, "k-steps split evenly; bias rows rotate over the WR waves");
+    static_assert(KS % WK == 0 && KPW % WR == 0, "k-steps split evenly; bias rows rotate over the WR waves: every k-step exactly once");
     constexpr int NCI = (R_T + KK - 2) / KK + 1;
     constexpr int AIMG = M_T * 16 * 16;                    // dY image: M_T rows of 16 slots of 16 bytes
     constexpr int ADMA = AIMG / 1024, APW = (ADMA + 7) / 8; // 1 KB DMA pieces, per wave
