@@ -15,7 +15,8 @@
 //                                           aligned ds_read_b128, but at 1/11 of the aligned rate — tools/lds_unaligned_bench.hip;
 //                                           two copies read with ds_read2_b32 pairs run at a quarter of the b64 rate on 32
 //                                           banks: 3x the LDS cycles of the n16 kernel, 190 vs 147 us on block 3.)
-// A stage is (sample n, 128 time steps) = 8 MFMA k-steps; workgroup tile M_T (co) x 512 columns r = ci*15 + k, eight waves,
+// A stage is (sample n, 128 time steps) = 8 MFMA k-steps; workgroup tile M_T (co) x 512 columns (32 input channels: two per
+// 32-lane column block, 15 taps each), eight waves,
 // one workgroup per CU, two dY images and two x images in LDS:
 //   dY tile [M_T][128] bf16 (32 KB at M_T = 128) streams global -> LDS by DMA (asm, see conv1d_bf16_ring.hip), rows of 16
 //     16-byte slots with slot s of row co stored at s ^ (co & 15) (conflict-free A reads) — needs dY rows zero-filled to a
@@ -67,7 +68,14 @@ __global__ __launch_bounds__(512) void conv1d_wgrad_bf16_tk_kernel(
     static_assert((MC == 2 && (MR == 4 || MR == 2)) || (MC == 1 && MR == 3), "wave tile 64 x 128, 64 x 64 or 32 x 96");
     constexpr int KPW = KS / WK;                            // k-steps per wave and stage
     static_assert(KS % WK == 0 && KPW % WR == 0, "k-steps split evenly; bias rows rotate over the WR waves: every k-step exactly once");
-    constexpr int NCI = (R_T + KK - 2) / KK + 1;
+    // Columns of a tile <-> (input channel, tap): every 32-lane MFMA column block holds exactly TWO channels (lanes 0-14 and
+    // 15-29; lanes 30 / 31 idle) — a tile of R_T columns is CPT = R_T / 16 channels.  With r = ci * 15 + tap on the lanes (rounds
+    // 4) a block straddled three channels and the third one's bank window (16 banks per channel and copy, see XCOPY_PAD)
+    // coincided with the first one's: one 2-way conflict in every fragment read, i.e. twice the LDS cycles for the x operand
+    // (SQ_LDS_BANK_CONFLICT = 36 % of the LDS cycles of blocks 1-3).  The padded width is the same for the model's layers
+    // (128 channels: 64 blocks x 32 = 2048 columns, as 4 x 512 before).
+    constexpr int CPT = R_T / 16;
+    constexpr int NCI = CPT;
     constexpr int AIMG = M_T * 16 * 16;                    // dY image: M_T rows of 16 slots of 16 bytes
     constexpr int ADMA = AIMG / 1024, APW = (ADMA + 7) / 8; // 1 KB DMA pieces, per wave
     static_assert(ADMA % 8 == 0, "dY image must split evenly over the eight waves");
@@ -84,7 +92,7 @@ __global__ __launch_bounds__(512) void conv1d_wgrad_bf16_tk_kernel(
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int half = lane >> 5, l31 = lane & 31;
     const int R = Cin * KK;
-    const int RT = (R + R_T - 1) / R_T, CT = Cout / M_T;
+    const int RT = (Cin + CPT - 1) / CPT, CT = Cout / M_T;
     int tile;
     {       // XCD-aware order (conv1d_mfma.hip): the R tiles of one (C_out tile, split) share a dY slice
         const int nwg = gridDim.x, bid = blockIdx.x;
@@ -92,10 +100,12 @@ __global__ __launch_bounds__(512) void conv1d_wgrad_bf16_tk_kernel(
         tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
     }
     const int tile_r = tile % RT, tile_cs = tile / RT;
-    const int r0 = tile_r * R_T, co0 = (tile_cs % CT) * M_T, s = tile_cs / CT;
+    const int co0 = (tile_cs % CT) * M_T, s = tile_cs / CT;
     const int wk = wave % WK, wr = (wave / WK) % WR, wm = wave / (WK * WR);
     const int wm0 = wm * (M_T / WM), wr0 = wr * (R_T / WR);
-    const int ci_base = r0 / KK;
+    const int ci_base = tile_r * CPT;
+    // this lane's column: channel ci_base + 2 * (block index) + (lane >= 15), tap lane % 15; lanes 30 / 31 read what lane 29 reads
+    const int lch = l31 >= 15 ? 1 : 0, ltap = min(l31, 29) - 15 * lch;
     const int total = N * ntt;
     const int st_begin = (int)((long long)total * s / S), st_end = (int)((long long)total * (s + 1) / S);
 
@@ -105,12 +115,10 @@ __global__ __launch_bounds__(512) void conv1d_wgrad_bf16_tk_kernel(
     int boffl[MR];
 #pragma unroll
     for (int j = 0; j < MR; ++j) {
-        int r = r0 + wr0 + 32 * j + l31;
-        if (r >= R) r = R - 1;                              // clamped columns compute garbage that is never stored
-        const int ci = r / KK, tap = r - ci * KK;
+        const int row = 2 * ((wr0 >> 5) + j) + lch;         // row of the x image (columns past C_in compute garbage that is never stored)
         // first element of the fragment at k-step 0, half 0: e = tap + 1 -> copy e % 4 at byte 2 (e - e % 4): a multiple of 8
-        const int e = tap + 1, sft = e & 3;
-        boffl[j] = (ci - ci_base) * XRS + sft * XCSZ + (sft == 0 ? XCOPY_PAD[0] : sft == 1 ? XCOPY_PAD[1] : sft == 2 ? XCOPY_PAD[2] : XCOPY_PAD[3])
+        const int e = ltap + 1, sft = e & 3;
+        boffl[j] = row * XRS + sft * XCSZ + (sft == 0 ? XCOPY_PAD[0] : sft == 1 ? XCOPY_PAD[1] : sft == 2 ? XCOPY_PAD[2] : XCOPY_PAD[3])
                    + 2 * (e - sft) + 16 * half + 32 * wk;   // (this wave's first k-step of a stage is wk)
     }
 
@@ -391,8 +399,9 @@ __global__ __launch_bounds__(512) void conv1d_wgrad_bf16_tk_kernel(
     for (int i = 0; i < MC; ++i)
 #pragma unroll
         for (int j = 0; j < MR; ++j) {
-            const int r = r0 + wr0 + 32 * j + l31;
-            if (r < R) {
+            const int ci = ci_base + 2 * ((wr0 >> 5) + j) + lch;
+            if (l31 < 30 && ci < Cin) {
+                const int r = ci * KK + ltap;
 #pragma unroll
                 for (int q = 0; q < 16; ++q) {
                     const int co = co0 + wm0 + 32 * i + acc_row(q, half);
@@ -426,7 +435,7 @@ static TkPlan tk_plan(int N, int Cin, int Cout, int Lo) {
     p.m_t = Cout % 128 == 0 ? 128 : Cout % 64 == 0 ? 64 : 32;
     if (p.m_t == 32) p.r_t = 192;                           // the 32-channel first layer: 32 x 192 tiles, k-steps split over waves
     if (p.m_t == 128) p.r_t = ECG_TK_RT128;
-    const int tiles = cdiv(Cin * tk::KK, p.r_t) * (Cout / p.m_t);
+    const int tiles = cdiv(Cin, p.r_t / 16) * (Cout / p.m_t);      // a tile of r_t columns holds r_t / 16 input channels
     int s = (p.m_t == 32 ? ECG_TK_SLOTS32 : 256) / tiles;   // one eight-wave workgroup per CU (two of the small ones)
     const int total = N * p.ntt;
     if (s > total / 4) s = total / 4;                       // a slab is written and re-read per split: >= 4 stages each
@@ -455,7 +464,7 @@ int wgrad_bf16_tk(const void *dy_bf16, int ldy, const void *x, int x_is_bf16, in
     if (!p.m_t) return fail(ECG_EINVAL, "conv1d_bwd_weight_bias_bf16_ncl: C_out=%d is not a multiple of 32", Cout);
     const int R = Cin * K;
     const u16 *dy = static_cast<const u16 *>(dy_bf16);
-    dim3 grid((unsigned)(cdiv(R, p.r_t) * (Cout / p.m_t) * p.splits)), block(512);
+    dim3 grid((unsigned)(cdiv(Cin, p.r_t / 16) * (Cout / p.m_t) * p.splits)), block(512);
 #define ECG_TK(MT, RT, WM, WR, WK, XF) \
     hipLaunchKernelGGL((tk::conv1d_wgrad_bf16_tk_kernel<MT, RT, WM, WR, WK, XF>), grid, block, 0, st, dy, x, ws, N, Cin, Cout, L, \
                        ldy, ldx, p.ntt, p.splits)
