@@ -315,10 +315,17 @@ __global__ __launch_bounds__(512) void conv1d_wgrad_bf16_tk_kernel(
 #pragma unroll
                     for (int j = 0; j < XI; ++j) load_x(j);
                 }
-                if (i_ == KPW - 2) {
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (x loads and DMA pieces issued six k-steps ago)
+                // 128-channel tiles: the two waves of a SIMD (w and w + 4) commit at different k-steps, three apart — one's stores
+                // and shifts run under the other's MFMAs instead of beside its stores (same-box A/B, B=256 12x5000: block 3
+                // 184.0 -> 177.4 us, block 2 99.8 -> 98.3; two apart -4.7 / -0.6, four apart +5.6 / +3.2; the 64-channel plan of
+                // block 1 loses 0.9 us and keeps one commit point)
+                constexpr int STG = (M_T == 128) ? 3 : 0;
+                if (i_ == KPW - 2 || (STG && i_ == KPW - 2 - STG)) {
+                    if (STG == 0 || ((i_ == KPW - 2) == (wave < 4))) {
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (x loads and DMA pieces issued at the top of the stage)
 #pragma unroll
-                    for (int j = 0; j < XI; ++j) commit_x(j, img ^ 1);
+                        for (int j = 0; j < XI; ++j) commit_x(j, img ^ 1);
+                    }
                 }
             }
             const int kn = i_ + 1 < KPW ? i_ + 1 : KPW - 1;           // (the last step re-reads its own fragments: unused)

@@ -35,6 +35,7 @@ def main():
     ap.add_argument("--check", action="store_true")
     ap.add_argument("--blocks", default="0,1,2,3")
     ap.add_argument("--tag", default="")
+    ap.add_argument("--ops", default="fwd,dgrad,wgrad", help="which entry points to time")
     a = ap.parse_args()
     import torch
     from ecg_hip import _lib as L, functional as F
@@ -105,6 +106,7 @@ def main():
                 call("ecg_conv1d_bwd_weight_bias_ld", f32(dy), ldy, f32(x), f32(dw), f32(db), f32(ws), N, ci, co, Lc, K, pad, st())
 
         ops = [("fwd", fwd)] + ([("dgrad", dgrad)] if need_dx else []) + [("wgrad", wgrad)]
+        ops = [(n, f) for n, f in ops if n in a.ops.split(",")]
         for name, fn in ops:
             for _ in range(3):
                 fn()
