@@ -1,11 +1,11 @@
 #!/bin/bash
 # Collect the round's measurement artefacts on the GPU box (run from the repo root through gpurun):
-#   bash tools/collect_profiles.sh r04 [quick]
+#   bash tools/collect_profiles.sh r05 [quick]
 # Writes under gpurun_out/: the bench line, a rocprofv3 --kernel-trace --stats run of bench.py, and three
 # separate --pmc passes of tools/pmc_step.py (FETCH_SIZE / WRITE_SIZE / MFMA-busy; counters are never combined
 # with other trace domains).  tools/make_profile_artifacts.py turns them into the files committed under profiles/.
 set -o pipefail
-TAG=${1:-r04}
+TAG=${1:-r05}
 R=$PWD
 O=$R/gpurun_out
 mkdir -p "$O"

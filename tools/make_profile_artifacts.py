@@ -160,7 +160,9 @@ def traffic_tables():
     open(os.path.join(PROF, f"{TAG}_pmc_summary.txt"), "w").write("\n".join(lines) + "\n")
 
     import bench
-    commit = subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip()
+    # (the GPU box has no .git: tools/collect_profiles.sh is started with ECG_COMMIT=<short hash> in its environment)
+    commit = os.environ.get("ECG_COMMIT") or subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], capture_output=True,
+                                                             text=True).stdout.strip()
     meta = {"commit": commit, "csrc_digest": bench.csrc_digest(), "source": f"profiles/{TAG}_pmc_summary.txt",
             "formula": "hbm bytes per call = (2 * FETCH_SIZE + WRITE_SIZE) KiB summed over the entry point's launches, separate "
                        "rocprofv3 --pmc passes of tools/pmc_step.py; gfx950 FETCH_SIZE correction per MI355X_MICROARCH.md"}
