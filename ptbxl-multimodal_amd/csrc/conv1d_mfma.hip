@@ -781,12 +781,16 @@ __global__ __launch_bounds__(256, 2) void conv1d_mfma_wgrad_kernel(
 // inline constant 0 and the stage's 64-term sum is added to a second register set at the end of the stage: chains of
 // 64 + total terms, fixed order (bitwise reproducible), no extra memory traffic; cost = one v_pk_add_f32 per two
 // accumulator registers per stage (32 MFMAs of 64 cycles per register pair).
-template <int M_T, int R_T, int WM, int WR, int WK, int KK, int FL = 1>
+// T_T = 128 (round 5, the 64- and 32-channel tiles of blocks 0-1): a stage of 128 time steps — the fixed cost per stage (barrier,
+// drained waits, DMA issue, the second-level adds) is paid half as often on the layers whose stages are shortest; needs the
+// row stride to be a multiple of 128 floats, and two images of 38 KB still leave two workgroups per CU.
+template <int M_T, int R_T, int WM, int WR, int WK, int KK, int FL = 1, int T_T = 64>
 __global__ __launch_bounds__(256, 2) void conv1d_mfma_wgrad_dma_kernel(
     const float *__restrict__ dy, const float *__restrict__ x, float *__restrict__ slab, int N,
     int Cin, int Cout, int L, int Lo, int ldy, int pad, int S) {
     static_assert(WM * WR * WK == 4, "4 waves per workgroup");
-    constexpr int T_T = 64;
+    static_assert(T_T == 64 || T_T == 128, "64 or 128 time steps per stage");
+    constexpr int LPR = T_T / 4, RPP = 64 / LPR;        // 16-byte chunks (lanes) per dY row; rows per 1 KB DMA piece
     constexpr int MC = M_T / WM / 32, MR = R_T / WR / 32;
     constexpr int TW = T_T / WK;                        // WK > 1: the waves split the stage's t range (32-channel layer)
     constexpr int NST = TW / 2, NGRP = NST / 4;         // reduction steps per stage, in groups of 4
@@ -851,8 +855,8 @@ __global__ __launch_bounds__(256, 2) void conv1d_mfma_wgrad_dma_kernel(
     int doff[DPW];          // dY piece j of this wave: element offset from the stage base
 #pragma unroll
     for (int j = 0; j < DPW; ++j) {
-        const int row = (j * 4 + wave) * 4 + (lane >> 4);           // row inside the M_T tile
-        doff[j] = row * ldy + (((lane & 15) ^ (row & 15)) << 2);    // LDS chunk c <- global chunk c^(row&15)
+        const int row = (j * 4 + wave) * RPP + lane / LPR;          // row inside the M_T tile
+        doff[j] = row * ldy + (((lane % LPR) ^ (row & 15)) << 2);   // LDS chunk c <- global chunk c^(row&15)
     }
     int xci[XLOADS], xpos[XLOADS];
 #pragma unroll
@@ -1065,8 +1069,11 @@ struct WgCfg { int m_t, r_t, splits; };
 #ifndef ECG_WG_RT
 #define ECG_WG_RT 0
 #endif
+#ifndef ECG_WG_TT128
+#define ECG_WG_TT128 1       // 128-step stages on the 64- / 32-channel tiles (A/B: -DECG_WG_TT128=0)
+#endif
 
-static WgCfg wgrad_cfg(int N, int Cin, int Cout, int Lo, bool dma) {
+static WgCfg wgrad_cfg(int N, int Cin, int Cout, int Lo, bool dma, int tt = 64) {
     const int R = Cin * kKM;
     constexpr int slots = ECG_WG_SLOTS, rt128 = ECG_WG_RT;
     WgCfg c;
@@ -1085,8 +1092,8 @@ static WgCfg wgrad_cfg(int N, int Cin, int Cout, int Lo, bool dma) {
                                        // one workgroup over and the launch takes two rounds.
                                        // (64-channel tiles at 4 workgroups per CU measured no better here; nor did
                                        // 128 x 256 column tiles for block 3: 273 vs 271 us, 236 VGPRs.)
-    // the DMA kernel splits over stages (n, 64-wide t tile), the register-staged one over samples
-    const long long cap = dma ? (long long)N * cdiv(Lo, 64) : N;
+    // the DMA kernel splits over stages (n, 64- or 128-wide t tile), the register-staged one over samples
+    const long long cap = dma ? (long long)N * cdiv(Lo, tt) : N;
     if (s > cap) s = (int)cap;
     if (s < 1) s = 1;
     c.splits = s;
@@ -1100,7 +1107,7 @@ bool mfma_wgrad_supported(int Cin, int Cout, int K, int pad) {
 
 size_t mfma_wgrad_ws_floats(int N, int Cin, int Cout, int L, int K, int pad) {
     const int Lo = L + 2 * pad - K + 1;
-    const WgCfg a = wgrad_cfg(N, Cin, Cout, Lo, false), b = wgrad_cfg(N, Cin, Cout, Lo, true);
+    const WgCfg a = wgrad_cfg(N, Cin, Cout, Lo, false), b = wgrad_cfg(N, Cin, Cout, Lo, true);      // (128-step stages: never more splits)
     return (size_t)(a.splits > b.splits ? a.splits : b.splits) * ((size_t)Cout * Cin * K + Cout);
 }
 
@@ -1116,7 +1123,9 @@ int mfma_wgrad(const float *dy, int ldy, const float *x, float *dw, float *db, f
     const int R = Cin * K;
     const bool dma = mfma_wgrad_dma_supported(Cin, Cout, K) && ldy % 64 == 0 && ldy >= cdiv(Lo, 64) * 64 &&
                      (reinterpret_cast<uintptr_t>(dy) & 15) == 0;
-    const WgCfg c = wgrad_cfg(N, Cin, Cout, Lo, dma);
+    // 128-step stages for the small tiles (blocks 0-1) when the rows allow it (stride a multiple of 128 floats, zero pad to it)
+    const bool tt128 = ECG_WG_TT128 && dma && Cout % 128 != 0 && ldy % 128 == 0 && ldy >= cdiv(Lo, 128) * 128;
+    const WgCfg c = wgrad_cfg(N, Cin, Cout, Lo, dma, tt128 ? 128 : 64);
     dim3 grid((unsigned)(cdiv(R, c.r_t) * (Cout / c.m_t) * c.splits)), block(256);
 #define ECG_WG(KERNEL) \
     hipLaunchKernelGGL(KERNEL, grid, block, 0, st, dy, x, ws, N, Cin, Cout, L, Lo, ldy, pad, c.splits)
@@ -1125,6 +1134,8 @@ int mfma_wgrad(const float *dy, int ldy, const float *x, float *dw, float *db, f
     else
 #endif
     if (dma && c.m_t == 128) ECG_WG((conv1d_mfma_wgrad_dma_kernel<128, 128, 2, 2, 1, kKM, ECG_WG_FL>));
+    else if (tt128 && c.m_t == 64) ECG_WG((conv1d_mfma_wgrad_dma_kernel<64, 128, 2, 2, 1, kKM, ECG_WG_FL, 128>));
+    else if (tt128) ECG_WG((conv1d_mfma_wgrad_dma_kernel<32, 192, 1, 2, 2, kKM, ECG_WG_FL, 128>));
     else if (dma && c.m_t == 64) ECG_WG((conv1d_mfma_wgrad_dma_kernel<64, 128, 2, 2, 1, kKM, ECG_WG_FL>));
     else if (dma) ECG_WG((conv1d_mfma_wgrad_dma_kernel<32, 192, 1, 2, 2, kKM, ECG_WG_FL>));
     else if (c.m_t == 128) ECG_WG((conv1d_mfma_wgrad_kernel<128, 128, 2, 2, 1, 64, kKM, ECG_WG_FL>));
