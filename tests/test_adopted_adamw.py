@@ -144,6 +144,34 @@ def test_adopted_adamw_keeps_stock_semantics_where_the_one_launch_does_not_apply
     assert base <= mf.proj.weight.data_ptr() < base + 4 * of.flat_param.numel()
 
 
+def test_model_checkpoint_after_adoption_is_an_ordinary_checkpoint():
+    """scripts/03:167, 04:207, 05:158 save `model.state_dict()` after training: with the parameters re-homed as views of one flat
+    buffer the file must stay an ordinary checkpoint — no larger than the tensors it holds (torch.save stores the shared
+    storage once), loadable with strict=True into a fresh model, bit for bit."""
+    import io
+    from ecg_hip.optim import adopt_stock_adamw
+    from src.models.ecg_cnn import ECGCNN
+    ma, _ = _twin_models()
+    oa = adopt_stock_adamw(torch.optim.AdamW(ma.parameters(), lr=1e-3), allow_cpu=True)
+    _fake_grads((ma,), 0)
+    oa.step()
+    buf = io.BytesIO()
+    torch.save({"model_state": ma.state_dict(), "classes": ["a"]}, buf)
+    nbytes = sum(t.numel() * t.element_size() for t in ma.state_dict().values())
+    assert buf.tell() < 1.1 * nbytes + 65536, (buf.tell(), nbytes)
+    buf.seek(0)
+    ck = torch.load(buf, map_location="cpu")
+    mb = ECGCNN(num_labels=5)
+    mb.load_state_dict(ck["model_state"], strict=True)
+    for (k, a), b in zip(ma.state_dict().items(), mb.state_dict().values()):
+        assert torch.equal(a, b), k
+    # ... and a copy of the model (copy.deepcopy, as the tests and EMA helpers do) does not alias the optimizer's buffers
+    mc = copy.deepcopy(ma)
+    _fake_grads((ma,), 1)
+    oa.step()
+    assert not torch.equal(next(iter(mc.parameters())), next(iter(ma.parameters())))
+
+
 @gpu
 def test_adopted_stock_adamw_through_the_loops_equals_flat_adamw_and_checkpoints_into_stock_torch():
     """On the GPU the loops adopt the scripts' optimizer: same kernel, same flat layout as FlatAdamW -> the same bits; its
