@@ -13,7 +13,6 @@ For every entry point of one train step (same keys as bench.py's `layers`), from
                 those cycles that are bank conflicts (SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE)
   valu/mfma     SQ_INSTS_VALU / SQ_INSTS_MFMA (both per wave-instruction; VALU includes the MFMAs' own count if the
                 counter does — printed raw), lds/mfma = SQ_INSTS_LDS / SQ_INSTS_MFMA
-  vmem          SQ_ACTIVE_INST_VMEM x 4 / (1024 x us x clk): share of SIMD time with a vector-memory instruction issuing
   TB/s          (2 x FETCH_SIZE + WRITE_SIZE) / us  (gfx950 FETCH_SIZE correction, MI355X_MICROARCH.md HBM section)
   L2hit         TCC_HIT_sum / (TCC_HIT_sum + TCC_MISS_sum)
 clk = GRBM_GUI_ACTIVE / 8 / us, capped at 2.4 GHz (short dispatches: GUI_ACTIVE spans more than the kernel; then 2.1 GHz,
@@ -52,10 +51,10 @@ def main():
             return float("nan")
         return M.mean([s.get(c, 0.0) for s in v])
 
-    lines = [l.rstrip() for l in __doc__.splitlines()[5:26]]
+    lines = [l.rstrip() for l in __doc__.splitlines()[5:25]]
     lines = ["# " + l for l in lines]
     hdr = (f"{'entry point':72s} {'us':>7s} {'clk':>5s} {'mfma':>5s} {'occ':>4s} {'issue':>5s} {'wait':>5s} {'stall':>5s} "
-           f"{'lds':>5s} {'cf':>4s} {'valu/mfma':>9s} {'lds/mfma':>8s} {'vmem':>5s} {'TB/s':>5s} {'L2hit':>5s}  bound")
+           f"{'lds':>5s} {'cf':>4s} {'valu/mfma':>9s} {'lds/mfma':>8s} {'TB/s':>5s} {'L2hit':>5s}  bound")
     lines.append(hdr)
     for key in passes["A"]:
         if a.filter and a.filter not in key:
@@ -81,8 +80,6 @@ def main():
         nm = m("C", key, "SQ_INSTS_MFMA")
         vpm = m("B", key, "SQ_INSTS_VALU") / nm if nm else float("nan")
         lpm = m("B", key, "SQ_INSTS_LDS") / nm if nm else float("nan")
-        usC = M.mean([s["_ns"] for s in passes["C"][key]]) / 1e3 if key in passes.get("C", {}) else float("nan")
-        vmem = m("C", key, "SQ_ACTIVE_INST_VMEM") * 4 / (1024 * usC * 1e3 * 2.1) if usC == usC else float("nan")
         hit, miss = m("C", key, "TCC_HIT_sum"), m("C", key, "TCC_MISS_sum")
         l2 = hit / (hit + miss) if hit + miss else float("nan")
         tbs = float("nan")
@@ -96,7 +93,7 @@ def main():
         def f(v, w, p):
             return f"{v:{w}.{p}f}" if v == v else " " * (w - 1) + "-"
         lines.append(f"{key[:72]:72s} {us:7.1f} {clk:4.2f}{mark} {f(mfma, 5, 3)} {f(occ, 4, 2)} {f(issue, 5, 2)} {f(wait, 5, 2)} "
-                     f"{f(stall, 5, 2)} {f(lds, 5, 3)} {f(cf, 4, 2)} {f(vpm, 9, 2)} {f(lpm, 8, 2)} {f(vmem, 5, 3)} {f(tbs, 5, 2)} "
+                     f"{f(stall, 5, 2)} {f(lds, 5, 3)} {f(cf, 4, 2)} {f(vpm, 9, 2)} {f(lpm, 8, 2)} {f(tbs, 5, 2)} "
                      f"{f(l2, 5, 2)}  {bound}")
     text = "\n".join(lines) + "\n"
     if a.out:
