@@ -53,6 +53,8 @@ def main():
 
     lines = [l.rstrip() for l in __doc__.splitlines()[5:25]]
     lines = ["# " + l for l in lines]
+    lines.insert(0, f"# per entry point of one train step, from the five rocprofv3 --pmc passes of tools/attrib_counters.sh {a.tag} "
+                    "(tools/attrib_table.py); columns:")
     hdr = (f"{'entry point':72s} {'us':>7s} {'clk':>5s} {'mfma':>5s} {'occ':>4s} {'issue':>5s} {'wait':>5s} {'stall':>5s} "
            f"{'lds':>5s} {'cf':>4s} {'valu/mfma':>9s} {'lds/mfma':>8s} {'TB/s':>5s} {'L2hit':>5s}  bound")
     lines.append(hdr)
