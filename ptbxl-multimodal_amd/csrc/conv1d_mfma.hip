@@ -405,15 +405,248 @@ __global__ __launch_bounds__(256, 2) void conv1d_mfma_fwd_kernel(
     ECG_STAMP_AT(4);
 }
 
-struct FwdCfg { int co_t, t_t; };
+// ---------------------------------------------------------------------------------------
+// Forward / input gradient by a two-phase fast-FIR split (training epilogues: EPI_PLAIN, EPI_STATS).
+// The kernels above are bound by the fp32 matrix pipe (0.76-0.84 of its nominal peak at the clocks the chip holds), so the
+// only way down is fewer MFMAs.  With xt[p] = x[t0 - pad + p] and output column m of the tile <-> outputs t0 + 2m, t0 + 2m + 1:
+//     A[m] = sum_{j=0..7} w[2j]             * xt[2m + 2j]
+//     B[m] = sum_{j=0..6} w[2j+1]           * xt[2m + 2j + 1]
+//     C[m] = sum_{j=0..7} (w[2j] + w[2j-1]) * (xt[2m + 2j] + xt[2m + 2j + 1])          (w[-1] = 0)
+//     y[t0 + 2m] = A[m] + B[m],     y[t0 + 2m + 1] = C[m] - A[m] - B[m + 1]
+// i.e. 23 multiplies per output pair instead of 30: three 32 x 32 accumulators (A, B, C) over M_T = T/2 columns take 46 MFMAs
+// per chunk of four input channels where the direct form takes 60.  Nothing is pre-processed: the LDS images are the ones of
+// the kernel above ({weights [K][4][CO_T] | x tile [4][2 M_T + 16]}); one ds_read_b64 per lane yields (xt[2m+2j], xt[2m+2j+1])
+// for the A, B and C step of tap pair j (conflict-free: 32 lanes x 8 bytes), the two sums are one VALU add each.
+// B[m + 1] of the tile's last column belongs to the next tile, so a tile of M_T columns yields 2 M_T - 2 outputs: tiles are
+// TS = 2 M_T - 2 apart (column M_T - 1 only supplies B); for the model's row lengths that is the same number of tiles as
+// 2 M_T-wide ones.  In the epilogue B goes through LDS once (the images are dead) to come back shifted by a column.
+// Rounding: the two extra adds per product and the final combination are fp32; the result differs from the direct form by
+// a few ulp of the accumulated magnitude (tests state the bound) — inference keeps the direct kernel.
+template <int CO_T, int M_T, int WCO, int WT, int EPI>
+__global__ __launch_bounds__(256, 2) void conv1d_mfma_ffa_kernel(
+    const float *__restrict__ x, const float *__restrict__ wp, const float *__restrict__ bias,
+    float *__restrict__ y, float *__restrict__ partials, int Cin, int Cout, int L, int ldx, int Lo,
+    int pad, int P, int tiles_t) {
+    constexpr bool STATS = (EPI == EPI_STATS);
+    static_assert(EPI == EPI_STATS || EPI == EPI_PLAIN, "training epilogues only");
+    static_assert(WCO * WT == 4, "4 waves per workgroup");
+    static_assert(kKM == 15, "tap split 8 + 7");
+    static_assert(CO_T / WCO == 32 && M_T / WT == 32, "one 32 x 32 accumulator per product and wave");
+    constexpr int KK = kKM, CI_C = 4, NJ = (KK + 1) / 2, NST = NJ * (CI_C / 2);
+    constexpr int T_T = 2 * M_T, TS = T_T - 2;
+    constexpr int XS = T_T + 16;                 // x-tile row stride (span 2 (M_T - 1) + 16), even: the b64 reads stay aligned
+    constexpr int WSZ = KK * CI_C * CO_T;
+    constexpr int NDMA = (WSZ + 255) / 256;
+    constexpr int WPAD = NDMA * 256;
+    constexpr int DPW = (NDMA + 3) / 4;
+    constexpr int XEL = CI_C * XS;
+    constexpr int XLOADS = (XEL + 255) / 256;
+    constexpr int IMG = WPAD + XEL;
+    constexpr int BXS = M_T + 1;                 // row stride of the B exchange (odd: conflict-free column walks)
+    constexpr int REDF = STATS ? 4 * 32 * 2 : 0;
+    static_assert(CO_T * BXS + REDF <= 2 * IMG, "B exchange + stat scratch alias the dead images");
+    static_assert(NST >= 2 * XLOADS + DPW, "not enough steps to spread the staging over");
+
+    __shared__ __attribute__((aligned(1024))) float lds[2 * IMG];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int half = lane >> 5, l31 = lane & 31;
+    const int CT = Cout / CO_T;
+    const int tile = xcd_chunked(blockIdx.x, gridDim.x);
+    const int tile_co = tile % CT, tile_nt = tile / CT;
+    const int tile_t = tile_nt % tiles_t, n = tile_nt / tiles_t;
+    const int t0 = tile_t * TS, co0 = tile_co * CO_T;
+    const int wco = (wave / WT) * 32, wm = (wave % WT) * 32;
+    const float *xn = x + (size_t)n * Cin * ldx;
+
+    constexpr bool FL = (ECG_FWD_FL != 0);
+    f32x16 acc[3], acc2[3];
+    f32x16 zero16;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) zero16[r] = 0.f;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) { acc[a] = zero16; acc2[a] = zero16; }
+
+    const float p_b = bias ? bias[co0 + wco + acc_row(l31 & 15, half)] : 0.f;
+
+    int woff[DPW];
+#pragma unroll
+    for (int j = 0; j < DPW; ++j) {
+        const int e = min(((j * 4 + wave) * 64 + lane) * 4, WSZ - 4);
+        const int row = e / CO_T, col = e - row * CO_T;
+        const int k = row / CI_C, ci = row - k * CI_C;
+        woff[j] = (k * Cin + ci) * Cout + col;
+    }
+    int xoff[XLOADS];
+    unsigned xmask = 0;
+#pragma unroll
+    for (int j = 0; j < XLOADS; ++j) {
+        const int e = min(tid + 256 * j, XEL - 1);
+        const int ci = e / XS, pos = e - ci * XS;
+        const int s = t0 - pad + pos;
+        xoff[j] = ci * ldx + min(max(s, 0), L - 1);
+        xmask |= ((s >= 0) && (s < L)) ? (1u << j) : 0u;
+    }
+    float xreg[XLOADS];
+
+    const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) float *)lds;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    auto dma_w = [&](int j, int ci0, float *img) {
+        if ((j * 4 + wave_u) < NDMA)
+            glds16(wp + (size_t)ci0 * Cout + co0, (unsigned)woff[j] * 4u,
+                   (unsigned)__builtin_amdgcn_readfirstlane((int)(lds_base + (unsigned)((img - lds) + (j * 4 + wave_u) * 256) * 4u)));
+    };
+    auto load_x = [&](int j, int ci0) { xreg[j] = xn[(size_t)ci0 * ldx + xoff[j]]; };
+    auto commit_x = [&](int j, float *img) {
+        const int e = tid + 256 * j;
+        const unsigned keep = 0u - ((xmask >> j) & 1u);
+        if (256 * (j + 1) <= XEL || e < XEL)
+            img[WPAD + e] = __uint_as_float(__float_as_uint(xreg[j]) & keep);
+    };
+
+    const int nchunks = Cin / CI_C;
+#pragma unroll
+    for (int j = 0; j < DPW; ++j) dma_w(j, 0, lds);
+#pragma unroll
+    for (int j = 0; j < XLOADS; ++j) load_x(j, 0);
+#pragma unroll
+    for (int j = 0; j < XLOADS; ++j) commit_x(j, lds);
+    if (nchunks > 1) {
+#pragma unroll
+        for (int j = 0; j < XLOADS; ++j) load_x(j, CI_C);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    typedef float f32x2t __attribute__((ext_vector_type(2)));
+    for (int c = 0; c < nchunks; ++c) {
+        const float *ws = lds + (c & 1) * IMG, *xs = ws + WPAD;
+        float *nxt = lds + ((c + 1) & 1) * IMG;
+        const bool do_next = c + 1 < nchunks, do_next2 = c + 2 < nchunks;
+        const int ci_next = (c + 1) * CI_C, ci_next2 = (c + 2) * CI_C;
+
+        // one step = tap pair j of channel pair cp: w[2j], w[2j+1] (one dword each) and (xt[2m+2j], xt[2m+2j+1]) (one b64)
+        // feed the A, B and C MFMAs; the reads of step s + 1 are issued before the MFMAs of step s
+        auto ld = [&](int st, float &wa, float &wb, f32x2t &xq) {
+            const int j = st / (CI_C / 2), cp = st % (CI_C / 2);
+            const float *wrow = ws + ((2 * j * CI_C + 2 * cp + half) * CO_T + wco + l31);
+            wa = wrow[0];
+            wb = (2 * j + 1 < KK) ? wrow[CI_C * CO_T] : 0.f;
+            xq = *reinterpret_cast<const f32x2t *>(xs + (2 * cp + half) * XS + 2 * (wm + l31) + 2 * j);
+        };
+        float wa_c, wb_c, wa_n, wb_n, wprev[CI_C / 2];
+        f32x2t xq_c, xq_n;
+#pragma unroll
+        for (int i = 0; i < CI_C / 2; ++i) wprev[i] = 0.f;
+        ld(0, wa_c, wb_c, xq_c);
+#pragma unroll
+        for (int st = 0; st < NST; ++st) {
+            const int j = st / (CI_C / 2), cp = st % (CI_C / 2);
+            ld(st + 1 < NST ? st + 1 : 0, wa_n, wb_n, xq_n);
+            wait_lgkm_f(3);
+            if (st < XLOADS) {
+                if (do_next) commit_x(st, nxt);
+            } else if (st < XLOADS + DPW) {
+                if (do_next) dma_w(st - XLOADS, ci_next, nxt);
+            } else if (st < 2 * XLOADS + DPW) {
+                if (do_next2) load_x(st - XLOADS - DPW, ci_next2);
+            }
+#ifndef ECG_FFA_MINUS
+#define ECG_FFA_MINUS 1
+#endif
+            const float wc = ECG_FFA_MINUS ? wa_c - wprev[cp] : wa_c + wprev[cp];
+            const float xc = ECG_FFA_MINUS ? xq_c[0] - xq_c[1] : xq_c[0] + xq_c[1];
+            __builtin_amdgcn_sched_barrier(0);
+            acc[0] = mfma32(wa_c, xq_c[0], (FL && j == 0 && cp == 0) ? zero16 : acc[0]);
+            if (2 * j + 1 < KK) acc[1] = mfma32(wb_c, xq_c[1], (FL && j == 0 && cp == 0) ? zero16 : acc[1]);
+            acc[2] = mfma32(wc, xc, (FL && j == 0 && cp == 0) ? zero16 : acc[2]);
+            __builtin_amdgcn_sched_barrier(0);
+            wprev[cp] = wb_c;
+            wa_c = wa_n; wb_c = wb_n; xq_c = xq_n;
+        }
+        if (FL) {
+#pragma unroll
+            for (int a = 0; a < 3; ++a) acc2[a] += acc[a];
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+    if (FL) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a) acc[a] = acc2[a];
+    }
+
+    // ---- epilogue -------------------------------------------------------------------------------------
+    __builtin_amdgcn_s_waitcnt(0x0F70);        // vmcnt(0) (see the kernel above)
+    // B one column to the left: through LDS (the last column of a wave's block comes from the wave beside it)
+    float *bx = lds, *red = lds + CO_T * BXS;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) bx[(wco + acc_row(r, half)) * BXS + wm + l31] = acc[1][r];
+    __syncthreads();
+    f32x16 bn;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) bn[r] = bx[(wco + acc_row(r, half)) * BXS + min(wm + l31 + 1, M_T - 1)];
+    auto pick = [&](float v, int r) {
+        const int vi = __float_as_int(v);
+        const float lo = __int_as_float(__builtin_amdgcn_readlane(vi, r));
+        const float hi = __int_as_float(__builtin_amdgcn_readlane(vi, r + 32));
+        return half ? hi : lo;
+    };
+    float st_s = 0.f, st_q = 0.f;
+    const int m = wm + l31, t = t0 + 2 * m;
+    const bool ok0 = m < M_T - 1 && t < Lo, ok1 = m < M_T - 1 && t + 1 < Lo;
+    float *yw = y + ((size_t)n * Cout + co0 + wco + 4 * half) * Lo + t;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int rowk = (r & 3) + 8 * (r >> 2);
+        const float bv = pick(p_b, r);
+        const float v0 = (acc[0][r] + acc[1][r]) + bv;
+        const float v1 = (ECG_FFA_MINUS ? (acc[0][r] + bn[r]) - acc[2][r] : (acc[2][r] - acc[0][r]) - bn[r]) + bv;
+        float s = 0.f, q = 0.f;
+        if (ok0) { yw[rowk * Lo] = v0; if (STATS) { s += v0; q = __fmaf_rn(v0, v0, q); } }
+        if (ok1) { yw[rowk * Lo + 1] = v1; if (STATS) { s += v1; q = __fmaf_rn(v1, v1, q); } }
+        if (STATS) {
+            const bool mine = (l31 & 15) == r;
+            s = row16_sum(s);
+            st_s += mine ? s : 0.f;
+            q = row16_sum(q);
+            st_q += mine ? q : 0.f;
+        }
+    }
+    if (STATS) {
+        const float s = st_s + __shfl_xor(st_s, 16, 64);
+        const float q = st_q + __shfl_xor(st_q, 16, 64);
+        if (l31 < 16) {
+            const int lc = acc_row(l31, half);
+            red[(wave * 32 + lc) * 2] = s;
+            red[(wave * 32 + lc) * 2 + 1] = q;
+        }
+        __syncthreads();
+        for (int e = tid; e < CO_T * 2; e += 256) {
+            const int col = e >> 1, w = e & 1;
+            const int wrow = col / 32, lc = col - wrow * 32;
+            float s2 = 0.f;
+#pragma unroll
+            for (int j = 0; j < WT; ++j) s2 += red[((wrow * WT + j) * 32 + lc) * 2 + w];
+            const int pidx = n * tiles_t + tile_t;
+            partials[((size_t)(co0 + col) * P + pidx) * 2 + w] = s2;
+        }
+    }
+}
+
+struct FwdCfg { int co_t, t_t, stride; bool ffa; };     // stride: distance of the t tiles (ffa: t_t - 2)
+#ifndef ECG_FWD_FFA
+#define ECG_FWD_FFA 3       // bit 0: forward (statistics epilogue), bit 1: plain epilogue (input gradient, unfused forward)
+#endif
 
 // Tile choice of the one-tile-per-workgroup kernel (inference epilogues).  Measured on MI355X (B=256): 64x128
 // tiles at 4 resident workgroups per CU beat 128x128 at 2 per CU by 6-8 % (more independent waves per SIMD to
 // cover each other's prologue, epilogue and staging waits), so the 64-channel tile is used whenever C_out allows it.
-static FwdCfg fwd_cfg(int N, int Cout, int Lo) {
+static FwdCfg fwd_cfg(int N, int Cout, int Lo, bool train) {
     (void)N; (void)Lo;
-    if (Cout % 64 == 0) return {64, 128};
-    return {32, 256};
+    const bool ffa = train && (ECG_FWD_FFA & 1);         // (the statistics partials: forward with the training epilogue)
+    if (Cout % 64 == 0) return {64, 128, ffa ? 126 : 128, ffa};
+    return {32, 256, ffa ? 254 : 256, ffa};
 }
 
 bool mfma_fwd_supported(int Cin, int Cout, int K, int pad) {
@@ -423,13 +656,25 @@ bool mfma_fwd_supported(int Cin, int Cout, int K, int pad) {
 
 int mfma_fwd_stat_partials(int N, int Cin, int Cout, int Lo) {
     (void)Cin;
-    return N * cdiv(Lo, fwd_cfg(N, Cout, Lo).t_t);
+    return N * cdiv(Lo, fwd_cfg(N, Cout, Lo, true).stride);
 }
 
 template <int CO_T, int T_T, int WCO, int WT>
 static void launch_fwd(const float *x, const float *wp, const float *bias, float *y,
                        float *partials, const EvalEpi *ev, int N, int Cin, int Cout, int L, int ldx,
                        int Lo, int pad, hipStream_t st) {
+    if (!ev && (((ECG_FWD_FFA & 1) && partials) || ((ECG_FWD_FFA & 2) && !partials))) {
+        const int tiles_t = cdiv(Lo, T_T - 2);
+        dim3 grid((unsigned)((size_t)tiles_t * (Cout / CO_T) * N)), block(256);
+        const int P = N * tiles_t;
+        if (partials)
+            hipLaunchKernelGGL((conv1d_mfma_ffa_kernel<CO_T, T_T / 2, WCO, WT, EPI_STATS>), grid, block, 0, st, x, wp, bias, y,
+                               partials, Cin, Cout, L, ldx, Lo, pad, P, tiles_t);
+        else
+            hipLaunchKernelGGL((conv1d_mfma_ffa_kernel<CO_T, T_T / 2, WCO, WT, EPI_PLAIN>), grid, block, 0, st, x, wp, bias, y,
+                               partials, Cin, Cout, L, ldx, Lo, pad, P, tiles_t);
+        return;
+    }
     const int tiles_t = cdiv(Lo, T_T);
     dim3 grid((unsigned)((size_t)tiles_t * (Cout / CO_T) * N)), block(256);
     const int P = N * tiles_t;
@@ -448,7 +693,7 @@ static int mfma_fwd_any(const float *x, const float *wp, const float *bias, floa
                         float *partials, const EvalEpi *ev, int N, int Cin, int Cout, int L, int ldx,
                         int K, int pad, hipStream_t st) {
     const int Lo = L + 2 * pad - K + 1;
-    const FwdCfg c = fwd_cfg(N, Cout, Lo);
+    const FwdCfg c = fwd_cfg(N, Cout, Lo, ev == nullptr);
     if (c.co_t == 64)
         launch_fwd<64, 128, 2, 2>(x, wp, bias, y, partials, ev, N, Cin, Cout, L, ldx, Lo, pad, st);
     else
@@ -474,7 +719,7 @@ int mfma_fwd_eval_pool(const float *x, const float *wp, const float *bias, const
 
 bool mfma_fwd_eval_gap_supported(int Cin, int Cout, int L, int K, int pad) {
     const int Lo = L + 2 * pad - K + 1;
-    return mfma_fwd_supported(Cin, Cout, K, pad) && Lo >= 2 && Lo <= fwd_cfg(1, Cout, Lo).t_t;
+    return mfma_fwd_supported(Cin, Cout, K, pad) && Lo >= 2 && Lo <= fwd_cfg(1, Cout, Lo, false).t_t;
 }
 
 // =======================================================================================
