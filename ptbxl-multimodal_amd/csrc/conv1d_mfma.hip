@@ -20,6 +20,7 @@
 // backward (src/training/loop.py:33).
 #include "common.h"
 #include <cstdlib>
+#include <type_traits>
 
 namespace ecg {
 
@@ -422,8 +423,11 @@ __global__ __launch_bounds__(256, 2) void conv1d_mfma_fwd_kernel(
 // 2 M_T-wide ones.  In the epilogue B goes through LDS once (the images are dead) to come back shifted by a column.
 // Rounding: the two extra adds per product and the final combination are fp32; the result differs from the direct form by
 // a few ulp of the accumulated magnitude (tests state the bound) — inference keeps the direct kernel.
+#ifndef ECG_FFA_MINB
+#define ECG_FFA_MINB 2
+#endif
 template <int CO_T, int M_T, int WCO, int WT, int EPI>
-__global__ __launch_bounds__(256, 2) void conv1d_mfma_ffa_kernel(
+__global__ __launch_bounds__(256, ECG_FFA_MINB) void conv1d_mfma_ffa_kernel(
     const float *__restrict__ x, const float *__restrict__ wp, const float *__restrict__ bias,
     float *__restrict__ y, float *__restrict__ partials, int Cin, int Cout, int L, int ldx, int Lo,
     int pad, int P, int tiles_t) {
@@ -603,8 +607,14 @@ __global__ __launch_bounds__(256, 2) void conv1d_mfma_ffa_kernel(
         const float v0 = (acc[0][r] + acc[1][r]) + bv;
         const float v1 = (ECG_FFA_MINUS ? (acc[0][r] + bn[r]) - acc[2][r] : (acc[2][r] - acc[0][r]) - bn[r]) + bv;
         float s = 0.f, q = 0.f;
-        if (ok0) { yw[rowk * Lo] = v0; if (STATS) { s += v0; q = __fmaf_rn(v0, v0, q); } }
-        if (ok1) { yw[rowk * Lo + 1] = v1; if (STATS) { s += v1; q = __fmaf_rn(v1, v1, q); } }
+        // (the pair is 4-byte aligned only: odd row lengths; gfx950 global stores do not need more)
+        typedef float f32x2u __attribute__((ext_vector_type(2), aligned(4)));
+        if (ok1) { f32x2u v; v[0] = v0; v[1] = v1; *reinterpret_cast<f32x2u *>(yw + rowk * Lo) = v; }
+        else if (ok0) yw[rowk * Lo] = v0;
+        if (STATS) {
+            if (ok0) { s += v0; q = __fmaf_rn(v0, v0, q); }
+            if (ok1) { s += v1; q = __fmaf_rn(v1, v1, q); }
+        }
         if (STATS) {
             const bool mine = (l31 & 15) == r;
             s = row16_sum(s);
@@ -1297,6 +1307,330 @@ __global__ __launch_bounds__(256, 2) void conv1d_mfma_wgrad_dma_kernel(
     ECG_STAMP_AT(4);
 }
 
+// ---------------------------------------------------------------------------------------
+// Weight gradient by the transposed two-phase fast-FIR split (the forward's split, conv1d_mfma_ffa_kernel, read as a trilinear
+// form in (dY, w, x) and differentiated by w).  With m <-> the output pair (2m, 2m + 1) of a stage, xt[p] = x[t0 - pad + p]:
+//     U[co][ci][j] = sum_m (dY[2m] + dY[2m+1]) * xt[2m + 2j]                        j = 0..7
+//     V[co][ci][j] = sum_m (dY[2m] + dY[2m-1]) * xt[2m + 2j + 1]                    j = 0..6, m = 0..T/2 (dY outside the stage = 0)
+//     G[co][ci][j] = sum_m  dY[2m+1]           * (xt[2m + 2j] - xt[2m + 2j + 1])    j = 0..7
+//     dW[2j] = U[j] - G[j],     dW[2j+1] = V[j] + G[j+1]
+// 23 column families of half as many reduction steps instead of 15: 23/30 of the MFMAs.  The pairing (dY[2m], dY[2m-1]) of V
+// is kept INSIDE a stage (its first and last m carry one term each: T/2 + 1 values, one extra MFMA step per stage), so
+// stages stay independent.  A workgroup owns one column tile of ONE family: the A operand (the dY combination) is uniform
+// per workgroup; B is one ds_read_b64 per lane and step ((xt[2m+2j], xt[2m+2j+1]); x rows 16 floats (mod 64) apart: four
+// channels x eight tap pairs of a 32-lane column block cover the 64 banks once).  For smooth x the G products are small
+// and xt[2m+2j] - xt[2m+2j+1] is exact, so U - G loses nothing against the direct sum (tests: float64 comparison).
+// Slab layout: [s][co][U columns ci*8+j | V columns ci*7+j | G columns ci*8+j] (+ the bias slab); wgrad_ffa_reduce_kernel
+// adds the slabs in double, in slab order, and forms the 15 taps.  Image, DMA, swizzle, two-level accumulation: as in
+// conv1d_mfma_wgrad_dma_kernel above.
+template <int M_T, int R_T, int WM, int WR, int FL, int T_T>
+__global__ __launch_bounds__(256, 2) void conv1d_mfma_wgrad_ffa_kernel(
+    const float *__restrict__ dy, const float *__restrict__ x, float *__restrict__ slab, int N,
+    int Cin, int Cout, int L, int Lo, int ldy, int pad, int S) {
+    static_assert(WM * WR == 4, "4 waves per workgroup");
+    static_assert(kKM == 15, "tap split 8 + 7");
+    static_assert(T_T == 64 || T_T == 128, "64 or 128 time steps per stage");
+    constexpr int LPR = T_T / 4, RPP = 64 / LPR;
+    constexpr int MC = M_T / WM / 32, MR = R_T / WR / 32;
+    constexpr int NST = T_T / 4, NGRP = NST / 4;        // MFMA steps per stage (two m each), in groups of 4 (= 16 t per lane half)
+    constexpr int XS = T_T + 16;                        // >= T_T + 14, == 16 (mod 64), even
+    static_assert(XS % 64 == 16, "x rows 16 banks apart");
+    constexpr int NCI = (R_T + 6) / 7 + 1;              // channels a column tile of the 7-tap family can touch
+    constexpr int XEL = NCI * XS, XLOADS = (XEL + 255) / 256;
+    constexpr int AEL = M_T * T_T;
+    constexpr int NDMA = AEL / 256;
+    constexpr int DPW = NDMA / 4;
+    constexpr int IMG = ((AEL + XEL + 63) / 64) * 64;
+    constexpr int OPS = 2 * XLOADS + DPW;               // staging operations of a stage, spread over its steps
+    static_assert(NDMA % 4 == 0, "dY image must split evenly over the four waves");
+    static_assert(XLOADS <= 32, "mask bits");
+    static_assert(2 * IMG * 4 <= 80 * 1024, "two workgroups per CU");
+
+    __shared__ __attribute__((aligned(1024))) float lds[2 * IMG];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int half = lane >> 5, l31 = lane & 31;
+    const int RU = Cin * 8, RV = Cin * 7;
+    const int TU = (RU + R_T - 1) / R_T, TV = (RV + R_T - 1) / R_T;
+    const int RT = 2 * TU + TV, CT = Cout / M_T;
+    const int tile = xcd_chunked(blockIdx.x, gridDim.x);
+    const int tile_r = tile % RT, tile_cs = tile / RT;
+    const int fam = tile_r < TU ? 0 : (tile_r < TU + TV ? 1 : 2);                 // uniform per workgroup
+    const int tile_rf = tile_r - (fam == 0 ? 0 : (fam == 1 ? TU : TU + TV));
+    const int NJ = fam == 1 ? 7 : 8, RF = Cin * NJ, offf = fam == 0 ? 0 : (fam == 1 ? RU : RU + RV);
+    const int r0 = tile_rf * R_T, co0 = (tile_cs % CT) * M_T, s = tile_cs / CT;
+    const int wr = wave % WR, wm = wave / WR;
+    const int wm0 = wm * (M_T / WM), wr0 = wr * (R_T / WR);
+    const int ci_base = r0 / NJ;
+    const int ntt = (Lo + T_T - 1) / T_T;
+    const int it_begin = (int)((long long)N * ntt * s / S), it_end = (int)((long long)N * ntt * (s + 1) / S);
+
+    int xcol[MR];
+#pragma unroll
+    for (int j = 0; j < MR; ++j) {
+        int r = r0 + wr0 + 32 * j + l31;
+        if (r >= RF) r = RF - 1;               // clamped columns compute garbage that is never stored
+        const int ci = r / NJ;
+        xcol[j] = (ci - ci_base) * XS + 2 * (r - ci * NJ) + 8 * half;
+    }
+
+    f32x16 acc[MC][MR], acc2[MC][MR];
+    f32x16 zero16;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) zero16[r] = 0.f;
+#pragma unroll
+    for (int a = 0; a < MC; ++a)
+#pragma unroll
+        for (int b = 0; b < MR; ++b) { acc[a][b] = zero16; acc2[a][b] = zero16; }
+    float bsum[MC], bsum2[MC];
+#pragma unroll
+    for (int a = 0; a < MC; ++a) bsum[a] = bsum2[a] = 0.f;
+    const bool want_bias = (tile_r == 0) && (wr == 0);     // (family U: its A operand sums to the bias gradient)
+
+    int doff[DPW];
+#pragma unroll
+    for (int j = 0; j < DPW; ++j) {
+        const int row = (j * 4 + wave) * RPP + lane / LPR;
+        doff[j] = row * ldy + (((lane % LPR) ^ (row & 15)) << 2);
+    }
+    float xreg[XLOADS];                                 // (element -> (channel, position) is recomputed per load: registers)
+    unsigned xmask = 0, cxmask = 0;
+    const int total = it_end - it_begin;
+
+    int sn = it_begin / ntt, stt = it_begin - sn * ntt;
+    int dn = sn, dtt = stt;
+    auto advance = [&]() { if (++stt == ntt) { stt = 0; ++sn; } };
+    const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) float *)lds;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    auto dma_a = [&](int j, float *img) {
+        const float *base = dy + ((size_t)min(dn, N - 1) * Cout + co0) * ldy + dtt * T_T;
+        glds16(base, (unsigned)doff[j] * 4u,
+               (unsigned)__builtin_amdgcn_readfirstlane((int)(lds_base + (unsigned)((img - lds) + (j * 4 + wave_u) * 256) * 4u)));
+    };
+    auto load_x = [&](int j) {
+        const float *xn = x + (size_t)min(sn, N - 1) * Cin * L;
+        const int e = min(tid + 256 * j, XEL - 1), row = e / XS;
+        const int sidx = stt * T_T + (e - row * XS) - pad;
+        xreg[j] = xn[min(ci_base + row, Cin - 1) * L + min(max(sidx, 0), L - 1)];
+        const unsigned bit = ((sidx >= 0) && (sidx < L)) ? (1u << j) : 0u;
+        xmask = (j == 0) ? bit : (xmask | bit);
+    };
+    auto commit_x = [&](int j, float *img) {
+        const int e = tid + 256 * j;
+        const unsigned keep = 0u - ((cxmask >> j) & 1u);
+        if (256 * (j + 1) <= XEL || e < XEL)
+            img[AEL + e] = __uint_as_float(__float_as_uint(xreg[j]) & keep);
+    };
+
+    if (total > 0) {
+#pragma unroll
+        for (int j = 0; j < DPW; ++j) dma_a(j, lds);
+#pragma unroll
+        for (int j = 0; j < XLOADS; ++j) load_x(j);
+        cxmask = xmask;
+#pragma unroll
+        for (int j = 0; j < XLOADS; ++j) commit_x(j, lds);
+        advance();
+        dn = sn; dtt = stt;
+#pragma unroll
+        for (int j = 0; j < XLOADS; ++j) load_x(j);
+        advance();
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    typedef float f32x2t __attribute__((ext_vector_type(2)));
+    const int aoff = (wm0 + l31) * T_T, swz = (l31 & 15) << 2;
+    // one stage of family FAM (0 = U, 1 = V, 2 = G)
+    auto stage = [&](auto fam_c, int it) {
+        constexpr int FAM = decltype(fam_c)::value;
+        const float *dys = lds + (it & 1) * IMG, *xs = dys + AEL;
+        float *nxt = lds + ((it + 1) & 1) * IMG;
+        cxmask = xmask;
+        const float *arow = dys + aoff;
+        // group g: this lane half's eight consecutive t (two 16-byte chunks, swizzled) [+ V: the element in front of them]
+        // (the first chunk is read two steps before the group starts, the second during its first step: one spare set of
+        // four registers per row block instead of two)
+        auto lda_lo = [&](int g, f32x4 *lo, float *prev) {
+#pragma unroll
+            for (int i = 0; i < MC; ++i) {
+                const float *rb = arow + 32 * i * T_T;
+                const int c0 = 4 * g + 2 * half;
+                lo[i] = *reinterpret_cast<const f32x4 *>(rb + ((c0 << 2) ^ swz));
+                if (FAM == 1) {
+                    const float pv = rb[((max(c0 - 1, 0) << 2) ^ swz) + 3];
+                    prev[i] = (g == 0 && half == 0) ? 0.f : pv;
+                }
+            }
+        };
+        auto lda_hi = [&](int g, f32x4 *hi) {
+#pragma unroll
+            for (int i = 0; i < MC; ++i)
+                hi[i] = *reinterpret_cast<const f32x4 *>(arow + 32 * i * T_T + (((4 * g + 2 * half + 1) << 2) ^ swz));
+        };
+        auto ldb = [&](int st, f32x2t *b) {
+            const int tp = 16 * (st >> 2) + 2 * (st & 3);
+#pragma unroll
+            for (int j = 0; j < MR; ++j) b[j] = *reinterpret_cast<const f32x2t *>(xs + xcol[j] + tp);
+        };
+        f32x4 lo_c[MC], hi_c[MC], lo_n[MC];
+        float pv_c[MC], pv_n[MC];
+        f32x2t b_c[MR], b_n[MR];
+        lda_lo(0, lo_c, pv_c);
+        lda_hi(0, hi_c);
+        ldb(0, b_c);
+#pragma unroll
+        for (int st = 0; st < NST; ++st) {
+            const int j4 = st & 3;
+            ldb(st + 1 < NST ? st + 1 : 0, b_n);
+            if (j4 == 2 && (st >> 2) + 1 < NGRP) lda_lo((st >> 2) + 1, lo_n, pv_n);
+            if (j4 == 0 && st > 0) lda_hi(st >> 2, hi_c);
+#pragma unroll
+            for (int o = st * OPS / NST; o < (st + 1) * OPS / NST; ++o) {
+                // dY pieces FIRST (a stage is 16 short steps: issued last they would be waited for at the barrier), then the
+                // x commits, then the loads of the stage after next — the youngest vector-memory operations, left in flight
+                if (o < DPW) dma_a(o, nxt);
+                else if (o < DPW + XLOADS) commit_x(o - DPW, nxt);
+                else load_x(o - DPW - XLOADS);
+            }
+            float av[MC], bv[MR];
+#pragma unroll
+            for (int i = 0; i < MC; ++i) {
+                const f32x4 d = j4 < 2 ? lo_c[i] : hi_c[i];
+                const float d0 = d[2 * (j4 & 1)], d1 = d[2 * (j4 & 1) + 1];
+                const float dp = j4 == 0 ? pv_c[i] : (j4 == 1 ? lo_c[i][1] : (j4 == 2 ? lo_c[i][3] : hi_c[i][1]));
+                av[i] = FAM == 0 ? d0 + d1 : (FAM == 1 ? d0 + dp : d1);
+            }
+#pragma unroll
+            for (int j = 0; j < MR; ++j) bv[j] = FAM == 0 ? b_c[j][0] : (FAM == 1 ? b_c[j][1] : b_c[j][0] - b_c[j][1]);
+            __builtin_amdgcn_sched_barrier(0);
+            if (FAM == 0) {
+#pragma unroll
+                for (int i = 0; i < MC; ++i) bsum[i] = (FL && st == 0) ? av[i] : bsum[i] + av[i];
+            }
+#pragma unroll
+            for (int i = 0; i < MC; ++i)
+#pragma unroll
+                for (int j = 0; j < MR; ++j)
+                    acc[i][j] = mfma32(av[i], bv[j], (FL && st == 0) ? zero16 : acc[i][j]);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < MR; ++j) b_c[j] = b_n[j];
+            if (j4 == 3) {
+#pragma unroll
+                for (int i = 0; i < MC; ++i) { lo_c[i] = lo_n[i]; pv_c[i] = pv_n[i]; }
+            }
+        }
+        if (FAM == 1) {
+            // m = T_T / 2: the last dY of the stage alone (lane half 0; half 1 contributes an exact zero)
+#pragma unroll
+            for (int i = 0; i < MC; ++i) {
+                const float dl = arow[32 * i * T_T + (((LPR - 1) << 2) ^ swz) + 3];
+                const float a = half ? 0.f : dl;
+#pragma unroll
+                for (int j = 0; j < MR; ++j)
+                    acc[i][j] = mfma32(a, xs[xcol[j] - 8 * half + T_T + 1], acc[i][j]);
+            }
+        }
+        if (FL) {
+#pragma unroll
+            for (int i = 0; i < MC; ++i)
+#pragma unroll
+                for (int j = 0; j < MR; ++j) acc2[i][j] += acc[i][j];
+            if (FAM == 0) {
+#pragma unroll
+                for (int i = 0; i < MC; ++i) bsum2[i] += bsum[i];
+            }
+        }
+        dn = sn; dtt = stt;
+        advance();
+        asm volatile("s_waitcnt vmcnt(%0)" :: "n"(XLOADS) : "memory");    // the DMA pieces are older than the x loads
+        __syncthreads();
+    };
+    if (fam == 0) { for (int it = 0; it < total; ++it) stage(std::integral_constant<int, 0>{}, it); }
+    else if (fam == 1) { for (int it = 0; it < total; ++it) stage(std::integral_constant<int, 1>{}, it); }
+    else { for (int it = 0; it < total; ++it) stage(std::integral_constant<int, 2>{}, it); }
+
+    if (FL) {
+#pragma unroll
+        for (int i = 0; i < MC; ++i) {
+            bsum[i] = bsum2[i];
+#pragma unroll
+            for (int j = 0; j < MR; ++j) acc[i][j] = acc2[i][j];
+        }
+    }
+    if (want_bias) {
+#pragma unroll
+        for (int i = 0; i < MC; ++i) bsum[i] += __shfl_xor(bsum[i], 32, 64);
+    }
+    const size_t RVT = (size_t)Cin * 23, wslab = (size_t)Cout * RVT;
+    float *out = slab + (size_t)s * wslab + offf;
+#pragma unroll
+    for (int i = 0; i < MC; ++i)
+#pragma unroll
+        for (int j = 0; j < MR; ++j) {
+            const int r = r0 + wr0 + 32 * j + l31;
+            if (r < RF) {
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    const int co = co0 + wm0 + 32 * i + acc_row(q, half);
+                    out[(size_t)co * RVT + r] = acc[i][j][q];
+                }
+            }
+        }
+    if (want_bias && half == 0) {
+#pragma unroll
+        for (int i = 0; i < MC; ++i)
+            slab[(size_t)S * wslab + (size_t)s * Cout + co0 + wm0 + 32 * i + l31] = bsum[i];
+    }
+}
+
+// dw[co][ci][k] from the S slabs of the kernel above (double sums in slab order; wave w of a workgroup takes slabs w, w + G, ...);
+// the bias row behind them as in wgrad_reduce_kernel
+template <int G>
+__global__ __launch_bounds__(64 * G) void wgrad_ffa_reduce_kernel(const float *__restrict__ slab, float *__restrict__ dw,
+                                                                  float *__restrict__ db, int Cin, int Cout, int S) {
+    __shared__ double part[G][64][2];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const size_t i = (size_t)blockIdx.x * 64 + lane;
+    const size_t nout = (size_t)Cout * Cin * 15, RVT = (size_t)Cin * 23, wslab = (size_t)Cout * RVT;
+    const bool live = i < nout + Cout && (i < nout || db);
+    double a = 0.0, g = 0.0;
+    bool odd = false;
+    if (live) {
+        if (i < nout) {
+            const int co = (int)(i / ((size_t)Cin * 15)), rem = (int)(i - (size_t)co * Cin * 15);
+            const int ci = rem / 15, k = rem - ci * 15, j = k >> 1;
+            odd = k & 1;
+            const float *pa = slab + (size_t)co * RVT + (odd ? Cin * 8 + ci * 7 + j : ci * 8 + j);
+            const float *pg = slab + (size_t)co * RVT + Cin * 15 + ci * 8 + j + (odd ? 1 : 0);
+            int s = w;
+            for (; s + 3 * G < S; s += 4 * G) {
+                float va[4], vg[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { va[u] = pa[(size_t)(s + u * G) * wslab]; vg[u] = pg[(size_t)(s + u * G) * wslab]; }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { a += (double)va[u]; g += (double)vg[u]; }
+            }
+            for (; s < S; s += G) { a += (double)pa[(size_t)s * wslab]; g += (double)pg[(size_t)s * wslab]; }
+        } else {
+            const float *src = slab + (size_t)S * wslab + (i - nout);
+            for (int s = w; s < S; s += G) a += (double)src[(size_t)s * Cout];
+        }
+    }
+    if (G > 1) {
+        part[w][lane][0] = a; part[w][lane][1] = g;
+        __syncthreads();
+        if (w != 0) return;
+#pragma unroll
+        for (int q = 1; q < G; ++q) { a += part[q][lane][0]; g += part[q][lane][1]; }
+    }
+    if (live) {
+        if (i < nout) dw[i] = (float)(odd ? a + g : a - g);
+        else db[i - nout] = (float)a;
+    }
+}
+
 // conv1d_direct.hip: dw[i] = sum_s slab[s][i] in fixed order
 int wgrad_reduce(const float *ws, float *dw, float *db, size_t wslab, int Cout, int S,
                  hipStream_t st);
@@ -1345,6 +1679,24 @@ static WgCfg wgrad_cfg(int N, int Cin, int Cout, int Lo, bool dma, int tt = 64) 
     return c;
 }
 
+#ifndef ECG_WG_FFA
+#define ECG_WG_FFA 1         // fast-FIR weight gradient on the 64- / 128-channel tiles (A/B: -DECG_WG_FFA=0)
+#endif
+// fast-FIR form: column tiles of 128 over the three families (U: 8 C_in, V: 7 C_in, G: 8 C_in columns), 64-step stages
+// Measured (B = 256, 12x1000, same box): 128 -> 256 channels 290.3 -> 277.0 us; 64 -> 128 164.5 -> 164.8; 32 -> 64 88.9 -> 94.4 —
+// a stage is half as many MFMA steps between the same barrier, x commits and second-level adds (~2 000 cycles per stage
+// in both forms), and 128-step stages do not fit two workgroups per CU here: used where the column count makes it pay.
+static bool wgrad_ffa_ok(int Cin, int Cout, bool dma) { return ECG_WG_FFA && dma && Cout % 128 == 0 && Cin >= 128; }
+static int wgrad_ffa_splits(int N, int Cin, int Cout, int Lo) {
+    const int m_t = Cout % 128 == 0 ? 128 : 64;
+    const int tiles = (2 * cdiv(Cin * 8, 128) + cdiv(Cin * 7, 128)) * (Cout / m_t);
+    long long s = ECG_WG_SLOTS / tiles;
+    const long long cap = (long long)N * cdiv(Lo, 64);
+    if (s > cap) s = cap;
+    if (s < 1) s = 1;
+    return (int)s;
+}
+
 bool mfma_wgrad_supported(int Cin, int Cout, int K, int pad) {
     (void)pad; (void)Cin;
     return K == kKM && Cout % 32 == 0;
@@ -1353,7 +1705,12 @@ bool mfma_wgrad_supported(int Cin, int Cout, int K, int pad) {
 size_t mfma_wgrad_ws_floats(int N, int Cin, int Cout, int L, int K, int pad) {
     const int Lo = L + 2 * pad - K + 1;
     const WgCfg a = wgrad_cfg(N, Cin, Cout, Lo, false), b = wgrad_cfg(N, Cin, Cout, Lo, true);      // (128-step stages: never more splits)
-    return (size_t)(a.splits > b.splits ? a.splits : b.splits) * ((size_t)Cout * Cin * K + Cout);
+    size_t need = (size_t)(a.splits > b.splits ? a.splits : b.splits) * ((size_t)Cout * Cin * K + Cout);
+    if (wgrad_ffa_ok(Cin, Cout, true)) {
+        const size_t ffa = (size_t)wgrad_ffa_splits(N, Cin, Cout, Lo) * ((size_t)Cout * Cin * 23 + Cout);
+        if (ffa > need) need = ffa;
+    }
+    return need;
 }
 
 // dY rows that the DMA kernel can stream: 64-float multiples with a zero pad (see the kernel)
@@ -1370,6 +1727,33 @@ int mfma_wgrad(const float *dy, int ldy, const float *x, float *dw, float *db, f
                      (reinterpret_cast<uintptr_t>(dy) & 15) == 0;
     // 128-step stages for the small tiles (blocks 0-1) when the rows allow it (stride a multiple of 128 floats, zero pad to it)
     const bool tt128 = ECG_WG_TT128 && dma && Cout % 128 != 0 && ldy % 128 == 0 && ldy >= cdiv(Lo, 128) * 128;
+    if (wgrad_ffa_ok(Cin, Cout, dma)) {
+        const int S = wgrad_ffa_splits(N, Cin, Cout, Lo), m_t = Cout % 128 == 0 ? 128 : 64;
+        const int tiles = (2 * cdiv(Cin * 8, 128) + cdiv(Cin * 7, 128)) * (Cout / m_t);
+        dim3 fgrid((unsigned)(tiles * S)), fblock(256);
+        if (m_t == 128)
+            hipLaunchKernelGGL((conv1d_mfma_wgrad_ffa_kernel<128, 128, 2, 2, ECG_WG_FL, 64>), fgrid, fblock, 0, st, dy, x, ws, N, Cin,
+                               Cout, L, Lo, ldy, pad, S);
+        else
+            hipLaunchKernelGGL((conv1d_mfma_wgrad_ffa_kernel<64, 128, 2, 2, ECG_WG_FL, 64>), fgrid, fblock, 0, st, dy, x, ws, N, Cin,
+                               Cout, L, Lo, ldy, pad, S);
+        int frc = check_launch("conv1d_mfma_wgrad_ffa_kernel");
+        if (frc) return frc;
+        const size_t nout = (size_t)Cout * Cin * 15 + Cout;
+        const dim3 rgrid((unsigned)cdiv(nout, (size_t)64));
+        int G = 1;
+        while (G < 16 && (size_t)rgrid.x * G < 1024 && S / (2 * G) >= 8) G *= 2;
+#define ECG_FRED(GG) hipLaunchKernelGGL((wgrad_ffa_reduce_kernel<GG>), rgrid, dim3(64 * GG), 0, st, ws, dw, db, Cin, Cout, S)
+        switch (G) {
+            case 1: ECG_FRED(1); break;
+            case 2: ECG_FRED(2); break;
+            case 4: ECG_FRED(4); break;
+            case 8: ECG_FRED(8); break;
+            default: ECG_FRED(16); break;
+        }
+#undef ECG_FRED
+        return check_launch("wgrad_ffa_reduce_kernel");
+    }
     const WgCfg c = wgrad_cfg(N, Cin, Cout, Lo, dma, tt128 ? 128 : 64);
     dim3 grid((unsigned)(cdiv(R, c.r_t) * (Cout / c.m_t) * c.splits)), block(256);
 #define ECG_WG(KERNEL) \
