@@ -148,6 +148,63 @@ def test_conv_stats_epilogue_and_finalize(hip, oracle):
         np.testing.assert_allclose(host(invstd2), oinv, rtol=2e-5)
 
 
+@pytest.mark.parametrize("Co,Lin", [(64, 1), (64, 2), (64, 125), (64, 126), (64, 127), (64, 128), (64, 251), (64, 252), (64, 253),
+                                    (64, 379), (32, 253), (32, 254), (32, 255), (32, 256), (32, 509), (128, 130)])
+def test_conv_fast_fir_tile_edges(hip, oracle, Co, Lin):
+    """The training forward / input gradient split every output pair (2m, 2m + 1) into three half-rate products
+    (conv1d_mfma_ffa_kernel: 23 multiplies per pair; y[2m+1] needs the B product of column m + 1, so a tile of M columns
+    yields 2M - 2 outputs and tiles are 126 / 254 apart).  Row lengths around those strides, on smooth non-negative
+    activations (what the layers see) and on white noise: the plain epilogue (unfused forward, input gradient) and the
+    statistics epilogue against the oracle; the (sum, sum^2) partials must describe exactly the stored y."""
+    from ecg_hip import _lib as L
+    Ci, N = 32, 3
+    rng = np.random.default_rng(Co * 1000 + Lin)
+    smooth = np.maximum(np.cumsum(rng.standard_normal((N, Ci, Lin)), axis=2) * 0.3 + 0.5, 0).astype(np.float32)
+    noise = rng.standard_normal((N, Ci, Lin)).astype(np.float32)
+    w = (rng.standard_normal((Co, Ci, 15)) / np.sqrt(Ci * 15)).astype(np.float32)
+    b = rng.standard_normal(Co).astype(np.float32)
+    w_fwd, w_bwd = hip.conv1d_pack(dev(w))
+    for x in (smooth, noise):
+        ry = oracle.conv1d_fwd(x, w, b, 7)
+        tol = 3e-6 * max(1.0, float(np.abs(ry).max()))
+        y0, _, _ = hip.conv1d_forward_raw(dev(x), w_fwd, dev(b), Co, 15, 7, want_stats=False)
+        np.testing.assert_allclose(host(y0), ry, rtol=2e-5, atol=tol)
+        y, partials, P = hip.conv1d_forward_raw(dev(x), w_fwd, dev(b), Co, 15, 7, want_stats=True)
+        assert P == L.query("ecg_conv1d_fwd_stat_partials", N, Ci, Co, Lin, 15, 7)
+        np.testing.assert_array_equal(host(y), host(y0))                     # the two epilogues store the same values
+        part = host(partials).reshape(Co, P, 2).astype(np.float64)
+        yd = host(y).astype(np.float64)
+        np.testing.assert_allclose(part[:, :, 0].sum(1), yd.sum((0, 2)), rtol=1e-6, atol=1e-4)
+        np.testing.assert_allclose(part[:, :, 1].sum(1), (yd * yd).sum((0, 2)), rtol=1e-6, atol=1e-4)
+    dy = rng.standard_normal((N, Co, Lin)).astype(np.float32)
+    dx, _, _ = hip.conv1d_backward_raw(dev(noise), dev(dy), w.shape, w_bwd, 7, need_dx=True)
+    np.testing.assert_allclose(host(dx), oracle.conv1d_bwd_data(dy, w, Lin, 7), rtol=2e-5, atol=6e-5)
+
+
+@pytest.mark.parametrize("N,Co,Lin", [(1, 128, 1), (1, 128, 2), (2, 128, 63), (1, 256, 64), (3, 128, 65), (5, 256, 125), (2, 128, 129),
+                                      (40, 128, 33)])
+def test_conv_fast_fir_weight_grad_edges(hip, oracle, N, Co, Lin):
+    """128-channel layers take the transposed split for the weight gradient (conv1d_mfma_wgrad_ffa_kernel: column families
+    U / V / G, dW[2j] = U[j] - G[j], dW[2j+1] = V[j] + G[j+1]; V pairs dY[2m] with dY[2m-1] INSIDE a 64-step stage, whose
+    first and last pair are half empty).  Ragged rows, single stages, fewer stages than slabs; smooth non-negative x."""
+    from ecg_hip import _lib as L
+    Ci = 128
+    rng = np.random.default_rng(N * 100000 + Co * 100 + Lin)
+    x = np.maximum(np.cumsum(rng.standard_normal((N, Ci, Lin)), axis=2) * 0.3 + 0.5, 0).astype(np.float32)
+    dy = rng.standard_normal((N, Co, Lin)).astype(np.float32)
+    w = (rng.standard_normal((Co, Ci, 15)) / np.sqrt(Ci * 15)).astype(np.float32)
+    _, w_bwd = hip.conv1d_pack(dev(w))
+    ldy = L.query("ecg_conv1d_dy_row_stride", N, Ci, Co, Lin, 15, 7, 1)
+    assert ldy % 64 == 0 and ldy >= Lin
+    dyp = np.zeros((N, Co, ldy), np.float32)
+    dyp[:, :, :Lin] = dy
+    _, dw, db = hip.conv1d_backward_raw(dev(x), dev(dyp), w.shape, w_bwd, 7, need_dx=False, ldy=ldy)
+    rdw, rdb = oracle.conv1d_bwd_weight(dy, x, 15, 7)
+    tol = 2e-6 * np.sqrt(N * Lin) * max(1.0, float(np.abs(x).max())) + 3e-5
+    np.testing.assert_allclose(host(dw), rdw, rtol=2e-5, atol=tol)
+    np.testing.assert_allclose(host(db), rdb, rtol=2e-5, atol=tol)
+
+
 @pytest.mark.parametrize("shape", [(3, 32, 50), (2, 64, 33), (4, 256, 125), (2, 5, 1), (2, 7, 2), (1, 3, 1001)])
 @pytest.mark.parametrize("train", [True, False])
 def test_bn_relu_pool_fwd_bwd(hip, oracle, shape, train):
