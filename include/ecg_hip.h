@@ -105,6 +105,16 @@ int ecg_conv1d_bwd_data(const float *dy, const float *w_bwd, float *dx,
  * plain entry points are the ldy == Lo case.  need_dx: whether ecg_conv1d_bwd_data_ld will be called on
  * this dY too (not for the first layer) — the stride must then be one the input-gradient kernel reads. */
 int ecg_conv1d_dy_row_stride(int N, int C_in, int C_out, int L, int K, int pad, int need_dx);
+
+/* Multiplies the fp32 kernels issue per output PAIR (2m, 2m+1) and (c_in, c_out): 30 = the direct form (2 x 15 taps), 23 = the
+ * two-phase fast-FIR split (round 5): three half-rate products over the even / odd taps and samples, the third on DIFFERENCES
+ * (w[2j] - w[2j-1]) * (x[2m+2j] - x[2m+2j+1]) — exact for neighbouring samples of like sign and magnitude — combined in fp32 in
+ * the epilogue (forward, input gradient) or in the double-precision slab reduce (weight gradient).  Same operands, same
+ * results to a few ulp of the accumulated magnitude (tests/test_gpu_ops.py: error against float64 no larger than the CPU fp32
+ * path's); measurement code uses this to report the matrix-pipe utilisation beside the algorithmic rate.
+ * op: 0 = ecg_conv1d_fwd in training (statistics epilogue; the inference epilogues stay direct), 1 = ecg_conv1d_bwd_data[_ld]
+ * and ecg_conv1d_fwd without statistics, 2 = ecg_conv1d_bwd_weight_bias_ld on row-padded dY. */
+int ecg_conv1d_multiplies_per_output_pair(int op, int C_in, int C_out, int K, int pad);
 int ecg_conv1d_bwd_data_ld(const float *dy, int ldy, const float *w_bwd, float *dx,
                            int N, int C_in, int C_out, int L, int K, int pad, ecg_stream_t stream);
 int ecg_conv1d_bwd_weight_bias_ld(const float *dy, int ldy, const float *x, float *dw, float *db,

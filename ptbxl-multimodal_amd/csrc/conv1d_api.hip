@@ -26,6 +26,7 @@ bool mfma_fwd_eval_gap_supported(int Cin, int Cout, int L, int K, int pad);
 bool mfma_wgrad_supported(int Cin, int Cout, int K, int pad);
 size_t mfma_wgrad_ws_floats(int N, int Cin, int Cout, int L, int K, int pad);
 bool mfma_wgrad_dma_supported(int Cin, int Cout, int K);
+int mfma_multiplies_per_pair(int op, int Cin, int Cout, int K, int pad);
 int mfma_wgrad(const float *dy, int ldy, const float *x, float *dw, float *db, float *ws, int N,
                int Cin, int Cout, int L, int K, int pad, hipStream_t st);
 
@@ -106,6 +107,11 @@ ECG_API int ecg_conv1d_dy_row_stride(int N, int C_in, int C_out, int L, int K, i
     if (mfma_wgrad_dma_supported(C_in, C_out, K) && (!need_dx || mfma_fwd_supported(C_out, C_in, K, K - 1 - pad)))
         return cdiv(Lo, 64) * 64;
     return Lo;
+}
+
+ECG_API int ecg_conv1d_multiplies_per_output_pair(int op, int C_in, int C_out, int K, int pad) {
+    if (op < 0 || op > 2 || K < 1) return 0;
+    return mfma_multiplies_per_pair(op, C_in, C_out, K, pad);
 }
 
 // Input gradient = forward conv of dy with the tap-flipped, channel-transposed weights

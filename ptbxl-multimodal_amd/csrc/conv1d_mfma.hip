@@ -1697,6 +1697,14 @@ static int wgrad_ffa_splits(int N, int Cin, int Cout, int Lo) {
     return (int)s;
 }
 
+bool mfma_wgrad_dma_supported(int Cin, int Cout, int K);
+// what ecg_conv1d_multiplies_per_output_pair reports: mirrors the dispatch of launch_fwd / mfma_wgrad
+int mfma_multiplies_per_pair(int op, int Cin, int Cout, int K, int pad) {
+    if (op == 2) return (K == kKM && wgrad_ffa_ok(Cin, Cout, mfma_wgrad_dma_supported(Cin, Cout, K))) ? 23 : 2 * K;
+    const bool mfma = op == 0 ? mfma_fwd_supported(Cin, Cout, K, pad) : mfma_fwd_supported(Cout, Cin, K, K - 1 - pad);
+    return (mfma && (ECG_FWD_FFA & (op == 0 ? 1 : 2))) ? 23 : 2 * K;
+}
+
 bool mfma_wgrad_supported(int Cin, int Cout, int K, int pad) {
     (void)pad; (void)Cin;
     return K == kKM && Cout % 32 == 0;

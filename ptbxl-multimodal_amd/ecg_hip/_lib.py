@@ -35,6 +35,7 @@ SIGNATURES = {
     "ecg_conv1d_bwd_weight_ws_floats": (_sz, [_i, _i, _i, _i, _i, _i]),
     "ecg_conv1d_bwd_weight_bias": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "ecg_conv1d_dy_row_stride": (_i, [_i] * 7),
+    "ecg_conv1d_multiplies_per_output_pair": (_i, [_i] * 5),
     "ecg_conv1d_bwd_data_ld": (_i, [_vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "ecg_conv1d_bwd_weight_bias_ld": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "ecg_conv1d_bf16_supported": (_i, [_i, _i, _i, _i]),

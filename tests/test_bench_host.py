@@ -32,6 +32,10 @@ def test_layer_table_prices_entry_points_against_their_roofs(monkeypatch):
     assert f["algorithmic_flops"] == flops and f["calls"] == 2 and f["operands"] == "f32"
     assert abs(f["tflops"] - flops / 0.25e-3 / 1e12) < 0.01 and abs(f["frac"] - f["tflops"] / 157.3) < 1e-3
     assert f["algorithmic_bytes"] == 4.0 * 256 * 125 * (128 + 256) + 4.0 * 256 * 128 * 15
+    # the fast-FIR kernels issue 23 of the 30 multiplies per output pair: the matrix-pipe share is reported beside the algorithmic rate
+    assert f["multiplies_per_output_pair"] == 23 and abs(f["pipe_frac"] - f["frac"] * 23 / 30) < 1e-3
+    assert by["ecg_conv1d_fwd_bf16_yh"]["multiplies_per_output_pair"] == 30
+    assert bench.frac_by_block(rows, "pipe_frac")["fwd"][-1] in (f["pipe_frac"], by["ecg_conv1d_fwd_bf16_yh"]["pipe_frac"])
     assert f["traffic_bytes_from_profile"] == 65_000_000 and f["traffic_over_algorithmic"] == round(65e6 / f["algorithmic_bytes"], 3)
     # bf16 activation storage: two bytes per activation element on both sides, priced against the bf16 peak
     h = by["ecg_conv1d_fwd_bf16_yh"]
