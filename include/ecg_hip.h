@@ -112,8 +112,9 @@ int ecg_conv1d_dy_row_stride(int N, int C_in, int C_out, int L, int K, int pad, 
  * the epilogue (forward, input gradient) or in the double-precision slab reduce (weight gradient).  Same operands, same
  * results to a few ulp of the accumulated magnitude (tests/test_gpu_ops.py: error against float64 no larger than the CPU fp32
  * path's); measurement code uses this to report the matrix-pipe utilisation beside the algorithmic rate.
- * op: 0 = ecg_conv1d_fwd in training (statistics epilogue; the inference epilogues stay direct), 1 = ecg_conv1d_bwd_data[_ld]
- * and ecg_conv1d_fwd without statistics, 2 = ecg_conv1d_bwd_weight_bias_ld on row-padded dY. */
+ * op: 0 = ecg_conv1d_fwd with the statistics epilogue (training), 1 = ecg_conv1d_bwd_data[_ld] and ecg_conv1d_fwd without
+ * statistics, 2 = ecg_conv1d_bwd_weight_bias_ld on row-padded dY, 3 = the one-launch inference blocks
+ * (ecg_conv1d_bn_relu_pool[_gap]_eval_fwd). */
 int ecg_conv1d_multiplies_per_output_pair(int op, int C_in, int C_out, int K, int pad);
 int ecg_conv1d_bwd_data_ld(const float *dy, int ldy, const float *w_bwd, float *dx,
                            int N, int C_in, int C_out, int L, int K, int pad, ecg_stream_t stream);
@@ -300,8 +301,8 @@ int ecg_conv1d_bn_relu_pool_eval_fwd(const float *x, const float *w_fwd, const f
                                      int K, int pad, ecg_stream_t stream);
 /* The same with the global average pool behind it (last block of the backbone): g [N][C_out] =
  * mean_j max(0, max(a[2j], a[2j+1])), nothing else is written.  Covered when the conv output row fits
- * one time tile of the kernel (Lo <= 128 for C_out % 64 == 0: 12x1000 windows; longer windows use
- * ecg_conv1d_fwd + ecg_bn_relu_pool_gap_fwd). */
+ * one time tile of the kernel (Lo <= 126 for C_out % 64 == 0, <= 254 otherwise — the tile distance of the fast-FIR kernel:
+ * 12x1000 windows end at 125; longer windows use ecg_conv1d_fwd + ecg_bn_relu_pool_gap_fwd). */
 int ecg_conv1d_bn_relu_pool_gap_eval_supported(int C_in, int C_out, int L, int K, int pad);
 int ecg_conv1d_bn_relu_pool_gap_eval_fwd(const float *x, const float *w_fwd, const float *bias,
                                          const float *gamma, const float *beta,

@@ -110,7 +110,7 @@ ECG_API int ecg_conv1d_dy_row_stride(int N, int C_in, int C_out, int L, int K, i
 }
 
 ECG_API int ecg_conv1d_multiplies_per_output_pair(int op, int C_in, int C_out, int K, int pad) {
-    if (op < 0 || op > 2 || K < 1) return 0;
+    if (op < 0 || op > 3 || K < 1) return 0;
     return mfma_multiplies_per_pair(op, C_in, C_out, K, pad);
 }
 

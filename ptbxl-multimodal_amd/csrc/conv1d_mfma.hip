@@ -407,7 +407,7 @@ __global__ __launch_bounds__(256, 2) void conv1d_mfma_fwd_kernel(
 }
 
 // ---------------------------------------------------------------------------------------
-// Forward / input gradient by a two-phase fast-FIR split (training epilogues: EPI_PLAIN, EPI_STATS).
+// Forward / input gradient by a two-phase fast-FIR split (all four epilogues of the kernel above).
 // The kernels above are bound by the fp32 matrix pipe (0.76-0.84 of its nominal peak at the clocks the chip holds), so the
 // only way down is fewer MFMAs.  With xt[p] = x[t0 - pad + p] and output column m of the tile <-> outputs t0 + 2m, t0 + 2m + 1:
 //     A[m] = sum_{j=0..7} w[2j]             * xt[2m + 2j]
@@ -422,7 +422,8 @@ __global__ __launch_bounds__(256, 2) void conv1d_mfma_fwd_kernel(
 // TS = 2 M_T - 2 apart (column M_T - 1 only supplies B); for the model's row lengths that is the same number of tiles as
 // 2 M_T-wide ones.  In the epilogue B goes through LDS once (the images are dead) to come back shifted by a column.
 // Rounding: the two extra adds per product and the final combination are fp32; the result differs from the direct form by
-// a few ulp of the accumulated magnitude (tests state the bound) — inference keeps the direct kernel.
+// a few ulp of the accumulated magnitude (tests state the bound).  Inference epilogues: the pooling pair (2m, 2m + 1) sits in ONE
+// lane, so BatchNorm + ReLU + MaxPool(2) is three VALU operations per pair and the pooled row leaves as contiguous dwords.
 #ifndef ECG_FFA_MINB
 #define ECG_FFA_MINB 2
 #endif
@@ -430,9 +431,9 @@ template <int CO_T, int M_T, int WCO, int WT, int EPI>
 __global__ __launch_bounds__(256, ECG_FFA_MINB) void conv1d_mfma_ffa_kernel(
     const float *__restrict__ x, const float *__restrict__ wp, const float *__restrict__ bias,
     float *__restrict__ y, float *__restrict__ partials, int Cin, int Cout, int L, int ldx, int Lo,
-    int pad, int P, int tiles_t) {
-    constexpr bool STATS = (EPI == EPI_STATS);
-    static_assert(EPI == EPI_STATS || EPI == EPI_PLAIN, "training epilogues only");
+    int pad, int P, int tiles_t, EvalEpi ev) {
+    constexpr bool STATS = (EPI == EPI_STATS), GAP = (EPI == EPI_EVAL_GAP);
+    constexpr bool EVALM = (EPI == EPI_EVAL || EPI == EPI_EVAL_GAP);
     static_assert(WCO * WT == 4, "4 waves per workgroup");
     static_assert(kKM == 15, "tap split 8 + 7");
     static_assert(CO_T / WCO == 32 && M_T / WT == 32, "one 32 x 32 accumulator per product and wave");
@@ -447,7 +448,7 @@ __global__ __launch_bounds__(256, ECG_FFA_MINB) void conv1d_mfma_ffa_kernel(
     constexpr int XLOADS = (XEL + 255) / 256;
     constexpr int IMG = WPAD + XEL;
     constexpr int BXS = M_T + 1;                 // row stride of the B exchange (odd: conflict-free column walks)
-    constexpr int REDF = STATS ? 4 * 32 * 2 : 0;
+    constexpr int REDF = (STATS || GAP) ? 4 * 32 * 2 : 0;
     static_assert(CO_T * BXS + REDF <= 2 * IMG, "B exchange + stat scratch alias the dead images");
     static_assert(NST >= 2 * XLOADS + DPW, "not enough steps to spread the staging over");
 
@@ -471,7 +472,13 @@ __global__ __launch_bounds__(256, ECG_FFA_MINB) void conv1d_mfma_ffa_kernel(
 #pragma unroll
     for (int a = 0; a < 3; ++a) { acc[a] = zero16; acc2[a] = zero16; }
 
-    const float p_b = bias ? bias[co0 + wco + acc_row(l31 & 15, half)] : 0.f;
+    const int pch = co0 + wco + acc_row(l31 & 15, half);      // lane-indexed epilogue parameters (see the kernel above)
+    const float p_b = bias ? bias[pch] : 0.f;
+    float p_mu = 0.f, p_sc = 0.f, p_be = 0.f;
+    if (EVALM) {
+        const float is = (float)(1.0 / sqrt((double)ev.var[pch] + (double)ev.eps));
+        p_sc = is * ev.gamma[pch]; p_mu = ev.mean[pch]; p_be = ev.beta[pch];
+    }
 
     int woff[DPW];
 #pragma unroll
@@ -599,7 +606,10 @@ __global__ __launch_bounds__(256, ECG_FFA_MINB) void conv1d_mfma_ffa_kernel(
     float st_s = 0.f, st_q = 0.f;
     const int m = wm + l31, t = t0 + 2 * m;
     const bool ok0 = m < M_T - 1 && t < Lo, ok1 = m < M_T - 1 && t + 1 < Lo;
-    float *yw = y + ((size_t)n * Cout + co0 + wco + 4 * half) * Lo + t;
+    const int Lp = Lo >> 1, pm = (t0 >> 1) + m;               // (t0 is even: the pair (t, t + 1) is pooled output pm)
+    const bool okp = m < M_T - 1 && pm < Lp;
+    float *yw = EVALM ? y + ((size_t)n * Cout + co0 + wco + 4 * half) * Lp + pm
+                      : y + ((size_t)n * Cout + co0 + wco + 4 * half) * Lo + t;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int rowk = (r & 3) + 8 * (r >> 2);
@@ -607,6 +617,15 @@ __global__ __launch_bounds__(256, ECG_FFA_MINB) void conv1d_mfma_ffa_kernel(
         const float v0 = (acc[0][r] + acc[1][r]) + bv;
         const float v1 = (ECG_FFA_MINUS ? (acc[0][r] + bn[r]) - acc[2][r] : (acc[2][r] - acc[0][r]) - bn[r]) + bv;
         float s = 0.f, q = 0.f;
+        if (EVALM) {
+            const float mu = pick(p_mu, r), sc = pick(p_sc, r), be = pick(p_be, r);
+            const float mx = fmaxf(fmaxf(bn_apply1(v0, mu, sc, be), bn_apply1(v1, mu, sc, be)), 0.f);
+            if (GAP) {
+                s = row16_sum(okp ? mx : 0.f);
+                st_s += ((l31 & 15) == r) ? s : 0.f;
+            } else if (okp) yw[rowk * Lp] = mx;
+            continue;
+        }
         // (the pair is 4-byte aligned only: odd row lengths; gfx950 global stores do not need more)
         typedef float f32x2u __attribute__((ext_vector_type(2), aligned(4)));
         if (ok1) { f32x2u v; v[0] = v0; v[1] = v1; *reinterpret_cast<f32x2u *>(yw + rowk * Lo) = v; }
@@ -623,7 +642,7 @@ __global__ __launch_bounds__(256, ECG_FFA_MINB) void conv1d_mfma_ffa_kernel(
             st_q += mine ? q : 0.f;
         }
     }
-    if (STATS) {
+    if (STATS || GAP) {
         const float s = st_s + __shfl_xor(st_s, 16, 64);
         const float q = st_q + __shfl_xor(st_q, 16, 64);
         if (l31 < 16) {
@@ -632,6 +651,17 @@ __global__ __launch_bounds__(256, ECG_FFA_MINB) void conv1d_mfma_ffa_kernel(
             red[(wave * 32 + lc) * 2 + 1] = q;
         }
         __syncthreads();
+    }
+    if (GAP) {       // global average pool: combine the WT waves of each channel row, divide by the pooled length
+        for (int col = tid; col < CO_T; col += 256) {
+            const int wrow = col / 32, lc = col - wrow * 32;
+            float g = 0.f;
+#pragma unroll
+            for (int j = 0; j < WT; ++j) g += red[((wrow * WT + j) * 32 + lc) * 2];
+            y[(size_t)n * Cout + co0 + col] = g / (float)Lp;
+        }
+    }
+    if (STATS) {
         for (int e = tid; e < CO_T * 2; e += 256) {
             const int col = e >> 1, w = e & 1;
             const int wrow = col / 32, lc = col - wrow * 32;
@@ -646,15 +676,15 @@ __global__ __launch_bounds__(256, ECG_FFA_MINB) void conv1d_mfma_ffa_kernel(
 
 struct FwdCfg { int co_t, t_t, stride; bool ffa; };     // stride: distance of the t tiles (ffa: t_t - 2)
 #ifndef ECG_FWD_FFA
-#define ECG_FWD_FFA 3       // bit 0: forward (statistics epilogue), bit 1: plain epilogue (input gradient, unfused forward)
-#endif
+#define ECG_FWD_FFA 7       // bit 0: forward (statistics epilogue), bit 1: plain epilogue (input gradient, unfused forward),
+#endif                      // bit 2: the inference epilogues
 
 // Tile choice of the one-tile-per-workgroup kernel (inference epilogues).  Measured on MI355X (B=256): 64x128
 // tiles at 4 resident workgroups per CU beat 128x128 at 2 per CU by 6-8 % (more independent waves per SIMD to
 // cover each other's prologue, epilogue and staging waits), so the 64-channel tile is used whenever C_out allows it.
 static FwdCfg fwd_cfg(int N, int Cout, int Lo, bool train) {
     (void)N; (void)Lo;
-    const bool ffa = train && (ECG_FWD_FFA & 1);         // (the statistics partials: forward with the training epilogue)
+    const bool ffa = train ? (ECG_FWD_FFA & 1) != 0 : (ECG_FWD_FFA & 4) != 0;   // (callers: statistics partials | one-tile GAP)
     if (Cout % 64 == 0) return {64, 128, ffa ? 126 : 128, ffa};
     return {32, 256, ffa ? 254 : 256, ffa};
 }
@@ -673,16 +703,19 @@ template <int CO_T, int T_T, int WCO, int WT>
 static void launch_fwd(const float *x, const float *wp, const float *bias, float *y,
                        float *partials, const EvalEpi *ev, int N, int Cin, int Cout, int L, int ldx,
                        int Lo, int pad, hipStream_t st) {
-    if (!ev && (((ECG_FWD_FFA & 1) && partials) || ((ECG_FWD_FFA & 2) && !partials))) {
+    if (ev ? (ECG_FWD_FFA & 4) != 0 : (((ECG_FWD_FFA & 1) && partials) || ((ECG_FWD_FFA & 2) && !partials))) {
         const int tiles_t = cdiv(Lo, T_T - 2);
         dim3 grid((unsigned)((size_t)tiles_t * (Cout / CO_T) * N)), block(256);
         const int P = N * tiles_t;
-        if (partials)
-            hipLaunchKernelGGL((conv1d_mfma_ffa_kernel<CO_T, T_T / 2, WCO, WT, EPI_STATS>), grid, block, 0, st, x, wp, bias, y,
-                               partials, Cin, Cout, L, ldx, Lo, pad, P, tiles_t);
-        else
-            hipLaunchKernelGGL((conv1d_mfma_ffa_kernel<CO_T, T_T / 2, WCO, WT, EPI_PLAIN>), grid, block, 0, st, x, wp, bias, y,
-                               partials, Cin, Cout, L, ldx, Lo, pad, P, tiles_t);
+        const EvalEpi none{nullptr, nullptr, nullptr, nullptr, 0.f, 0};
+#define ECG_FFA(MODE, EV) \
+        hipLaunchKernelGGL((conv1d_mfma_ffa_kernel<CO_T, T_T / 2, WCO, WT, MODE>), grid, block, 0, st, x, wp, bias, y, \
+                           partials, Cin, Cout, L, ldx, Lo, pad, P, tiles_t, EV)
+        if (ev && ev->gap) ECG_FFA(EPI_EVAL_GAP, *ev);
+        else if (ev) ECG_FFA(EPI_EVAL, *ev);
+        else if (partials) ECG_FFA(EPI_STATS, none);
+        else ECG_FFA(EPI_PLAIN, none);
+#undef ECG_FFA
         return;
     }
     const int tiles_t = cdiv(Lo, T_T);
@@ -729,7 +762,7 @@ int mfma_fwd_eval_pool(const float *x, const float *wp, const float *bias, const
 
 bool mfma_fwd_eval_gap_supported(int Cin, int Cout, int L, int K, int pad) {
     const int Lo = L + 2 * pad - K + 1;
-    return mfma_fwd_supported(Cin, Cout, K, pad) && Lo >= 2 && Lo <= fwd_cfg(1, Cout, Lo, false).t_t;
+    return mfma_fwd_supported(Cin, Cout, K, pad) && Lo >= 2 && Lo <= fwd_cfg(1, Cout, Lo, false).stride;
 }
 
 // =======================================================================================
@@ -1701,8 +1734,8 @@ bool mfma_wgrad_dma_supported(int Cin, int Cout, int K);
 // what ecg_conv1d_multiplies_per_output_pair reports: mirrors the dispatch of launch_fwd / mfma_wgrad
 int mfma_multiplies_per_pair(int op, int Cin, int Cout, int K, int pad) {
     if (op == 2) return (K == kKM && wgrad_ffa_ok(Cin, Cout, mfma_wgrad_dma_supported(Cin, Cout, K))) ? 23 : 2 * K;
-    const bool mfma = op == 0 ? mfma_fwd_supported(Cin, Cout, K, pad) : mfma_fwd_supported(Cout, Cin, K, K - 1 - pad);
-    return (mfma && (ECG_FWD_FFA & (op == 0 ? 1 : 2))) ? 23 : 2 * K;
+    const bool mfma = op == 1 ? mfma_fwd_supported(Cout, Cin, K, K - 1 - pad) : mfma_fwd_supported(Cin, Cout, K, pad);
+    return (mfma && (ECG_FWD_FFA & (op == 0 ? 1 : (op == 1 ? 2 : 4)))) ? 23 : 2 * K;
 }
 
 bool mfma_wgrad_supported(int Cin, int Cout, int K, int pad) {

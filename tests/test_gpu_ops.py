@@ -742,7 +742,9 @@ def test_return_features_and_feature_gradient(hip, oracle):
         np.testing.assert_allclose(host(a.grad), b.grad.numpy(), atol=tol, err_msg=k)
 
 
-@pytest.mark.parametrize("shape", [(3, 12, 32, 300), (2, 32, 64, 257), (2, 64, 128, 125), (1, 128, 256, 33)])
+@pytest.mark.parametrize("shape", [(3, 12, 32, 300), (2, 32, 64, 257), (2, 64, 128, 125), (1, 128, 256, 33),
+                                   # rows around the tile distance of the fast-FIR kernel (126 / 254 outputs), odd lengths (MaxPool drops the last sample)
+                                   (2, 32, 64, 126), (2, 32, 64, 127), (2, 32, 64, 253), (3, 12, 32, 254), (3, 12, 32, 255), (2, 12, 32, 509)])
 def test_eval_fused_conv_bn_relu_pool(hip, oracle, shape):
     """Inference ConvBlock in one launch (BN folded into the conv epilogue) vs the oracle sequence."""
     from ecg_hip import _lib as L
@@ -767,7 +769,7 @@ def test_eval_fused_conv_bn_relu_pool(hip, oracle, shape):
     assert L.query("ecg_conv1d_bn_relu_pool_eval_supported", 7, 5, 3, 1) == 0
 
 
-@pytest.mark.parametrize("shape", [(3, 128, 256, 125), (2, 64, 128, 128), (5, 32, 64, 33), (2, 12, 32, 256), (1, 128, 256, 2)])
+@pytest.mark.parametrize("shape", [(3, 128, 256, 125), (2, 64, 128, 126), (5, 32, 64, 33), (2, 12, 32, 254), (1, 128, 256, 2), (2, 12, 32, 253)])
 def test_eval_fused_conv_bn_relu_pool_gap(hip, oracle, shape):
     """Last block at inference: conv + running-stat BN + ReLU + MaxPool + global average pool in ONE launch."""
     from ecg_hip import _lib as L
@@ -790,9 +792,10 @@ def test_eval_fused_conv_bn_relu_pool_gap(hip, oracle, shape):
     invstd = (1.0 / np.sqrt(rvar.astype(np.float64) + 1e-5)).astype(np.float32)
     rp = oracle.bn_relu_pool_fwd(y, gamma, beta, rmean, invstd)
     np.testing.assert_allclose(host(g), rp.astype(np.float64).mean(axis=2), atol=3e-5)
-    # rows longer than one time tile are not covered: callers fall back to conv + gap kernel
+    # rows longer than one time tile (126 outputs at 64-channel tiles, 254 at 32) are not covered: callers fall back to conv + gap kernel
     assert L.query("ecg_conv1d_bn_relu_pool_gap_eval_supported", 128, 256, 625, 15, 7) == 0
-    assert L.query("ecg_conv1d_bn_relu_pool_gap_eval_supported", 12, 32, 257, 15, 7) == 0
+    assert L.query("ecg_conv1d_bn_relu_pool_gap_eval_supported", 12, 32, 255, 15, 7) == 0
+    assert L.query("ecg_conv1d_bn_relu_pool_gap_eval_supported", 64, 128, 127, 15, 7) == 0
     with pytest.raises(L.EcgHipError, match="not covered"):
         L.call("ecg_conv1d_bn_relu_pool_gap_eval_fwd", L.f32(args[0]), L.f32(w_fwd), *map(L.f32, args[1:]), 1e-5, L.f32(g),
                N, Ci, Co, 1000, 15, 7, L.stream())
