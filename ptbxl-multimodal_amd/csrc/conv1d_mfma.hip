@@ -427,7 +427,7 @@ __global__ __launch_bounds__(256, 2) void conv1d_mfma_fwd_kernel(
 #ifndef ECG_FFA_MINB
 #define ECG_FFA_MINB 2
 #endif
-template <int CO_T, int M_T, int WCO, int WT, int EPI>
+template <int CO_T, int M_T, int WCO, int WT, int EPI, int CI_C = 4>
 __global__ __launch_bounds__(256, ECG_FFA_MINB) void conv1d_mfma_ffa_kernel(
     const float *__restrict__ x, const float *__restrict__ wp, const float *__restrict__ bias,
     float *__restrict__ y, float *__restrict__ partials, int Cin, int Cout, int L, int ldx, int Lo,
@@ -437,7 +437,7 @@ __global__ __launch_bounds__(256, ECG_FFA_MINB) void conv1d_mfma_ffa_kernel(
     static_assert(WCO * WT == 4, "4 waves per workgroup");
     static_assert(kKM == 15, "tap split 8 + 7");
     static_assert(CO_T / WCO == 32 && M_T / WT == 32, "one 32 x 32 accumulator per product and wave");
-    constexpr int KK = kKM, CI_C = 4, NJ = (KK + 1) / 2, NST = NJ * (CI_C / 2);
+    constexpr int KK = kKM, NJ = (KK + 1) / 2, NST = NJ * (CI_C / 2);
     constexpr int T_T = 2 * M_T, TS = T_T - 2;
     constexpr int XS = T_T + 16;                 // x-tile row stride (span 2 (M_T - 1) + 16), even: the b64 reads stay aligned
     constexpr int WSZ = KK * CI_C * CO_T;
@@ -708,9 +708,21 @@ static void launch_fwd(const float *x, const float *wp, const float *bias, float
         dim3 grid((unsigned)((size_t)tiles_t * (Cout / CO_T) * N)), block(256);
         const int P = N * tiles_t;
         const EvalEpi none{nullptr, nullptr, nullptr, nullptr, 0.f, 0};
-#define ECG_FFA(MODE, EV) \
-        hipLaunchKernelGGL((conv1d_mfma_ffa_kernel<CO_T, T_T / 2, WCO, WT, MODE>), grid, block, 0, st, x, wp, bias, y, \
-                           partials, Cin, Cout, L, ldx, Lo, pad, P, tiles_t, EV)
+        // Chunks of EIGHT input channels where the reduction is long (C_in >= 64, 64-channel tiles): one barrier and one
+        // second-level add per 92 MFMAs instead of 46 — first-level chains of 64 instead of 32 terms, half as many second-level
+        // adds: the same error budget (tools/wgrad_error.py) — at two instead of three workgroups per CU (70 KB of LDS).
+        // Same box: 128 channels 236.5 -> 227.2 / 219.6 -> 208.8 us (forward / input gradient), 64: 125.2 -> 124.5 / 116.8 -> 113.1,
+        // 32: 69.4 -> 69.8 (stays at four).
+#ifndef ECG_FFA_CIC
+#define ECG_FFA_CIC 8
+#endif
+#define ECG_FFA(MODE, EV) do { \
+        if (ECG_FFA_CIC == 8 && CO_T == 64 && Cin % 8 == 0 && Cin >= 64) \
+            hipLaunchKernelGGL((conv1d_mfma_ffa_kernel<CO_T, T_T / 2, WCO, WT, MODE, (CO_T == 64 ? 8 : 4)>), grid, block, 0, st, x, wp, \
+                               bias, y, partials, Cin, Cout, L, ldx, Lo, pad, P, tiles_t, EV); \
+        else \
+            hipLaunchKernelGGL((conv1d_mfma_ffa_kernel<CO_T, T_T / 2, WCO, WT, MODE>), grid, block, 0, st, x, wp, bias, y, \
+                               partials, Cin, Cout, L, ldx, Lo, pad, P, tiles_t, EV); } while (0)
         if (ev && ev->gap) ECG_FFA(EPI_EVAL_GAP, *ev);
         else if (ev) ECG_FFA(EPI_EVAL, *ev);
         else if (partials) ECG_FFA(EPI_STATS, none);
