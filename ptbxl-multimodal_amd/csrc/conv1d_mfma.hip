@@ -1630,49 +1630,57 @@ __global__ __launch_bounds__(256, 2) void conv1d_mfma_wgrad_ffa_kernel(
     }
 }
 
-// dw[co][ci][k] from the S slabs of the kernel above (double sums in slab order; wave w of a workgroup takes slabs w, w + G, ...);
-// the bias row behind them as in wgrad_reduce_kernel
-template <int G>
-__global__ __launch_bounds__(64 * G) void wgrad_ffa_reduce_kernel(const float *__restrict__ slab, float *__restrict__ dw,
-                                                                  float *__restrict__ db, int Cin, int Cout, int S) {
-    __shared__ double part[G][64][2];
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+// dw[co][ci][k] from the S slabs of the kernel above: one lane per (co, ci, tap pair j) forms dW[2j] = U[j] - G[j] and
+// dW[2j+1] = V[j] + G[j+1] (double sums in slab order; four slabs = sixteen loads in flight per lane); the bias row behind them
+// as in wgrad_reduce_kernel.  One wave per workgroup: the layers that take this form have >= 2 048 of them.
+__global__ __launch_bounds__(64) void wgrad_ffa_reduce_kernel(const float *__restrict__ slab, float *__restrict__ dw,
+                                                              float *__restrict__ db, int Cin, int Cout, int S) {
+    constexpr int G = 1, w = 0;
+    const int lane = threadIdx.x;
     const size_t i = (size_t)blockIdx.x * 64 + lane;
-    const size_t nout = (size_t)Cout * Cin * 15, RVT = (size_t)Cin * 23, wslab = (size_t)Cout * RVT;
-    const bool live = i < nout + Cout && (i < nout || db);
-    double a = 0.0, g = 0.0;
-    bool odd = false;
+    const size_t npair = (size_t)Cout * Cin * 8, RVT = (size_t)Cin * 23, wslab = (size_t)Cout * RVT;
+    const bool live = i < npair + Cout && (i < npair || db);
+    double a[4] = {0.0, 0.0, 0.0, 0.0};            // U[j], G[j], V[j], G[j+1]  |  bias
+    int j = 0;
+    size_t o = 0;
     if (live) {
-        if (i < nout) {
-            const int co = (int)(i / ((size_t)Cin * 15)), rem = (int)(i - (size_t)co * Cin * 15);
-            const int ci = rem / 15, k = rem - ci * 15, j = k >> 1;
-            odd = k & 1;
-            const float *pa = slab + (size_t)co * RVT + (odd ? Cin * 8 + ci * 7 + j : ci * 8 + j);
-            const float *pg = slab + (size_t)co * RVT + Cin * 15 + ci * 8 + j + (odd ? 1 : 0);
+        if (i < npair) {
+            const int co = (int)(i / ((size_t)Cin * 8)), rem = (int)(i - (size_t)co * Cin * 8);
+            const int ci = rem >> 3;
+            j = rem & 7;
+            o = ((size_t)co * Cin + ci) * 15 + 2 * j;
+            const int jv = j < 7 ? j : 6;           // (tap 15 does not exist: the lane of j = 7 re-reads valid columns and drops them)
+            const float *pu = slab + (size_t)co * RVT + ci * 8 + j;
+            const float *pg = slab + (size_t)co * RVT + Cin * 15 + ci * 8 + j;
+            const float *pv = slab + (size_t)co * RVT + Cin * 8 + ci * 7 + jv;
+            const int g1 = j < 7 ? 1 : 0;
             int s = w;
             for (; s + 3 * G < S; s += 4 * G) {
-                float va[4], vg[4];
+                float v[4][4];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) { va[u] = pa[(size_t)(s + u * G) * wslab]; vg[u] = pg[(size_t)(s + u * G) * wslab]; }
+                for (int u = 0; u < 4; ++u) {
+                    const size_t off = (size_t)(s + u * G) * wslab;
+                    v[u][0] = pu[off]; v[u][1] = pg[off]; v[u][2] = pv[off]; v[u][3] = pg[off + g1];
+                }
 #pragma unroll
-                for (int u = 0; u < 4; ++u) { a += (double)va[u]; g += (double)vg[u]; }
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) a[e] += (double)v[u][e];
             }
-            for (; s < S; s += G) { a += (double)pa[(size_t)s * wslab]; g += (double)pg[(size_t)s * wslab]; }
+            for (; s < S; s += G) {
+                const size_t off = (size_t)s * wslab;
+                a[0] += (double)pu[off]; a[1] += (double)pg[off]; a[2] += (double)pv[off]; a[3] += (double)pg[off + g1];
+            }
         } else {
-            const float *src = slab + (size_t)S * wslab + (i - nout);
-            for (int s = w; s < S; s += G) a += (double)src[(size_t)s * Cout];
+            const float *src = slab + (size_t)S * wslab + (i - npair);
+            for (int s = w; s < S; s += G) a[0] += (double)src[(size_t)s * Cout];
         }
     }
-    if (G > 1) {
-        part[w][lane][0] = a; part[w][lane][1] = g;
-        __syncthreads();
-        if (w != 0) return;
-#pragma unroll
-        for (int q = 1; q < G; ++q) { a += part[q][lane][0]; g += part[q][lane][1]; }
-    }
     if (live) {
-        if (i < nout) dw[i] = (float)(odd ? a + g : a - g);
-        else db[i - nout] = (float)a;
+        if (i < npair) {
+            dw[o] = (float)(a[0] - a[1]);
+            if (j < 7) dw[o + 1] = (float)(a[2] + a[3]);
+        } else db[i - npair] = (float)a[0];
     }
 }
 
@@ -1792,19 +1800,9 @@ int mfma_wgrad(const float *dy, int ldy, const float *x, float *dw, float *db, f
                                Cout, L, Lo, ldy, pad, S);
         int frc = check_launch("conv1d_mfma_wgrad_ffa_kernel");
         if (frc) return frc;
-        const size_t nout = (size_t)Cout * Cin * 15 + Cout;
+        const size_t nout = (size_t)Cout * Cin * 8 + Cout;          // one lane per (co, ci, tap pair) + the bias row
         const dim3 rgrid((unsigned)cdiv(nout, (size_t)64));
-        int G = 1;
-        while (G < 16 && (size_t)rgrid.x * G < 1024 && S / (2 * G) >= 8) G *= 2;
-#define ECG_FRED(GG) hipLaunchKernelGGL((wgrad_ffa_reduce_kernel<GG>), rgrid, dim3(64 * GG), 0, st, ws, dw, db, Cin, Cout, S)
-        switch (G) {
-            case 1: ECG_FRED(1); break;
-            case 2: ECG_FRED(2); break;
-            case 4: ECG_FRED(4); break;
-            case 8: ECG_FRED(8); break;
-            default: ECG_FRED(16); break;
-        }
-#undef ECG_FRED
+        hipLaunchKernelGGL(wgrad_ffa_reduce_kernel, rgrid, dim3(64), 0, st, ws, dw, db, Cin, Cout, S);
         return check_launch("wgrad_ffa_reduce_kernel");
     }
     const WgCfg c = wgrad_cfg(N, Cin, Cout, Lo, dma, tt128 ? 128 : 64);
