@@ -412,17 +412,21 @@ __global__ __launch_bounds__(256, 2) void conv1d_mfma_fwd_kernel(
 // only way down is fewer MFMAs.  With xt[p] = x[t0 - pad + p] and output column m of the tile <-> outputs t0 + 2m, t0 + 2m + 1:
 //     A[m] = sum_{j=0..7} w[2j]             * xt[2m + 2j]
 //     B[m] = sum_{j=0..6} w[2j+1]           * xt[2m + 2j + 1]
-//     C[m] = sum_{j=0..7} (w[2j] + w[2j-1]) * (xt[2m + 2j] + xt[2m + 2j + 1])          (w[-1] = 0)
-//     y[t0 + 2m] = A[m] + B[m],     y[t0 + 2m + 1] = C[m] - A[m] - B[m + 1]
-// i.e. 23 multiplies per output pair instead of 30: three 32 x 32 accumulators (A, B, C) over M_T = T/2 columns take 46 MFMAs
-// per chunk of four input channels where the direct form takes 60.  Nothing is pre-processed: the LDS images are the ones of
+//     D[m] = sum_{j=0..7} (w[2j] - w[2j-1]) * (xt[2m + 2j] - xt[2m + 2j + 1])          (w[-1] = 0)
+//     y[t0 + 2m] = A[m] + B[m],     y[t0 + 2m + 1] = A[m] + B[m + 1] - D[m]
+// i.e. 23 multiplies per output pair instead of 30: three 32 x 32 accumulators (A, B, D) over M_T = T/2 columns take 46 MFMAs
+// per chunk of four input channels where the direct form takes 60.  The third product on DIFFERENCES, not on the textbook's sums
+// ((w[2j] + w[2j-1]) (x.. + x..), y_odd = C - A - B'; ECG_FFA_MINUS = 0 builds it for A/B): neighbouring samples of like sign and
+// magnitude — pooled ReLU outputs — subtract exactly and D is small, where C is twice the size of A and every odd output a
+// difference of large sums (trajectory drift against float64 1.62x the CPU fp32 path's with C, 0.41x with D: EXPERIMENTS I5).
+// Nothing is pre-processed: the LDS images are the ones of
 // the kernel above ({weights [K][4][CO_T] | x tile [4][2 M_T + 16]}); one ds_read_b64 per lane yields (xt[2m+2j], xt[2m+2j+1])
-// for the A, B and C step of tap pair j (conflict-free: 32 lanes x 8 bytes), the two sums are one VALU add each.
+// for the A, B and D step of tap pair j (conflict-free: 32 lanes x 8 bytes), the two differences are one VALU operation each.
 // B[m + 1] of the tile's last column belongs to the next tile, so a tile of M_T columns yields 2 M_T - 2 outputs: tiles are
 // TS = 2 M_T - 2 apart (column M_T - 1 only supplies B); for the model's row lengths that is the same number of tiles as
 // 2 M_T-wide ones.  In the epilogue B goes through LDS once (the images are dead) to come back shifted by a column.
-// Rounding: the two extra adds per product and the final combination are fp32; the result differs from the direct form by
-// a few ulp of the accumulated magnitude (tests state the bound).  Inference epilogues: the pooling pair (2m, 2m + 1) sits in ONE
+// Rounding: the two extra subtractions per product and the final combination are fp32; the result differs from the direct form
+// by a few ulp of the accumulated magnitude (tests state the bounds: test_conv_fast_fir_error_by_signal_class).  Inference epilogues: the pooling pair (2m, 2m + 1) sits in ONE
 // lane, so BatchNorm + ReLU + MaxPool(2) is three VALU operations per pair and the pooled row leaves as contiguous dwords.
 #ifndef ECG_FFA_MINB
 #define ECG_FFA_MINB 2
@@ -674,7 +678,7 @@ __global__ __launch_bounds__(256, ECG_FFA_MINB) void conv1d_mfma_ffa_kernel(
     }
 }
 
-struct FwdCfg { int co_t, t_t, stride; bool ffa; };     // stride: distance of the t tiles (ffa: t_t - 2)
+struct FwdCfg { int co_t, t_t, stride; };     // stride: distance of the t tiles (fast-FIR kernel: t_t - 2)
 #ifndef ECG_FWD_FFA
 #define ECG_FWD_FFA 7       // bit 0: forward (statistics epilogue), bit 1: plain epilogue (input gradient, unfused forward),
 #endif                      // bit 2: the inference epilogues
@@ -685,8 +689,8 @@ struct FwdCfg { int co_t, t_t, stride; bool ffa; };     // stride: distance of t
 static FwdCfg fwd_cfg(int N, int Cout, int Lo, bool train) {
     (void)N; (void)Lo;
     const bool ffa = train ? (ECG_FWD_FFA & 1) != 0 : (ECG_FWD_FFA & 4) != 0;   // (callers: statistics partials | one-tile GAP)
-    if (Cout % 64 == 0) return {64, 128, ffa ? 126 : 128, ffa};
-    return {32, 256, ffa ? 254 : 256, ffa};
+    if (Cout % 64 == 0) return {64, 128, ffa ? 126 : 128};
+    return {32, 256, ffa ? 254 : 256};
 }
 
 bool mfma_fwd_supported(int Cin, int Cout, int K, int pad) {
