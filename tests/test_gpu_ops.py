@@ -181,20 +181,23 @@ def test_conv_fast_fir_tile_edges(hip, oracle, Co, Lin):
     np.testing.assert_allclose(host(dx), oracle.conv1d_bwd_data(dy, w, Lin, 7), rtol=2e-5, atol=6e-5)
 
 
-@pytest.mark.parametrize("N,Co,Lin", [(1, 128, 1), (1, 128, 2), (2, 128, 63), (1, 256, 64), (3, 128, 65), (5, 256, 125), (2, 128, 129),
-                                      (40, 128, 33)])
-def test_conv_fast_fir_weight_grad_edges(hip, oracle, N, Co, Lin):
+@pytest.mark.parametrize("N,Co,Lin,Ci", [(1, 128, 1, 128), (1, 128, 2, 128), (2, 128, 63, 128), (1, 256, 64, 128), (3, 128, 65, 128),
+                                         (5, 256, 125, 128), (2, 128, 129, 128), (40, 128, 33, 128),
+                                         # channel counts whose column families do not fill whole 128-column tiles
+                                         (3, 128, 70, 136), (2, 128, 100, 192), (2, 256, 61, 256), (2, 128, 90, 129)])
+def test_conv_fast_fir_weight_grad_edges(hip, oracle, N, Co, Lin, Ci):
     """128-channel layers take the transposed split for the weight gradient (conv1d_mfma_wgrad_ffa_kernel: column families
     U / V / G, dW[2j] = U[j] - G[j], dW[2j+1] = V[j] + G[j+1]; V pairs dY[2m] with dY[2m-1] INSIDE a 64-step stage, whose
     first and last pair are half empty).  Ragged rows, single stages, fewer stages than slabs; smooth non-negative x."""
     from ecg_hip import _lib as L
-    Ci = 128
-    rng = np.random.default_rng(N * 100000 + Co * 100 + Lin)
+    assert L.query("ecg_conv1d_multiplies_per_output_pair", 2, Ci, Co, 15, 7) == 23
+    rng = np.random.default_rng(N * 100000 + Co * 100 + Lin + Ci)
     x = np.maximum(np.cumsum(rng.standard_normal((N, Ci, Lin)), axis=2) * 0.3 + 0.5, 0).astype(np.float32)
     dy = rng.standard_normal((N, Co, Lin)).astype(np.float32)
     w = (rng.standard_normal((Co, Ci, 15)) / np.sqrt(Ci * 15)).astype(np.float32)
     _, w_bwd = hip.conv1d_pack(dev(w))
-    ldy = L.query("ecg_conv1d_dy_row_stride", N, Ci, Co, Lin, 15, 7, 1)
+    # (padded rows only when the input gradient — if it is wanted — reads them too: its MFMA kernel needs C_in % 32 == 0)
+    ldy = L.query("ecg_conv1d_dy_row_stride", N, Ci, Co, Lin, 15, 7, 1 if Ci % 32 == 0 else 0)
     assert ldy % 64 == 0 and ldy >= Lin
     dyp = np.zeros((N, Co, ldy), np.float32)
     dyp[:, :, :Lin] = dy
