@@ -429,7 +429,13 @@ __global__ __launch_bounds__(256, 2) void conv1d_mfma_fwd_kernel(
 // by a few ulp of the accumulated magnitude (tests state the bounds: test_conv_fast_fir_error_by_signal_class).  Inference epilogues: the pooling pair (2m, 2m + 1) sits in ONE
 // lane, so BatchNorm + ReLU + MaxPool(2) is three VALU operations per pair and the pooled row leaves as contiguous dwords.
 #ifndef ECG_FFA_MINB
-#define ECG_FFA_MINB 2
+#define ECG_FFA_MINB 2       // workgroups per CU the register allocation aims at (4: 128 registers, spills; measured slower)
+#endif
+#ifndef ECG_FFA_MINUS
+#define ECG_FFA_MINUS 1      // third product on differences (0: the textbook sum form, A/B only — fails the trajectory bars)
+#endif
+#ifndef ECG_FFA_CIC
+#define ECG_FFA_CIC 8        // input channels per chunk on long reductions (4: every layer as the short ones)
 #endif
 template <int CO_T, int M_T, int WCO, int WT, int EPI, int CI_C = 4>
 __global__ __launch_bounds__(256, ECG_FFA_MINB) void conv1d_mfma_ffa_kernel(
@@ -460,6 +466,7 @@ __global__ __launch_bounds__(256, ECG_FFA_MINB) void conv1d_mfma_ffa_kernel(
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int half = lane >> 5, l31 = lane & 31;
+    ECG_STAMP_AT(0);
     const int CT = Cout / CO_T;
     const int tile = xcd_chunked(blockIdx.x, gridDim.x);
     const int tile_co = tile % CT, tile_nt = tile / CT;
@@ -532,6 +539,7 @@ __global__ __launch_bounds__(256, ECG_FFA_MINB) void conv1d_mfma_ffa_kernel(
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    ECG_STAMP_AT(1);
 
     typedef float f32x2t __attribute__((ext_vector_type(2)));
     for (int c = 0; c < nchunks; ++c) {
@@ -566,9 +574,6 @@ __global__ __launch_bounds__(256, ECG_FFA_MINB) void conv1d_mfma_ffa_kernel(
             } else if (st < 2 * XLOADS + DPW) {
                 if (do_next2) load_x(st - XLOADS - DPW, ci_next2);
             }
-#ifndef ECG_FFA_MINUS
-#define ECG_FFA_MINUS 1
-#endif
             const float wc = ECG_FFA_MINUS ? wa_c - wprev[cp] : wa_c + wprev[cp];
             const float xc = ECG_FFA_MINUS ? xq_c[0] - xq_c[1] : xq_c[0] + xq_c[1];
             __builtin_amdgcn_sched_barrier(0);
@@ -585,11 +590,13 @@ __global__ __launch_bounds__(256, ECG_FFA_MINB) void conv1d_mfma_ffa_kernel(
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
+        if (c == 0) ECG_STAMP_AT(2);
     }
     if (FL) {
 #pragma unroll
         for (int a = 0; a < 3; ++a) acc[a] = acc2[a];
     }
+    ECG_STAMP_AT(3);
 
     // ---- epilogue -------------------------------------------------------------------------------------
     __builtin_amdgcn_s_waitcnt(0x0F70);        // vmcnt(0) (see the kernel above)
@@ -676,6 +683,10 @@ __global__ __launch_bounds__(256, ECG_FFA_MINB) void conv1d_mfma_ffa_kernel(
             partials[((size_t)(co0 + col) * P + pidx) * 2 + w] = s2;
         }
     }
+#ifdef ECG_STAMP
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the stores of the epilogue have left the wave
+#endif
+    ECG_STAMP_AT(4);
 }
 
 struct FwdCfg { int co_t, t_t, stride; };     // stride: distance of the t tiles (fast-FIR kernel: t_t - 2)
@@ -717,9 +728,6 @@ static void launch_fwd(const float *x, const float *wp, const float *bias, float
         // adds: the same error budget (tools/wgrad_error.py) — at two instead of three workgroups per CU (70 KB of LDS).
         // Same box: 128 channels 236.5 -> 227.2 / 219.6 -> 208.8 us (forward / input gradient), 64: 125.2 -> 124.5 / 116.8 -> 113.1,
         // 32: 69.4 -> 69.8 (stays at four).
-#ifndef ECG_FFA_CIC
-#define ECG_FFA_CIC 8
-#endif
 #define ECG_FFA(MODE, EV) do { \
         if (ECG_FFA_CIC == 8 && CO_T == 64 && Cin % 8 == 0 && Cin >= 64) \
             hipLaunchKernelGGL((conv1d_mfma_ffa_kernel<CO_T, T_T / 2, WCO, WT, MODE, (CO_T == 64 ? 8 : 4)>), grid, block, 0, st, x, wp, \
@@ -1396,6 +1404,7 @@ __global__ __launch_bounds__(256, 2) void conv1d_mfma_wgrad_ffa_kernel(
     static_assert(2 * IMG * 4 <= 80 * 1024, "two workgroups per CU");
 
     __shared__ __attribute__((aligned(1024))) float lds[2 * IMG];
+    ECG_STAMP_AT(0);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int half = lane >> 5, l31 = lane & 31;
@@ -1487,6 +1496,7 @@ __global__ __launch_bounds__(256, 2) void conv1d_mfma_wgrad_ffa_kernel(
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    ECG_STAMP_AT(1);
 
     typedef float f32x2t __attribute__((ext_vector_type(2)));
     const int aoff = (wm0 + l31) * T_T, swz = (l31 & 15) << 2;
@@ -1596,9 +1606,16 @@ __global__ __launch_bounds__(256, 2) void conv1d_mfma_wgrad_ffa_kernel(
         asm volatile("s_waitcnt vmcnt(%0)" :: "n"(XLOADS) : "memory");    // the DMA pieces are older than the x loads
         __syncthreads();
     };
-    if (fam == 0) { for (int it = 0; it < total; ++it) stage(std::integral_constant<int, 0>{}, it); }
-    else if (fam == 1) { for (int it = 0; it < total; ++it) stage(std::integral_constant<int, 1>{}, it); }
-    else { for (int it = 0; it < total; ++it) stage(std::integral_constant<int, 2>{}, it); }
+    if (fam == 0) { for (int it = 0; it < total; ++it) { stage(std::integral_constant<int, 0>{}, it); if (it == 0) ECG_STAMP_AT(2); } }
+    else if (fam == 1) { for (int it = 0; it < total; ++it) { stage(std::integral_constant<int, 1>{}, it); if (it == 0) ECG_STAMP_AT(2); } }
+    else { for (int it = 0; it < total; ++it) { stage(std::integral_constant<int, 2>{}, it); if (it == 0) ECG_STAMP_AT(2); } }
+    ECG_STAMP_AT(3);
+#ifdef ECG_STAMP
+    if (g_stamps && threadIdx.x == 0)          // stages | HW_ID << 16 | XCC_ID << 48 (as the direct kernel)
+        g_stamps[(size_t)blockIdx.x * 8 + 5] = (unsigned long long)(total & 0xFFFF) |
+            ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) << 16) |
+            ((unsigned long long)(__builtin_amdgcn_s_getreg((31 << 11) | 20) & 0xF) << 48);
+#endif
 
     if (FL) {
 #pragma unroll
@@ -1632,6 +1649,10 @@ __global__ __launch_bounds__(256, 2) void conv1d_mfma_wgrad_ffa_kernel(
         for (int i = 0; i < MC; ++i)
             slab[(size_t)S * wslab + (size_t)s * Cout + co0 + wm0 + 32 * i + l31] = bsum[i];
     }
+#ifdef ECG_STAMP
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+    ECG_STAMP_AT(4);
 }
 
 // dw[co][ci][k] from the S slabs of the kernel above: one lane per (co, ci, tap pair j) forms dW[2j] = U[j] - G[j] and

@@ -5,9 +5,7 @@ start / end of prologue / end of first chunk / end of main loop / end of epilogu
 in microseconds (s_memtime ticks at the shader clock; s_memrealtime, 100 MHz, anchors it).  --bf16 stamps the
 mixed-precision forward kernel, --long uses 12x5000 windows, --wgrad stamps the fp32 weight-gradient kernel (start / end of
 prologue / end of first stage / end of the stage loop / slab written; stages per workgroup in slot 5).
-The stamps sit in the DIRECT-form kernels (conv1d_mfma_fwd_kernel, conv1d_mfma_wgrad_dma_kernel): since the fast-FIR kernels took over
-the forward path (round 5) build the diagnostic library with them switched off to stamp that form:
-    make -C ptbxl-multimodal_amd/csrc STAMP=1 EXTRA='-DECG_FWD_FFA=0 -DECG_WG_FFA=0'
+The fast-FIR kernels (round 5) carry the same stamps; EXTRA='-DECG_FWD_FFA=0 -DECG_WG_FFA=0' on the make line stamps the direct form.
 """
 import ctypes
 import json
