@@ -280,6 +280,7 @@ def roofline_of(rows):
     return {"kernel": r["entry"], "op": r["op"], "avg_ms": round(r["avg_us"] / 1e3, 4), "bound": "mfma",
             "achieved": r["tflops"], "peak": r["peak"], "unit": "TFLOP/s", "frac": r["frac"],
             "multiplies_per_output_pair": r.get("multiplies_per_output_pair"), "pipe_frac": r.get("pipe_frac"),
+            "frac_is": "algorithmic: the op's 30 multiplies per output pair; the fast-FIR kernels issue 23 (pipe_frac), so frac may pass 1",
             "traffic": r["traffic_bytes_from_profile"], "traffic_over_algorithmic": r["traffic_over_algorithmic"],
             "traffic_source": r["traffic_source_short"],
             "algorithmic_flops": r["algorithmic_flops"], "algorithmic_bytes": r["algorithmic_bytes"],
