@@ -434,10 +434,10 @@ __global__ __launch_bounds__(256, 2) void conv1d_mfma_fwd_kernel(
 #ifndef ECG_FFA_MINUS
 #define ECG_FFA_MINUS 1      // third product on differences (0: the textbook sum form, A/B only — fails the trajectory bars)
 #endif
-#ifndef ECG_FFA_CIC
-#define ECG_FFA_CIC 8        // input channels per chunk on long reductions (4: every layer as the short ones)
+#ifndef ECG_FFA_FLP2
+#define ECG_FFA_FLP2 64      // one second-level add per TWO chunks where C_in % 8 == 0 and C_in >= this (0: per chunk everywhere)
 #endif
-template <int CO_T, int M_T, int WCO, int WT, int EPI, int CI_C = 4>
+template <int CO_T, int M_T, int WCO, int WT, int EPI, int CI_C = 4, int FLP = 1>
 __global__ __launch_bounds__(256, ECG_FFA_MINB) void conv1d_mfma_ffa_kernel(
     const float *__restrict__ x, const float *__restrict__ wp, const float *__restrict__ bias,
     float *__restrict__ y, float *__restrict__ partials, int Cin, int Cout, int L, int ldx, int Lo,
@@ -542,7 +542,9 @@ __global__ __launch_bounds__(256, ECG_FFA_MINB) void conv1d_mfma_ffa_kernel(
     ECG_STAMP_AT(1);
 
     typedef float f32x2t __attribute__((ext_vector_type(2)));
-    for (int c = 0; c < nchunks; ++c) {
+    // FLP = 2: a first-level sum runs over TWO chunks (OPEN starts it from zero, CLOSE adds it to the second level)
+    auto chunk = [&](int c, auto open_c, auto close_c) {
+        constexpr bool OPEN = decltype(open_c)::value, CLOSE = decltype(close_c)::value;
         const float *ws = lds + (c & 1) * IMG, *xs = ws + WPAD;
         float *nxt = lds + ((c + 1) & 1) * IMG;
         const bool do_next = c + 1 < nchunks, do_next2 = c + 2 < nchunks;
@@ -577,20 +579,29 @@ __global__ __launch_bounds__(256, ECG_FFA_MINB) void conv1d_mfma_ffa_kernel(
             const float wc = ECG_FFA_MINUS ? wa_c - wprev[cp] : wa_c + wprev[cp];
             const float xc = ECG_FFA_MINUS ? xq_c[0] - xq_c[1] : xq_c[0] + xq_c[1];
             __builtin_amdgcn_sched_barrier(0);
-            acc[0] = mfma32(wa_c, xq_c[0], (FL && j == 0 && cp == 0) ? zero16 : acc[0]);
-            if (2 * j + 1 < KK) acc[1] = mfma32(wb_c, xq_c[1], (FL && j == 0 && cp == 0) ? zero16 : acc[1]);
-            acc[2] = mfma32(wc, xc, (FL && j == 0 && cp == 0) ? zero16 : acc[2]);
+            acc[0] = mfma32(wa_c, xq_c[0], (FL && OPEN && j == 0 && cp == 0) ? zero16 : acc[0]);
+            if (2 * j + 1 < KK) acc[1] = mfma32(wb_c, xq_c[1], (FL && OPEN && j == 0 && cp == 0) ? zero16 : acc[1]);
+            acc[2] = mfma32(wc, xc, (FL && OPEN && j == 0 && cp == 0) ? zero16 : acc[2]);
             __builtin_amdgcn_sched_barrier(0);
             wprev[cp] = wb_c;
             wa_c = wa_n; wb_c = wb_n; xq_c = xq_n;
         }
-        if (FL) {
+        if (FL && CLOSE) {
 #pragma unroll
             for (int a = 0; a < 3; ++a) acc2[a] += acc[a];
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (c == 0) ECG_STAMP_AT(2);
+    };
+    {
+        const std::true_type yes{};
+        const std::false_type no{};
+        int c = 0;
+        if (FLP == 2) {
+            for (; c + 1 < nchunks; c += 2) { chunk(c, yes, no); chunk(c + 1, no, yes); }
+        }
+        for (; c < nchunks; ++c) chunk(c, yes, yes);
     }
     if (FL) {
 #pragma unroll
@@ -723,14 +734,16 @@ static void launch_fwd(const float *x, const float *wp, const float *bias, float
         dim3 grid((unsigned)((size_t)tiles_t * (Cout / CO_T) * N)), block(256);
         const int P = N * tiles_t;
         const EvalEpi none{nullptr, nullptr, nullptr, nullptr, 0.f, 0};
-        // Chunks of EIGHT input channels where the reduction is long (C_in >= 64, 64-channel tiles): one barrier and one
-        // second-level add per 92 MFMAs instead of 46 — first-level chains of 64 instead of 32 terms, half as many second-level
-        // adds: the same error budget (tools/wgrad_error.py) — at two instead of three workgroups per CU (70 KB of LDS).
-        // Same box: 128 channels 236.5 -> 227.2 / 219.6 -> 208.8 us (forward / input gradient), 64: 125.2 -> 124.5 / 116.8 -> 113.1,
-        // 32: 69.4 -> 69.8 (stays at four).
+        // One second-level add per TWO four-channel chunks where the reduction is long (C_in % 8 == 0, C_in >= 64): first-level chains
+        // of 64 instead of 32 terms, half as many second-level adds — the add (three accumulator sets behind the last MFMAs of a
+        // chunk) is what a chunk boundary costs, not its barrier.  Same box, forward + input gradient of the four blocks against
+        // eight-channel chunks with one add each (70 KB of LDS: two workgroups per CU; this form keeps three): 845.6 -> 832.8 us at
+        // 12x1000, 3 737.6 -> 3 643.3 at 12x5000.  NOT on the 32-channel reduction of block 1's forward (another -9 / -31 us): its y
+        // error against float64 goes 0.56 -> 0.69 of the CPU fp32 path's and the trajectory test fails its bars (drift 1.28x /
+        // 2.76x the CPU's at B = 32 / 256; with the threshold at 64: 0.41x / 0.39x) — EXPERIMENTS I5.
 #define ECG_FFA(MODE, EV) do { \
-        if (ECG_FFA_CIC == 8 && CO_T == 64 && Cin % 8 == 0 && Cin >= 64) \
-            hipLaunchKernelGGL((conv1d_mfma_ffa_kernel<CO_T, T_T / 2, WCO, WT, MODE, (CO_T == 64 ? 8 : 4)>), grid, block, 0, st, x, wp, \
+        if (ECG_FFA_FLP2 && Cin % 8 == 0 && Cin >= ECG_FFA_FLP2) \
+            hipLaunchKernelGGL((conv1d_mfma_ffa_kernel<CO_T, T_T / 2, WCO, WT, MODE, 4, 2>), grid, block, 0, st, x, wp, \
                                bias, y, partials, Cin, Cout, L, ldx, Lo, pad, P, tiles_t, EV); \
         else \
             hipLaunchKernelGGL((conv1d_mfma_ffa_kernel<CO_T, T_T / 2, WCO, WT, MODE>), grid, block, 0, st, x, wp, bias, y, \
