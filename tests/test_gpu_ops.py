@@ -181,6 +181,23 @@ def test_conv_fast_fir_tile_edges(hip, oracle, Co, Lin):
     np.testing.assert_allclose(host(dx), oracle.conv1d_bwd_data(dy, w, Lin, 7), rtol=2e-5, atol=6e-5)
 
 
+def test_conv_forward_without_bias(hip, oracle):
+    """The ABI takes a null bias (the reference's layers all have one; a caller's Conv1d(bias=False) does not): plain and statistics
+    epilogues of the MFMA forward, and the generic direct kernel."""
+    rng = np.random.default_rng(11)
+    for (N, Ci, Co, Lin) in [(2, 32, 64, 130), (3, 12, 32, 300), (2, 7, 5, 40)]:
+        x = rng.standard_normal((N, Ci, Lin)).astype(np.float32)
+        w = (rng.standard_normal((Co, Ci, 15)) / np.sqrt(Ci * 15)).astype(np.float32)
+        w_fwd, _ = hip.conv1d_pack(dev(w), need_bwd=False)
+        ry = oracle.conv1d_fwd(x, w, np.zeros(Co, np.float32), 7)
+        y0, _, _ = hip.conv1d_forward_raw(dev(x), w_fwd, None, Co, 15, 7, want_stats=False)
+        np.testing.assert_allclose(host(y0), ry, rtol=2e-5, atol=3e-5)
+        y1, partials, P = hip.conv1d_forward_raw(dev(x), w_fwd, None, Co, 15, 7, want_stats=True)
+        np.testing.assert_array_equal(host(y1), host(y0))
+        part = host(partials).reshape(Co, P, 2).astype(np.float64)
+        np.testing.assert_allclose(part[:, :, 0].sum(1), host(y1).astype(np.float64).sum((0, 2)), rtol=1e-6, atol=1e-4)
+
+
 @pytest.mark.parametrize("N,Co,Lin,Ci", [(1, 128, 1, 128), (1, 128, 2, 128), (2, 128, 63, 128), (1, 256, 64, 128), (3, 128, 65, 128),
                                          (5, 256, 125, 128), (2, 128, 129, 128), (40, 128, 33, 128),
                                          # channel counts whose column families do not fill whole 128-column tiles
